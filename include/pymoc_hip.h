@@ -1,0 +1,127 @@
+/*
+ * pymoc_hip.h -- C-ABI of libpymoc_hip.so, the MI355X (gfx950) engine behind the
+ * PyMOC timestep() path.
+ *
+ * The reference (pymoc 0.0.1rc5) has no FFI of its own: its boundary is the Python
+ * object API of four classes.  Every entry point below therefore names the Python
+ * method (reference file:line, relative to the reference checkout) whose arithmetic
+ * it replaces; the ctypes binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Pointers inside the pm_* batch
+ *     structs are DEVICE pointers obtained from pm_malloc(); everything else
+ *     (the struct itself, host buffers of pm_memcpy_*) lives in host memory.
+ *   - all floating point data is IEEE fp64; index/flag data is int32.
+ *   - batches are "ensemble-major": a field of a batch of n independent members is
+ *     one dense array [n][nlev], level fastest.
+ *   - every function returns PM_OK (0) or an error code; pm_last_error() gives the
+ *     text.  Kernel launches are asynchronous on the given stream (NULL = the
+ *     library's default stream); pm_stream_sync / pm_memcpy_d2h are sync points.
+ *   - no host pointer is retained after a call returns.
+ */
+#ifndef PYMOC_HIP_H
+#define PYMOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_OK 0
+#define PM_EINVAL 1     /* bad argument (shape, NULL pointer, unsupported size)  */
+#define PM_EHIP 2       /* a HIP runtime call failed                              */
+#define PM_ENCCL 3      /* an RCCL call failed / librccl could not be loaded      */
+#define PM_ENODEV 4     /* no HIP device visible                                  */
+
+typedef void *pm_stream_t;
+typedef void *pm_event_t;
+typedef void *pm_comm_t;
+typedef void *pm_graph_t;
+
+/* ------------------------------------------------------------------ runtime */
+const char *pm_version(void);
+const char *pm_last_error(void);
+int pm_device_count(int *count);
+int pm_set_device(int device);
+int pm_device_info(char *name, size_t name_len, int *compute_units,
+                   size_t *hbm_bytes, int *clock_mhz);
+
+int pm_malloc(void **dptr, size_t bytes);
+int pm_free(void *dptr);
+int pm_memset(void *dptr, int value, size_t bytes, pm_stream_t stream);
+int pm_memcpy_h2d(void *dst, const void *src, size_t bytes, pm_stream_t stream);
+int pm_memcpy_d2h(void *dst, const void *src, size_t bytes, pm_stream_t stream);
+int pm_memcpy_d2d(void *dst, const void *src, size_t bytes, pm_stream_t stream);
+
+int pm_stream_create(pm_stream_t *stream);
+int pm_stream_destroy(pm_stream_t stream);
+int pm_stream_sync(pm_stream_t stream);
+int pm_device_sync(void);
+
+int pm_event_create(pm_event_t *event);
+int pm_event_destroy(pm_event_t event);
+int pm_event_record(pm_event_t event, pm_stream_t stream);
+int pm_event_sync(pm_event_t event);
+int pm_event_elapsed_ms(pm_event_t start, pm_event_t stop, float *ms);
+
+/* hipGraph capture of a launch sequence issued on `stream` */
+int pm_graph_begin_capture(pm_stream_t stream);
+int pm_graph_end_capture(pm_stream_t stream, pm_graph_t *graph);
+int pm_graph_launch(pm_graph_t graph, pm_stream_t stream);
+int pm_graph_destroy(pm_graph_t graph);
+
+/* ------------------------------------------------------------------ Column
+ * Replaces pymoc.modules.Column time stepping:
+ *   Column.convect       src/pymoc/modules/column.py:251-271
+ *   Column.vertadvdiff   src/pymoc/modules/column.py:210-249
+ *   Column.horadv        src/pymoc/modules/column.py:288-313
+ *   Column.timestep      src/pymoc/modules/column.py:315-348  (order: convect,
+ *                        vertadvdiff, horadv)
+ * A batch is ncols independent columns on ONE shared vertical grid z[nz].
+ */
+#define PM_COL_DO_CONV 1   /* per-column flag: timestep(do_conv=True)             */
+#define PM_COL_BZBOT 2     /* per-column flag: bzbot is not None (column.py:232)  */
+
+#define PM_OP_CONVECT 1      /* run convect() on columns flagged PM_COL_DO_CONV   */
+#define PM_OP_VERTADVDIFF 2  /* run vertadvdiff(wA, dt, do_conv=flag)             */
+#define PM_OP_HORADV 4       /* run horadv(vdx_in, b_in, dt)                      */
+#define PM_OP_TIMESTEP 7     /* what Column.timestep does (horadv iff vdx given)  */
+
+typedef struct pm_columns {
+  int32_t ncols;         /* independent columns in the batch                      */
+  int32_t nz;            /* levels per column (2 <= nz <= 1024)                   */
+  int32_t nsel;          /* coefficient sets per column (1, or 2 for JN2018)      */
+  int32_t reserved;
+  const double *z;       /* [nz]              shared grid, ascending              */
+  double *b;             /* [ncols][nz]       buoyancy, updated in place          */
+  const double *kappa;   /* [nsel][ncols][nz] kappa(z)                            */
+  const double *area;    /* [ncols][nz]       Area(z)                             */
+  const double *dAkappa; /* [nsel][ncols][nz] np.gradient(Area*kappa, z)          */
+  const double *bs;      /* [ncols] surface buoyancy                              */
+  const double *bbot;    /* [ncols] bottom buoyancy (used unless PM_COL_BZBOT)    */
+  const double *bzbot;   /* [ncols] bottom stratification (may be NULL)           */
+  const double *N2min;   /* [ncols] convective-adjustment stratification          */
+  const int32_t *flags;  /* [ncols] PM_COL_* bits                                 */
+  const int32_t *ksel;   /* [ncols] coefficient set in use (NULL -> set 0)        */
+  int32_t *nonfinite;    /* [ncols] out: 1 if b holds a non-finite value at the
+                            end of the call (NULL -> not reported)                */
+} pm_columns;
+
+/* nsteps repetitions of the selected ops with wA (and vdx_in/b_in) held fixed, the
+ * whole loop fused in one launch with b resident in registers.
+ *   wA      [ncols][nz]  m^3/s
+ *   vdx_in  [ncols][nz]  or NULL; b_in [ncols][nz] required when vdx_in given
+ *   lanes_per_col  16, 32 or 64 lanes cooperate on one column; 0 = choose        */
+int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_in,
+                    const double *b_in, double dt, int32_t nsteps, int32_t ops,
+                    int32_t lanes_per_col, pm_stream_t stream);
+
+/* debug/test: lane-shift primitive self check (DPP wave shifts vs ds_bpermute) */
+int pm_selftest_lane_shift(int32_t *mismatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYMOC_HIP_H */

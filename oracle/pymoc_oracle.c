@@ -1,0 +1,756 @@
+/*
+ * pymoc_oracle.c -- CPU ORACLE.  TEST INFRASTRUCTURE, NOT PRODUCT (see pymoc_oracle.h).
+ *
+ * Plain C99, scalar, one member at a time -- written for clarity and for agreement
+ * with the reference's arithmetic (operation order follows the Python expressions
+ * cited at each function), not for speed.  Build: gcc -O2 -ffp-contract=off -fPIC -shared.
+ */
+#include "pymoc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ============================================================================
+ * NumPy primitives
+ * ========================================================================== */
+
+/* numpy/_core/src/multiarray/compiled_base.c: binary_search_with_guess().
+ * Returns j with xp[j] <= key < xp[j+1]; -1 / len outside the range.  The guess
+ * logic is kept so that even unsorted xp (np.interp does not check) agree. */
+static long interp_search(double key, const double *arr, long len, long guess) {
+  long imin = 0, imax = len;
+  if (key > arr[len - 1]) return len;
+  if (key < arr[0]) return -1;
+  if (len <= 4) {
+    long i = 1;
+    while (i < len && key >= arr[i]) ++i;
+    return i - 1;
+  }
+  if (guess > len - 3) guess = len - 3;
+  if (guess < 1) guess = 1;
+  if (key < arr[guess]) {
+    if (key < arr[guess - 1]) {
+      imax = guess - 1;
+      if (guess > 8 && key >= arr[guess - 8]) imin = guess - 8;
+    } else {
+      return guess - 1;
+    }
+  } else {
+    if (key < arr[guess + 1]) return guess;
+    if (key < arr[guess + 2]) return guess + 1;
+    imin = guess + 2;
+    if (guess < len - 8 - 1 && key < arr[guess + 8]) imax = guess + 8;
+  }
+  while (imin < imax) {
+    const long imid = imin + ((imax - imin) >> 1);
+    if (key >= arr[imid])
+      imin = imid + 1;
+    else
+      imax = imid;
+  }
+  return imin - 1;
+}
+
+/* np.interp(x, xp, fp) with default left/right (= fp[0], fp[-1]). */
+void orc_np_interp(const double *x, int nx, const double *xp, const double *fp, int nxp,
+                   double *out) {
+  const double lval = fp[0], rval = fp[nxp - 1];
+  if (nxp == 1) {
+    for (int i = 0; i < nx; ++i) {
+      const double xv = x[i];
+      out[i] = (xv < xp[0]) ? lval : ((xv > xp[0]) ? rval : fp[0]);
+    }
+    return;
+  }
+  long j = 0;
+  for (int i = 0; i < nx; ++i) {
+    const double xv = x[i];
+    if (isnan(xv)) {
+      out[i] = xv;
+      continue;
+    }
+    j = interp_search(xv, xp, nxp, j);
+    if (j == -1) {
+      out[i] = lval;
+    } else if (j == nxp) {
+      out[i] = rval;
+    } else if (j == nxp - 1) {
+      out[i] = fp[j];
+    } else if (xp[j] == xv) {
+      out[i] = fp[j]; /* avoids non-finite interpolation */
+    } else {
+      const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+      double r = slope * (xv - xp[j]) + fp[j];
+      if (isnan(r)) { /* nan in one direction: try the other */
+        r = slope * (xv - xp[j + 1]) + fp[j + 1];
+        if (isnan(r) && fp[j] == fp[j + 1]) r = fp[j];
+      }
+      out[i] = r;
+    }
+  }
+}
+
+/* np.gradient(f, x) for 1-D coordinates, edge_order=1
+ * (numpy/lib/_function_base_impl.py: gradient). */
+void orc_np_gradient(const double *f, const double *x, int n, double *out) {
+  if (n < 2) return;
+  int uniform = 1;
+  const double d0 = x[1] - x[0];
+  for (int i = 1; i < n - 1; ++i)
+    if ((x[i + 1] - x[i]) != d0) uniform = 0;
+  for (int i = 1; i < n - 1; ++i) {
+    if (uniform) {
+      out[i] = (f[i + 1] - f[i - 1]) / (2. * d0);
+    } else {
+      const double dx1 = x[i] - x[i - 1], dx2 = x[i + 1] - x[i];
+      const double a = -(dx2) / (dx1 * (dx1 + dx2));
+      const double b = (dx2 - dx1) / (dx1 * dx2);
+      const double c = dx1 / (dx2 * (dx1 + dx2));
+      out[i] = a * f[i - 1] + b * f[i] + c * f[i + 1];
+    }
+  }
+  out[0] = (f[1] - f[0]) / (x[1] - x[0]);
+  out[n - 1] = (f[n - 1] - f[n - 2]) / (x[n - 1] - x[n - 2]);
+}
+
+/* np.add.reduce on a contiguous double vector: pairwise summation
+ * (numpy/_core/src/umath/loops_utils.h.src: DOUBLE_pairwise_sum). */
+static double pairwise_sum(const double *a, long n) {
+  if (n < 8) {
+    double res = 0.;
+    for (long i = 0; i < n; ++i) res += a[i];
+    return res;
+  } else if (n <= 128) {
+    double r[8];
+    long i;
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  } else {
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2);
+  }
+}
+double orc_np_sum(const double *a, int n) { return pairwise_sum(a, n); }
+
+/* np.linspace(start, stop, num) (numpy/_core/function_base.py). */
+void orc_np_linspace(double start, double stop, int num, double *out) {
+  if (num <= 0) return;
+  const int div = num - 1;
+  const double delta = stop - start;
+  if (div > 0) {
+    const double step = delta / div;
+    for (int i = 0; i < num; ++i) {
+      if (step == 0.)
+        out[i] = ((double)i / div) * delta + start;
+      else
+        out[i] = (double)i * step + start;
+    }
+    out[num - 1] = stop;
+  } else {
+    out[0] = start;
+  }
+}
+
+/* scipy/optimize/Zeros/brentq.c with the Python defaults xtol=2e-12,
+ * rtol=4*eps, maxiter=100, applied to g(y) = np.interp(y, xp, fp) - target. */
+static double interp1(double xv, const double *xp, const double *fp, int nxp) {
+  double r;
+  orc_np_interp(&xv, 1, xp, fp, nxp, &r);
+  return r;
+}
+double orc_brentq_interp(const double *xp, const double *fp, int nxp, double target,
+                         double xa, double xb, int *status) {
+  const double xtol = 2e-12, rtol = 8.881784197001252e-16;
+  const int maxiter = 100;
+  double xpre = xa, xcur = xb, xblk = 0., fblk = 0., spre = 0., scur = 0.;
+  double fpre = interp1(xpre, xp, fp, nxp) - target;
+  double fcur = interp1(xcur, xp, fp, nxp) - target;
+  if (status) *status = 0;
+  if (fpre == 0) return xpre;
+  if (fcur == 0) return xcur;
+  if (signbit(fpre) == signbit(fcur)) {
+    if (status) *status = -1;
+    return 0.;
+  }
+  for (int it = 0; it < maxiter; ++it) {
+    if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
+      xblk = xpre;
+      fblk = fpre;
+      spre = scur = xcur - xpre;
+    }
+    if (fabs(fblk) < fabs(fcur)) {
+      xpre = xcur;
+      xcur = xblk;
+      xblk = xpre;
+      fpre = fcur;
+      fcur = fblk;
+      fblk = fpre;
+    }
+    const double delta = (xtol + rtol * fabs(xcur)) / 2;
+    const double sbis = (xblk - xcur) / 2;
+    if (fcur == 0 || fabs(sbis) < delta) return xcur;
+    if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+      double stry;
+      if (xpre == xblk) {
+        stry = -fcur * (xcur - xpre) / (fcur - fpre); /* secant */
+      } else {                                        /* inverse quadratic */
+        const double dpre = (fpre - fcur) / (xpre - xcur);
+        const double dblk = (fblk - fcur) / (xblk - xcur);
+        stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+      }
+      const double lim1 = fabs(spre), lim2 = 3 * fabs(sbis) - delta;
+      if (2 * fabs(stry) < (lim1 < lim2 ? lim1 : lim2)) {
+        spre = scur;
+        scur = stry;
+      } else {
+        spre = sbis;
+        scur = sbis;
+      }
+    } else {
+      spre = sbis;
+      scur = sbis;
+    }
+    xpre = xcur;
+    fpre = fcur;
+    if (fabs(scur) > delta)
+      xcur += scur;
+    else
+      xcur += (sbis > 0 ? delta : -delta);
+    fcur = interp1(xcur, xp, fp, nxp) - target;
+  }
+  if (status) *status = -2;
+  return xcur;
+}
+
+/* ============================================================================
+ * Column   (src/pymoc/modules/column.py)
+ * ========================================================================== */
+
+/* Column.convect, column.py:251-271 */
+void orc_column_convect(const double *z, double *b, int nz, double bs, double N2min) {
+  int any = 0, any_not = 0;
+  double zconv = z[0];
+  for (int i = 0; i < nz; ++i) {
+    if (b[i] > bs) {
+      any = 1;
+    } else {
+      if (!any_not || z[i] > zconv) zconv = z[i]; /* np.max(z[~ind]) */
+      any_not = 1;
+    }
+  }
+  if (any) {
+    if (!any_not) zconv = z[0];
+    for (int i = 0; i < nz; ++i)
+      if (b[i] > bs) b[i] = bs + N2min * (z[i] - zconv); /* all from the OLD b */
+  } else {
+    b[nz - 1] = bs;
+  }
+}
+
+/* Column.vertadvdiff, column.py:210-249; dAkappa_dz (column.py:96-122) is
+ * re-evaluated every call exactly as the reference does. */
+void orc_column_vertadvdiff(const double *z, const double *kappa, const double *area,
+                            double *b, int nz, const double *wA, double dt, int do_conv,
+                            double bs, double bbot, int use_bzbot, double bzbot) {
+  double *Ak = (double *)malloc(sizeof(double) * nz * 3);
+  double *dAk = Ak + nz, *bz = Ak + 2 * nz;
+  for (int i = 0; i < nz; ++i) Ak[i] = area[i] * kappa[i]; /* column.py:94 */
+  orc_np_gradient(Ak, z, nz, dAk);                         /* column.py:122 */
+  if (!do_conv) b[nz - 1] = bs;                            /* column.py:230-231 */
+  b[0] = use_bzbot ? (b[1] - bzbot * (z[1] - z[0])) : bbot; /* column.py:232-233 */
+  for (int i = 0; i < nz - 1; ++i) bz[i] = (b[i + 1] - b[i]) / (z[i + 1] - z[i]);
+  for (int i = 1; i < nz - 1; ++i) {
+    const double dzu = z[i + 1] - z[i], dzd = z[i] - z[i - 1];
+    const double bzz = (bz[i] - bz[i - 1]) / (0.5 * (dzu + dzd)); /* column.py:238 */
+    const double weff = wA[i] - dAk[i];                           /* column.py:241 */
+    const double bzu = (weff < 0) ? bz[i] : bz[i - 1];            /* column.py:242-243 */
+    const double db_dt = (-weff) * bzu / area[i] + kappa[i] * bzz; /* :245-248 */
+    Ak[i] = b[i] + dt * db_dt; /* staged: every tendency uses the old profile */
+  }
+  for (int i = 1; i < nz - 1; ++i) b[i] = Ak[i];
+  free(Ak);
+}
+
+/* Column.horadv, column.py:288-313 */
+void orc_column_horadv(const double *area, double *b, int nz, const double *vdx_in,
+                       const double *b_in, double dt) {
+  for (int i = 0; i < nz; ++i)
+    if (vdx_in[i] > 0.0) {
+      const double db = b_in[i] - b[i];
+      b[i] = b[i] + dt * vdx_in[i] * db / area[i];
+    }
+}
+
+/* Column.timestep, column.py:315-348 */
+void orc_column_timestep(const double *z, const double *kappa, const double *area,
+                         double *b, int nz, const double *wA, double dt, int do_conv,
+                         double bs, double bbot, int use_bzbot, double bzbot,
+                         double N2min, const double *vdx_in, const double *b_in) {
+  if (do_conv) orc_column_convect(z, b, nz, bs, N2min);
+  orc_column_vertadvdiff(z, kappa, area, b, nz, wA, dt, do_conv, bs, bbot, use_bzbot,
+                         bzbot);
+  if (vdx_in && b_in) orc_column_horadv(area, b, nz, vdx_in, b_in, dt);
+}
+
+void orc_column_ensemble_steps(const double *z, const double *kappa, const double *area,
+                               double *b, int ncols, int nz, const double *wA, double dt,
+                               const int *do_conv, const double *bs, const double *bbot,
+                               const double *N2min, int nsteps) {
+  for (int s = 0; s < nsteps; ++s)
+    for (int c = 0; c < ncols; ++c) {
+      const size_t o = (size_t)c * nz;
+      orc_column_timestep(z, kappa + o, area + o, b + o, nz, wA + o, dt, do_conv[c],
+                          bs[c], bbot[c], 0, 0.0, N2min[c], NULL, NULL);
+    }
+}
+
+/* ============================================================================
+ * Psi_Thermwind   (src/pymoc/modules/psi_thermwind.py)
+ * ========================================================================== */
+
+/* Psi_Thermwind.solve, psi_thermwind.py:125-135.  The reference hands
+ *   y0' = y1, y1' = (1/f)(b2(z)-b1(z)),  y0(z[0]) = y0(z[-1]) = 0
+ * to scipy.integrate.solve_bvp (4th-order Lobatto IIIA collocation on the mesh z).
+ * With np.interp profiles the right-hand side is piecewise linear, the collocation
+ * residual vanishes identically on the initial mesh (no refinement), and the
+ * collocation equations reduce to the two running integrals below. */
+void orc_thermwind_solve(const double *z, const double *b1, const double *b2, int nz,
+                         double f, double *Psi) {
+  const double rf = 1. / f; /* psi_thermwind.py:123: 1. / self.f * (...) */
+  double *g = (double *)malloc(sizeof(double) * nz * 3);
+  double *G = g + nz, *I = g + 2 * nz;
+  for (int i = 0; i < nz; ++i) g[i] = rf * (b2[i] - b1[i]);
+  G[0] = 0.;
+  I[0] = 0.;
+  for (int i = 0; i < nz - 1; ++i) {
+    const double h = z[i + 1] - z[i];
+    const double zm = z[i] + 0.5 * h;
+    /* rhs at the collocation midpoint through the same np.interp closures */
+    const double s1 = (b1[i + 1] - b1[i]) / h, s2 = (b2[i + 1] - b2[i]) / h;
+    const double b1m = s1 * (zm - z[i]) + b1[i], b2m = s2 * (zm - z[i]) + b2[i];
+    const double gm = rf * (b2m - b1m);
+    G[i + 1] = G[i] + h / 6. * (g[i] + g[i + 1] + 4. * gm);
+    const double Gm = 0.5 * (G[i] + G[i + 1]) - 0.125 * h * (g[i + 1] - g[i]);
+    I[i + 1] = I[i] + h / 6. * (G[i] + G[i + 1] + 4. * Gm);
+  }
+  const double span = z[nz - 1] - z[0];
+  for (int i = 0; i < nz; ++i)
+    Psi[i] = (I[i] - I[nz - 1] * ((z[i] - z[0]) / span)) / 1e6; /* Sv, :135 */
+  free(g);
+}
+
+static double np_clip01(double v) {
+  /* np.clip = minimum(maximum(v, 0), 1); both propagate NaN */
+  if (isnan(v)) return v;
+  v = v < 0. ? 0. : v;
+  return v > 1. ? 1. : v;
+}
+
+/* Psi_Thermwind.Psib, psi_thermwind.py:137-185 */
+void orc_thermwind_psib(const double *b1, const double *b2, const double *Psi, int nz,
+                        int nb, double *bgrid, double *psib) {
+  double bmin = b1[0], bmax = b1[0];
+  /* min(np.min(b1), np.min(b2)); np.min/np.max propagate NaN */
+  int has_nan = 0;
+  for (int i = 0; i < nz; ++i) {
+    if (isnan(b1[i]) || isnan(b2[i])) has_nan = 1;
+    if (b1[i] < bmin) bmin = b1[i];
+    if (b2[i] < bmin) bmin = b2[i];
+    if (b1[i] > bmax) bmax = b1[i];
+    if (b2[i] > bmax) bmax = b2[i];
+  }
+  if (has_nan) bmin = bmax = NAN;
+  orc_np_linspace(bmin, bmax, nb, bgrid); /* :174 */
+  const int nc = nz - 1;
+  double *u = (double *)malloc(sizeof(double) * nc * 4);
+  double *bot = u + nc, *top = u + 2 * nc, *w = u + 3 * nc;
+  for (int k = 0; k < nc; ++k) {
+    u[k] = -(Psi[k + 1] - Psi[k]); /* :175 */
+    if (u[k] < 0) {                /* :179-181 upwind: northern column */
+      bot[k] = b2[k];
+      top[k] = b2[k + 1];
+    } else {
+      bot[k] = b1[k];
+      top[k] = b1[k + 1];
+    }
+  }
+  for (int i = 0; i < nb; ++i) {
+    for (int k = 0; k < nc; ++k)
+      w[k] = np_clip01((top[k] - bgrid[i]) / (top[k] - bot[k])) * u[k]; /* :183 */
+    psib[i] = pairwise_sum(w, nc);                                      /* :184 */
+  }
+  free(u);
+}
+
+/* Psi_Thermwind.Psibz, psi_thermwind.py:187-208 */
+void orc_thermwind_psibz(const double *b1, const double *b2, const double *Psi, int nz,
+                         int nb, double *bgrid, double *psib, double *psibz1,
+                         double *psibz2) {
+  orc_thermwind_psib(b1, b2, Psi, nz, nb, bgrid, psib);
+  orc_np_interp(b1, nz, bgrid, psib, nb, psibz1);
+  orc_np_interp(b2, nz, bgrid, psib, nb, psibz2);
+}
+
+/* ============================================================================
+ * Psi_SO   (src/pymoc/modules/psi_SO.py)
+ * ========================================================================== */
+
+/* Psi_SO.ys, psi_SO.py:106-140 */
+double orc_psi_so_ys(const double *y, const double *bs, int ny, double b, int *status) {
+  double bsmin = bs[0];
+  int minind = 0;
+  for (int j = 1; j < ny; ++j)
+    if (bs[j] < bsmin) {
+      bsmin = bs[j];
+      minind = j;
+    }
+  if (status) *status = 0;
+  if (b < bsmin) return y[0] - 1e3;  /* :128-130 */
+  if (b > bs[ny - 1]) return y[ny - 1]; /* :131-133 */
+  return orc_brentq_interp(y, bs, ny, b, y[minind], y[ny - 1], status); /* :139-140 */
+}
+
+static void bottom_taper(int has, double H, const double *z, int nz, double *out) {
+  /* psi_SO.py:164-187: 1. - np.maximum(z[0] + H - z, 0.)**2. / H**2. */
+  for (int i = 0; i < nz; ++i) {
+    if (!has) {
+      out[i] = 1.;
+    } else {
+      double m = z[0] + H - z[i];
+      m = m > 0. ? m : 0.;
+      out[i] = 1. - (m * m) / (H * H);
+    }
+  }
+}
+static void top_taper(int has, double H, const double *z, int nz, int scalar,
+                      double *out) {
+  /* psi_SO.py:189-216 */
+  for (int i = 0; i < nz; ++i) {
+    if (has) {
+      double m = z[i] + H;
+      m = m > 0 ? m : 0;
+      out[i] = 1 - (m * m) / (H * H);
+    } else {
+      out[i] = 1.;
+    }
+  }
+  if (!has && !scalar) out[nz - 1] = 0.;
+}
+
+/* 4th-order (Lobatto IIIA / Simpson, the scheme of scipy.integrate.solve_bvp)
+ * collocation for  u'' = q(x) (u - T(x)),  u(x0)=ua, u(xn)=ub  with q = N2/c^2 and
+ * N2, T the np.interp closures of psi_SO.py:309-316, on the grid z refined R-fold.
+ * Eliminating u' interval by interval leaves a tridiagonal system in u. */
+static void gm_bvp(const double *z, int nz, const double *N2, const double *T, double c,
+                   double ua, double ub, int R, double *out) {
+  const int n = (nz - 1) * R + 1;
+  const double c2 = c * c;
+  double *x = (double *)malloc(sizeof(double) * (size_t)n * 8);
+  double *q = x + n, *r = x + 2 * n, *lo = x + 3 * n, *di = x + 4 * n, *up = x + 5 * n,
+         *rh = x + 6 * n, *u = x + 7 * n;
+  for (int k = 0; k < nz - 1; ++k) {
+    const double h = z[k + 1] - z[k];
+    const double sN = (N2[k + 1] - N2[k]) / h, sT = (T[k + 1] - T[k]) / h;
+    for (int j = 0; j < R; ++j) {
+      const int m = k * R + j;
+      const double xv = (j == 0) ? z[k] : z[k] + h * ((double)j / R);
+      const double n2 = (j == 0) ? N2[k] : sN * (xv - z[k]) + N2[k];
+      const double tv = (j == 0) ? T[k] : sT * (xv - z[k]) + T[k];
+      x[m] = xv;
+      q[m] = n2 / c2;
+      r[m] = q[m] * tv;
+    }
+  }
+  x[n - 1] = z[nz - 1];
+  q[n - 1] = N2[nz - 1] / c2;
+  r[n - 1] = q[n - 1] * T[nz - 1];
+  /* per-interval slope relations: S = u'_k + u'_{k+1}, D = u'_{k+1} - u'_k */
+  double *sA = (double *)malloc(sizeof(double) * (size_t)n * 6);
+  double *sB = sA + n, *sC = sA + 2 * n, *dA = sA + 3 * n, *dB = sA + 4 * n,
+         *dC = sA + 5 * n;
+  for (int m = 0; m < n - 1; ++m) {
+    const double h = x[m + 1] - x[m];
+    const int k = m / R;
+    const double xm = x[m] + 0.5 * h;
+    const double hz = z[k + 1] - z[k];
+    const double n2m = (N2[k + 1] - N2[k]) / hz * (xm - z[k]) + N2[k];
+    const double tm = (T[k + 1] - T[k]) / hz * (xm - z[k]) + T[k];
+    const double qm = n2m / c2, rm = qm * tm;
+    const double al = 1. + h * h * qm / 12.;
+    sA[m] = -(2. / h) * (1. + h * h * q[m] / 12.);
+    sB[m] = (2. / h) * (1. + h * h * q[m + 1] / 12.);
+    sC[m] = -(h / 6.) * (r[m + 1] - r[m]);
+    dA[m] = (h / 6.) * (q[m] + 2. * qm) / al;
+    dB[m] = (h / 6.) * (q[m + 1] + 2. * qm) / al;
+    dC[m] = -(h / 6.) * (r[m] + r[m + 1] + 4. * rm) / al;
+  }
+  di[0] = 1.;
+  up[0] = 0.;
+  lo[0] = 0.;
+  rh[0] = ua;
+  for (int m = 1; m < n - 1; ++m) {
+    lo[m] = -(sA[m - 1] + dA[m - 1]);
+    di[m] = (sA[m] - dA[m]) - (sB[m - 1] + dB[m - 1]);
+    up[m] = sB[m] - dB[m];
+    rh[m] = -(sC[m] - dC[m]) + (sC[m - 1] + dC[m - 1]);
+  }
+  di[n - 1] = 1.;
+  lo[n - 1] = 0.;
+  up[n - 1] = 0.;
+  rh[n - 1] = ub;
+  /* Thomas */
+  for (int m = 1; m < n; ++m) {
+    const double w = lo[m] / di[m - 1];
+    di[m] -= w * up[m - 1];
+    rh[m] -= w * rh[m - 1];
+  }
+  u[n - 1] = rh[n - 1] / di[n - 1];
+  for (int m = n - 2; m >= 0; --m) u[m] = (rh[m] - up[m] * u[m + 1]) / di[m];
+  for (int k = 0; k < nz; ++k) out[k] = u[k * R];
+  free(sA);
+  free(x);
+}
+
+/* Psi_SO.solve, psi_SO.py:333-354 = calc_Ekman (:218-243) + calc_GM (:277-331) */
+void orc_psi_so_solve(const double *z, int nz, const double *y, int ny, const double *b,
+                      const double *bs, const double *tau, const orc_psi_so_par *par,
+                      double *Psi, double *Psi_Ek, double *Psi_GM, int *status) {
+  double *ysv = (double *)malloc(sizeof(double) * (size_t)nz * 8);
+  double *tau_ave = ysv + nz, *tap1 = ysv + 2 * nz, *tap2 = ysv + 3 * nz,
+         *dy = ysv + 4 * nz, *temp = ysv + 5 * nz, *N2 = ysv + 6 * nz,
+         *ekraw = ysv + 7 * nz;
+  double yl[100], tl[100];
+  int st_all = 0;
+  /* ---- calc_Ekman */
+  for (int i = 0; i < nz; ++i) {
+    int st = 0;
+    ysv[i] = orc_psi_so_ys(y, bs, ny, b[i], &st); /* :238 (b(z[ii]) == b[ii]) */
+    if (st) st_all = st;
+    orc_np_linspace(ysv[i], y[ny - 1], 100, yl);
+    if (tau)
+      orc_np_interp(yl, 100, y, tau, ny, tl);
+    else
+      for (int k = 0; k < 100; ++k) tl[k] = par->tau_scalar + 0 * yl[k];
+    tau_ave[i] = pairwise_sum(tl, 100) / 100.; /* np.mean, :239 */
+  }
+  bottom_taper(par->has_Hsill, par->Hsill, z, nz, tap1);
+  top_taper(par->has_HEk, par->HEk, z, nz, 0, tap2);
+  for (int i = 0; i < nz; ++i) {
+    ekraw[i] = tau_ave[i] / par->f / par->rho * par->L * tap1[i] * tap2[i]; /* :243 */
+    Psi_Ek[i] = ekraw[i] / 1e6;                                            /* :349 */
+  }
+  /* ---- calc_GM */
+  const double eps = 0.1;
+  for (int i = 0; i < nz; ++i) {
+    const double d = y[ny - 1] - ysv[i];
+    dy[i] = d > eps ? d : eps; /* max(d, eps), :305 (NaN d -> d, as Python max) */
+    if (isnan(d)) dy[i] = d;
+  }
+  bottom_taper(par->has_Htaperbot, par->Htaperbot, z, nz, tap1);
+  top_taper(par->has_Htapertop, par->Htapertop, z, nz, 1, tap2);
+  if (par->has_c) {
+    for (int i = 0; i < nz; ++i)
+      temp[i] = par->KGM * z[i] / dy[i] * par->L * tap2[i] * tap1[i]; /* :310 */
+    /* calc_N2, :142-162 */
+    for (int i = 1; i < nz - 1; ++i)
+      N2[i] = (b[i + 1] - b[i - 1]) / ((z[i + 1] - z[i]) + (z[i] - z[i - 1]));
+    N2[0] = (b[1] - b[0]) / (z[1] - z[0]);
+    N2[nz - 1] = (b[nz - 1] - b[nz - 2]) / (z[nz - 1] - z[nz - 2]);
+    double ua = 0., ub = 0.;
+    if (par->bvp_with_Ek) { /* bc_GM, :270-273 */
+      ua = -(Psi_Ek[0] * 1e6);
+      ub = -(Psi_Ek[nz - 1] * 1e6);
+    }
+    gm_bvp(z, nz, N2, temp, par->c, ua, ub, par->bvp_refine > 0 ? par->bvp_refine : 16,
+           temp);
+  } else {
+    for (int i = 0; i < nz; ++i) {
+      double s = z[i] / dy[i];
+      if (!(s >= -par->smax) && !isnan(s)) s = -par->smax; /* np.maximum */
+      temp[i] = par->KGM * s * par->L * tap2[i] * tap1[i]; /* :325-327 */
+    }
+  }
+  for (int i = 0; i < nz; ++i) { /* :329-330 */
+    if (dy[i] > y[ny - 1] - y[0]) {
+      const double lim = -Psi_Ek[i] * 1e6;
+      if (isnan(lim) || lim > temp[i]) temp[i] = lim;
+    }
+  }
+  for (int i = 0; i < nz; ++i) {
+    Psi_GM[i] = temp[i] / 1e6;        /* :350 */
+    Psi[i] = Psi_Ek[i] + Psi_GM[i];   /* :351 */
+  }
+  Psi[0] = 0.; /* :354 */
+  if (status) *status = st_all;
+  free(ysv);
+}
+
+/* ============================================================================
+ * SO_ML   (src/pymoc/modules/SO_ML.py)
+ * ========================================================================== */
+
+/* calc_implicit_diffusion, SO_ML.py:136-196.  dense != 0: invert U by Gauss-Jordan
+ * with partial pivoting and form (Uinv V) bs like the reference's
+ * np.dot(np.dot(np.linalg.inv(U), V), bs); dense == 0: Thomas sweep on U x = V bs. */
+static void so_ml_implicit_diffusion(double *bs, int ny, double s, int dense) {
+  double *rhs = (double *)malloc(sizeof(double) * ny);
+  if (!dense) {
+    double *cp = (double *)malloc(sizeof(double) * ny * 2), *dp = cp + ny;
+    rhs[0] = bs[0];
+    rhs[ny - 1] = bs[ny - 1];
+    for (int i = 1; i < ny - 1; ++i)
+      rhs[i] = (s / 2.) * bs[i - 1] + (1 - s) * bs[i] + (s / 2.) * bs[i + 1];
+    /* U: rows 0 and ny-1 identity; interior (-s/2, 1+s, -s/2) */
+    cp[0] = 0.;
+    dp[0] = rhs[0];
+    for (int i = 1; i < ny - 1; ++i) {
+      const double a = -s / 2., bd = 1 + s, c = -s / 2.;
+      const double den = bd - a * cp[i - 1];
+      cp[i] = c / den;
+      dp[i] = (rhs[i] - a * dp[i - 1]) / den;
+    }
+    dp[ny - 1] = rhs[ny - 1];
+    bs[ny - 1] = dp[ny - 1];
+    for (int i = ny - 2; i >= 0; --i) bs[i] = dp[i] - cp[i] * bs[i + 1];
+    free(cp);
+  } else {
+    const int n = ny;
+    double *U = (double *)calloc((size_t)n * n * 3, sizeof(double));
+    double *V = U + (size_t)n * n, *Ui = U + 2 * (size_t)n * n;
+    for (int i = 0; i < n; ++i) {
+      U[i * n + i] = 1 + s;
+      V[i * n + i] = 1 - s;
+      if (i > 0) {
+        U[i * n + i - 1] = -s / 2.;
+        V[i * n + i - 1] = s / 2.;
+      }
+      if (i < n - 1) {
+        U[i * n + i + 1] = -s / 2.;
+        V[i * n + i + 1] = s / 2.;
+      }
+      Ui[i * n + i] = 1.;
+    }
+    U[0] = 1;
+    U[1] = 0;
+    U[(n - 1) * n + n - 2] = 0;
+    U[(n - 1) * n + n - 1] = 1;
+    V[0] = 1;
+    V[1] = 0;
+    V[(n - 1) * n + n - 2] = 0;
+    V[(n - 1) * n + n - 1] = 1;
+    for (int col = 0; col < n; ++col) { /* Gauss-Jordan, partial pivoting */
+      int piv = col;
+      for (int rr = col + 1; rr < n; ++rr)
+        if (fabs(U[rr * n + col]) > fabs(U[piv * n + col])) piv = rr;
+      if (piv != col)
+        for (int k = 0; k < n; ++k) {
+          double t = U[col * n + k];
+          U[col * n + k] = U[piv * n + k];
+          U[piv * n + k] = t;
+          t = Ui[col * n + k];
+          Ui[col * n + k] = Ui[piv * n + k];
+          Ui[piv * n + k] = t;
+        }
+      const double d = U[col * n + col];
+      for (int k = 0; k < n; ++k) {
+        U[col * n + k] /= d;
+        Ui[col * n + k] /= d;
+      }
+      for (int rr = 0; rr < n; ++rr)
+        if (rr != col && U[rr * n + col] != 0.) {
+          const double fct = U[rr * n + col];
+          for (int k = 0; k < n; ++k) {
+            U[rr * n + k] -= fct * U[col * n + k];
+            Ui[rr * n + k] -= fct * Ui[col * n + k];
+          }
+        }
+    }
+    /* M = Ui V (reuse U), then M bs */
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) {
+        double acc = 0.;
+        for (int k = 0; k < n; ++k) acc += Ui[i * n + k] * V[k * n + j];
+        U[i * n + j] = acc;
+      }
+    for (int i = 0; i < n; ++i) {
+      double acc = 0.;
+      for (int j = 0; j < n; ++j) acc += U[i * n + j] * bs[j];
+      rhs[i] = acc;
+    }
+    memcpy(bs, rhs, sizeof(double) * n);
+    free(U);
+  }
+  free(rhs);
+}
+
+/* SO_ML.advdiff, SO_ML.py:198-274 (+ set_boundary_conditions :77-98,
+ * calc_advective_tendency :100-134) */
+int orc_so_ml_advdiff(const double *y, int ny, const double *surflux,
+                      const double *rest_mask, const double *b_rest,
+                      const orc_so_ml_par *par, double *bs, double *Psi_s,
+                      const double *b_basin, const double *Psi_b, int nz, double dt,
+                      int dense_inverse) {
+  double *Psi_mod = (double *)malloc(sizeof(double) * (nz + 2 * ny));
+  double *flux = Psi_mod + nz, *adv = flux + ny;
+  int ind = -1;
+  for (int i = 0; i < nz; ++i)
+    if (Psi_b[i] != 0.) { /* np.nonzero(Psi_mod)[0][0], :229 (NaN counts) */
+      ind = i;
+      break;
+    }
+  if (ind < 0) {
+    free(Psi_mod);
+    return -1; /* IndexError in the reference */
+  }
+  for (int i = 0; i < nz; ++i) Psi_mod[i] = (i < ind) ? Psi_b[ind] : Psi_b[i]; /* :230 */
+  orc_np_interp(bs, ny, b_basin, Psi_mod, nz, Psi_s);                          /* :232 */
+  int amin = 0; /* np.argmin: first minimum; NaN wins */
+  for (int j = 1; j < ny; ++j) {
+    if (isnan(bs[amin])) break;
+    if (isnan(bs[j]) || bs[j] < bs[amin]) amin = j;
+  }
+  for (int j = 0; j < amin; ++j) Psi_s[j] = 0.; /* :240 */
+  Psi_s[0] = 0.;                                /* :241-243 */
+  /* set_boundary_conditions, :93-98 */
+  int first_pos = -1;
+  for (int i = 0; i < nz; ++i)
+    if (Psi_b[i] > 0) {
+      first_pos = i;
+      break;
+    }
+  if (Psi_s[1] > 0) {
+    if (first_pos < 0) {
+      free(Psi_mod);
+      return -1;
+    }
+    bs[0] = b_basin[first_pos];
+  } else {
+    bs[0] = bs[1];
+  }
+  for (int j = 0; j < ny; ++j) /* :250-252 */
+    flux[j] = surflux[j] / par->h + rest_mask[j] * par->v_pist / par->h * (b_rest[j] - bs[j]);
+  const double dy = y[1] - y[0]; /* :255 */
+  for (int j = 0; j < ny; ++j) adv[j] = 0.;
+  for (int j = 1; j < ny - 1; ++j) { /* :126-133 */
+    if (Psi_s[j] < 0.)
+      adv[j] = -Psi_s[j] * 1e6 * (bs[j + 1] - bs[j]) / par->h / par->L / dy;
+    else if (Psi_s[j] > 0.)
+      adv[j] = -Psi_s[j] * 1e6 * (bs[j] - bs[j - 1]) / par->h / par->L / dy;
+  }
+  for (int j = 0; j < ny; ++j) bs[j] = bs[j] + dt * (flux[j] + adv[j]); /* :259 */
+  if (Psi_s[1] <= 0) bs[0] = bs[1];                                     /* :264-266 */
+  const double s = par->Ks * dt / (dy * dy);                            /* :191 */
+  so_ml_implicit_diffusion(bs, ny, s, dense_inverse);                   /* :269 */
+  if (Psi_s[1] > 0) /* :274 */
+    bs[0] = b_basin[first_pos];
+  else
+    bs[0] = bs[1];
+  free(Psi_mod);
+  return 0;
+}

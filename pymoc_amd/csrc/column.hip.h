@@ -1,0 +1,251 @@
+// column.hip.h -- K1: the advective-diffusive column update, fused over nsteps.
+//
+// Arithmetic restated from the reference (nothing copied):
+//   Column.convect      src/pymoc/modules/column.py:251-271
+//   Column.vertadvdiff  src/pymoc/modules/column.py:210-249
+//   Column.horadv       src/pymoc/modules/column.py:288-313
+//   Column.timestep     src/pymoc/modules/column.py:315-348
+// Every operation is an elementwise IEEE fp64 +,-,*,/ in the reference's order
+// (compiled with -ffp-contract=off), so results are bit-identical to NumPy.
+//
+// Work decomposition: G lanes (16, 32 or 64) of one wavefront own one column; lane
+// lg holds the P contiguous levels [lg*P, lg*P+P) in registers for the whole launch.
+// The 3-point stencil needs one value from each neighbour lane per step (b of the
+// level above, bz of the interface below): two DPP wave shifts, no LDS, no barrier.
+#pragma once
+#include "common.hip.h"
+
+namespace pm {
+
+template <int P>
+struct ColRegs {
+  double b[P];     // state
+  double z[P];     // level depth
+  double dz[P];    // z[i+1]-z[i]           (interface above level i)
+  double dzc[P];   // 0.5*(dz[i]+dz[i-1])   (column.py:238)
+  double kap[P];   // kappa(z_i)
+  double area[P];  // Area(z_i)
+  double dAk[P];   // d(Area*kappa)/dz at z_i (np.gradient, host precomputed)
+};
+
+// Column.convect (column.py:251-271).  `zg` is the shared grid in global memory.
+template <int G, int P>
+__device__ __forceinline__ void col_convect(double (&b)[P], const double (&z)[P],
+                                            double bs, double N2min, int lg, int lane,
+                                            int nz, const double *__restrict__ zg) {
+  const unsigned long long gm = group_mask<G>(lane);
+  bool ind[P];
+  bool any_l = false;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lg * P + p;
+    ind[p] = (i < nz) && (b[p] > bs);  // column.py:264
+    any_l |= ind[p];
+  }
+  const unsigned long long anym = __ballot(any_l) & gm;
+  if (anym != 0ull) {
+    // zconv = max(z[~ind]) (column.py:267): z ascends, so it is z at the highest
+    // non-convecting level; bottom of the ocean if every level convects.
+    int jmax = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lg * P + p;
+      const unsigned long long m = __ballot((i < nz) && !ind[p]) & gm;
+      if (m != 0ull) {
+        const int hl = 63 - __clzll((long long)m);
+        const int j = (hl % G) * P + p;
+        jmax = j > jmax ? j : jmax;
+      }
+    }
+    const double zconv = zg[jmax];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (ind[p]) b[p] = bs + N2min * (z[p] - zconv);  // column.py:268
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (lg * P + p == nz - 1) b[p] = bs;  // column.py:271
+  }
+}
+
+// Column.vertadvdiff (column.py:210-249), one explicit step.
+template <int G, int P>
+__device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA)[P],
+                                                double dt, bool do_conv, double bs,
+                                                double bbot, bool use_bzbot,
+                                                double bzbot, int lg, int nz) {
+  // surface boundary condition (column.py:230-231)
+  if (!do_conv) {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (lg * P + p == nz - 1) r.b[p] = bs;
+  }
+  // b at the level above each owned level
+  const double nb0 = from_next_lane(r.b[0]);
+  double bup[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) bup[p] = (p < P - 1) ? r.b[p + 1 < P ? p + 1 : p] : nb0;
+  // bottom boundary condition (column.py:232-233); level 0 = lane 0, slot 0
+  if (lg == 0) r.b[0] = use_bzbot ? (bup[0] - bzbot * r.dz[0]) : bbot;
+
+  double bz[P];  // (b[i+1]-b[i])/dz[i]  (column.py:235)
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lg * P + p;
+    bz[p] = (i < nz - 1) ? (bup[p] - r.b[p]) / r.dz[p] : 0.0;
+  }
+  const double pbz = from_prev_lane(bz[P - 1]);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lg * P + p;
+    if (i >= 1 && i <= nz - 2) {
+      const double bz_up = bz[p];
+      const double bz_dn = (p > 0) ? bz[p > 0 ? p - 1 : 0] : pbz;
+      const double bzz = (bz_up - bz_dn) / r.dzc[p];          // column.py:238
+      const double weff = wA[p] - r.dAk[p];                   // column.py:241
+      const double bzu = (weff < 0.0) ? bz_up : bz_dn;        // column.py:242-243
+      const double db_dt = (-weff) * bzu / r.area[p] + r.kap[p] * bzz;  // :245-248
+      r.b[p] = r.b[p] + dt * db_dt;                           // column.py:249
+    }
+  }
+}
+
+// Column.horadv (column.py:288-313)
+template <int P>
+__device__ __forceinline__ void col_horadv(ColRegs<P> &r, const double (&vdx)[P],
+                                           const double (&bin)[P], double dt, int lg,
+                                           int nz) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lg * P + p;
+    if (i < nz && vdx[p] > 0.0) {
+      const double db = bin[p] - r.b[p];
+      r.b[p] = r.b[p] + dt * vdx[p] * db / r.area[p];
+    }
+  }
+}
+
+// static part of a column (grid metrics + coefficient set `sel`) into registers
+template <int P>
+__device__ __forceinline__ void col_load_static(ColRegs<P> &r, const pm_columns &c,
+                                                int col, int sel, int lg) {
+  const int nz = c.nz;
+  const size_t base = (size_t)col * nz;
+  const size_t sbase = ((size_t)sel * c.ncols + col) * nz;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lg * P + p;
+    const int ic = i < nz ? i : nz - 1;
+    const int iu = ic + 1 < nz ? ic + 1 : nz - 1;
+    const int id = ic > 0 ? ic - 1 : 0;
+    const double zc = c.z[ic];
+    r.z[p] = zc;
+    r.dz[p] = c.z[iu] - zc;
+    r.dzc[p] = 0.5 * (r.dz[p] + (zc - c.z[id]));
+    r.kap[p] = c.kappa[sbase + ic];
+    r.dAk[p] = c.dAkappa[sbase + ic];
+    r.area[p] = c.area[base + ic];
+  }
+}
+
+template <int G, int P>
+__global__ __launch_bounds__(256) void k_column_steps(
+    pm_columns c, const double *__restrict__ wA_g, const double *__restrict__ vdx_g,
+    const double *__restrict__ bin_g, double dt, int nsteps, int ops) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int lg = threadIdx.x % G;
+  const int col_raw = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) / G);
+  const bool col_ok = col_raw < c.ncols;
+  const int col = col_ok ? col_raw : c.ncols - 1;  // idle groups shadow the last column
+  const int nz = c.nz;
+  const size_t base = (size_t)col * nz;
+
+  ColRegs<P> r;
+  const int sel = c.ksel ? c.ksel[col] : 0;
+  col_load_static<P>(r, c, col, sel, lg);
+
+  double wA[P], vdx[P], bin[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lg * P + p;
+    const int ic = i < nz ? i : nz - 1;
+    r.b[p] = c.b[base + ic];
+    wA[p] = wA_g ? wA_g[base + ic] : 0.0;
+    vdx[p] = vdx_g ? vdx_g[base + ic] : 0.0;
+    bin[p] = bin_g ? bin_g[base + ic] : 0.0;
+  }
+  const int flags = c.flags ? c.flags[col] : 0;
+  const bool do_conv = (flags & PM_COL_DO_CONV) != 0;
+  const bool use_bzbot = (flags & PM_COL_BZBOT) != 0 && c.bzbot != nullptr;
+  const double bs = c.bs[col];
+  const double bbot = c.bbot[col];
+  const double bzbot = use_bzbot ? c.bzbot[col] : 0.0;
+  const double N2min = c.N2min[col];
+
+  for (int s = 0; s < nsteps; ++s) {
+    if ((ops & PM_OP_CONVECT) && do_conv)
+      col_convect<G, P>(r.b, r.z, bs, N2min, lg, lane, nz, c.z);
+    if (ops & PM_OP_VERTADVDIFF)
+      col_vertadvdiff<G, P>(r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lg, nz);
+    if ((ops & PM_OP_HORADV) && vdx_g) col_horadv<P>(r, vdx, bin, dt, lg, nz);
+  }
+
+  bool bad = false;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lg * P + p;
+    if (i < nz) {
+      if (col_ok) c.b[base + i] = r.b[p];
+      bad |= !isfinite(r.b[p]);
+    }
+  }
+  if (c.nonfinite) {
+    const unsigned long long m = __ballot(bad) & group_mask<G>(lane);
+    if (lg == 0 && col_ok) c.nonfinite[col] = (m != 0ull) ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------ dispatch
+inline int pick_levels_per_lane(int need) {
+  static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13, 16};
+  for (int v : sup)
+    if (v >= need) return v;
+  return -1;
+}
+
+template <int G, int P>
+int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx,
+                        const double *bin, double dt, int nsteps, int ops,
+                        hipStream_t st) {
+  const int cols_per_block = 256 / G;
+  const unsigned grid = (unsigned)((c.ncols + cols_per_block - 1) / cols_per_block);
+  hipLaunchKernelGGL((k_column_steps<G, P>), dim3(grid), dim3(256), 0, st, c, wA, vdx,
+                     bin, dt, nsteps, ops);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
+template <int G>
+int dispatch_column_steps_P(int P, const pm_columns &c, const double *wA,
+                            const double *vdx, const double *bin, double dt, int nsteps,
+                            int ops, hipStream_t st) {
+  switch (P) {
+#define PM_CASE(PP) \
+  case PP:          \
+    return launch_column_steps<G, PP>(c, wA, vdx, bin, dt, nsteps, ops, st);
+    PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
+    PM_CASE(8) PM_CASE(10) PM_CASE(13) PM_CASE(16)
+#undef PM_CASE
+  }
+  return fail(PM_EINVAL, "unsupported levels-per-lane %d", P);
+}
+
+inline int auto_lanes_per_col(int ncols, int nz) {
+  // Few columns: one wave per column keeps every SIMD busy (1024 SIMDs on the chip).
+  // Many columns: narrower groups raise per-lane ILP and cut idle padding lanes.
+  int G = ncols <= 4096 ? 64 : (ncols <= 16384 ? 32 : 16);
+  while (G < 64 && pick_levels_per_lane((nz + G - 1) / G) < 0) G *= 2;
+  return G;
+}
+
+}  // namespace pm

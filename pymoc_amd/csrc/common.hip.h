@@ -1,0 +1,105 @@
+// common.hip.h -- error plumbing and wavefront primitives shared by all kernels.
+// gfx950 only: wave = 64 lanes, DPP wave shifts available (GFX9 family).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/pymoc_hip.h"
+
+namespace pm {
+
+// ---------------------------------------------------------------- host errors
+extern thread_local char g_err[512];
+int fail(int code, const char *fmt, ...);
+
+#define PM_HIP(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess)                                                         \
+      return pm::fail(PM_EHIP, "%s failed: %s (%s:%d)", #call,                    \
+                      hipGetErrorString(e_), __FILE__, __LINE__);                 \
+  } while (0)
+
+#define PM_REQUIRE(cond, ...)                                                     \
+  do {                                                                            \
+    if (!(cond)) return pm::fail(PM_EINVAL, __VA_ARGS__);                         \
+  } while (0)
+
+hipStream_t resolve_stream(pm_stream_t s);
+
+// ------------------------------------------------------------- lane primitives
+constexpr int WAVE = 64;
+
+// DPP controls (GFX9): wave_shl:1 = 0x130 (lane i <- lane i+1),
+//                      wave_shr:1 = 0x138 (lane i <- lane i-1).
+// Lanes without a source keep their own value (bound_ctrl = 0, old = src).
+__device__ __forceinline__ double from_next_lane(double x) {
+#ifdef PM_NO_DPP
+  return __shfl_down(x, 1, WAVE);
+#else
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+#endif
+}
+
+__device__ __forceinline__ double from_prev_lane(double x) {
+#ifdef PM_NO_DPP
+  return __shfl_up(x, 1, WAVE);
+#else
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+#endif
+}
+
+// 64-bit mask of the G lanes of this lane's group inside the wave.
+template <int G>
+__device__ __forceinline__ unsigned long long group_mask(int lane) {
+  if constexpr (G == 64) {
+    return ~0ull;
+  } else {
+    return ((1ull << G) - 1ull) << ((lane / G) * G);
+  }
+}
+
+// value of `x` held by lane `src` (absolute lane in wave)
+__device__ __forceinline__ double lane_bcast(double x, int src) {
+  return __shfl(x, src, WAVE);
+}
+
+// min / max / sum over the G lanes of a group (butterfly; every lane gets the result)
+template <int G>
+__device__ __forceinline__ double group_min(double x) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) {
+    double y = __shfl_xor(x, o, WAVE);
+    x = (y < x) ? y : x;
+  }
+  return x;
+}
+template <int G>
+__device__ __forceinline__ double group_max(double x) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) {
+    double y = __shfl_xor(x, o, WAVE);
+    x = (y > x) ? y : x;
+  }
+  return x;
+}
+
+// inclusive prefix sum over the G lanes of a group (Hillis-Steele on ds_bpermute)
+template <int G>
+__device__ __forceinline__ double group_scan_incl(double x, int lg) {
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) {
+    double y = __shfl_up(x, o, G);
+    if (lg >= o) x += y;
+  }
+  return x;
+}
+
+}  // namespace pm

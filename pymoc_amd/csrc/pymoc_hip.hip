@@ -1,0 +1,239 @@
+// pymoc_hip.hip -- the single translation unit of libpymoc_hip.so: runtime plumbing
+// (memory, streams, events, graphs) and the extern "C" launchers of every kernel.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+#include <stdarg.h>
+#include <dlfcn.h>
+#include "common.hip.h"
+#include "column.hip.h"
+
+namespace pm {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static hipStream_t g_default_stream = nullptr;
+
+hipStream_t resolve_stream(pm_stream_t s) {
+  if (s) return (hipStream_t)s;
+  if (!g_default_stream) {
+    if (hipStreamCreateWithFlags(&g_default_stream, hipStreamNonBlocking) != hipSuccess)
+      g_default_stream = nullptr;  // fall back to the null stream
+  }
+  return g_default_stream;
+}
+
+// ---- lane shift self test -------------------------------------------------------
+__global__ void k_selftest_lane_shift(int *mismatch) {
+  const int lane = threadIdx.x & 63;
+  const double x = 1000.0 * blockIdx.x + lane + 0.25;
+  const double n_dpp = from_next_lane(x);
+  const double p_dpp = from_prev_lane(x);
+  const double n_ref = __shfl_down(x, 1, 64);
+  const double p_ref = __shfl_up(x, 1, 64);
+  int bad = 0;
+  if (lane < 63 && n_dpp != n_ref) bad = 1;
+  if (lane > 0 && p_dpp != p_ref) bad = 1;
+  if (lane == 63 && n_dpp != x) bad = 1;  // no source: keeps own value
+  if (lane == 0 && p_dpp != x) bad = 1;
+  if (bad) atomicAdd(mismatch, 1);
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+extern "C" {
+
+const char *pm_version(void) { return "pymoc_hip 0.1.0 (gfx950)"; }
+const char *pm_last_error(void) { return g_err; }
+
+int pm_device_count(int *count) {
+  PM_REQUIRE(count, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(PM_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return PM_OK;
+}
+
+int pm_set_device(int device) {
+  PM_HIP(hipSetDevice(device));
+  return PM_OK;
+}
+
+int pm_device_info(char *name, size_t name_len, int *compute_units, size_t *hbm_bytes,
+                   int *clock_mhz) {
+  int dev = 0;
+  PM_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  PM_HIP(hipGetDeviceProperties(&p, dev));
+  if (name && name_len) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+  if (compute_units) *compute_units = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+  if (clock_mhz) *clock_mhz = p.clockRate / 1000;
+  return PM_OK;
+}
+
+int pm_malloc(void **dptr, size_t bytes) {
+  PM_REQUIRE(dptr, "dptr is NULL");
+  *dptr = nullptr;
+  if (bytes == 0) return PM_OK;
+  PM_HIP(hipMalloc(dptr, bytes));
+  return PM_OK;
+}
+int pm_free(void *dptr) {
+  if (dptr) PM_HIP(hipFree(dptr));
+  return PM_OK;
+}
+int pm_memset(void *dptr, int value, size_t bytes, pm_stream_t stream) {
+  if (bytes) PM_HIP(hipMemsetAsync(dptr, value, bytes, resolve_stream(stream)));
+  return PM_OK;
+}
+int pm_memcpy_h2d(void *dst, const void *src, size_t bytes, pm_stream_t stream) {
+  if (!bytes) return PM_OK;
+  hipStream_t st = resolve_stream(stream);
+  PM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+  PM_HIP(hipStreamSynchronize(st));  // the host buffer is not retained
+  return PM_OK;
+}
+int pm_memcpy_d2h(void *dst, const void *src, size_t bytes, pm_stream_t stream) {
+  if (!bytes) return PM_OK;
+  hipStream_t st = resolve_stream(stream);
+  PM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+  PM_HIP(hipStreamSynchronize(st));
+  return PM_OK;
+}
+int pm_memcpy_d2d(void *dst, const void *src, size_t bytes, pm_stream_t stream) {
+  if (bytes)
+    PM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice,
+                          resolve_stream(stream)));
+  return PM_OK;
+}
+
+int pm_stream_create(pm_stream_t *stream) {
+  PM_REQUIRE(stream, "stream is NULL");
+  hipStream_t s;
+  PM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (pm_stream_t)s;
+  return PM_OK;
+}
+int pm_stream_destroy(pm_stream_t stream) {
+  if (stream) PM_HIP(hipStreamDestroy((hipStream_t)stream));
+  return PM_OK;
+}
+int pm_stream_sync(pm_stream_t stream) {
+  PM_HIP(hipStreamSynchronize(resolve_stream(stream)));
+  return PM_OK;
+}
+int pm_device_sync(void) {
+  PM_HIP(hipDeviceSynchronize());
+  return PM_OK;
+}
+
+int pm_event_create(pm_event_t *event) {
+  PM_REQUIRE(event, "event is NULL");
+  hipEvent_t e;
+  PM_HIP(hipEventCreate(&e));
+  *event = (pm_event_t)e;
+  return PM_OK;
+}
+int pm_event_destroy(pm_event_t event) {
+  if (event) PM_HIP(hipEventDestroy((hipEvent_t)event));
+  return PM_OK;
+}
+int pm_event_record(pm_event_t event, pm_stream_t stream) {
+  PM_HIP(hipEventRecord((hipEvent_t)event, resolve_stream(stream)));
+  return PM_OK;
+}
+int pm_event_sync(pm_event_t event) {
+  PM_HIP(hipEventSynchronize((hipEvent_t)event));
+  return PM_OK;
+}
+int pm_event_elapsed_ms(pm_event_t start, pm_event_t stop, float *ms) {
+  PM_REQUIRE(ms, "ms is NULL");
+  PM_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return PM_OK;
+}
+
+int pm_graph_begin_capture(pm_stream_t stream) {
+  PM_HIP(hipStreamBeginCapture(resolve_stream(stream), hipStreamCaptureModeThreadLocal));
+  return PM_OK;
+}
+int pm_graph_end_capture(pm_stream_t stream, pm_graph_t *graph) {
+  PM_REQUIRE(graph, "graph is NULL");
+  hipGraph_t g = nullptr;
+  PM_HIP(hipStreamEndCapture(resolve_stream(stream), &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e != hipSuccess)
+    return fail(PM_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  *graph = (pm_graph_t)ge;
+  return PM_OK;
+}
+int pm_graph_launch(pm_graph_t graph, pm_stream_t stream) {
+  PM_HIP(hipGraphLaunch((hipGraphExec_t)graph, resolve_stream(stream)));
+  return PM_OK;
+}
+int pm_graph_destroy(pm_graph_t graph) {
+  if (graph) PM_HIP(hipGraphExecDestroy((hipGraphExec_t)graph));
+  return PM_OK;
+}
+
+// -------------------------------------------------------------------- Column
+int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_in,
+                    const double *b_in, double dt, int32_t nsteps, int32_t ops,
+                    int32_t lanes_per_col, pm_stream_t stream) {
+  PM_REQUIRE(cols, "cols is NULL");
+  const pm_columns &c = *cols;
+  PM_REQUIRE(c.ncols >= 0 && c.nz >= 2 && c.nz <= 1024,
+             "bad batch shape ncols=%d nz=%d (need nz in [2,1024])", c.ncols, c.nz);
+  PM_REQUIRE(c.nsel >= 1 && c.nsel <= 2, "nsel must be 1 or 2 (got %d)", c.nsel);
+  PM_REQUIRE(c.z && c.b && c.kappa && c.area && c.dAkappa && c.bs && c.bbot && c.N2min,
+             "pm_columns has a NULL required pointer");
+  PM_REQUIRE(nsteps >= 0, "nsteps < 0");
+  PM_REQUIRE((ops & ~PM_OP_TIMESTEP) == 0, "unknown op bits 0x%x", ops);
+  PM_REQUIRE(!(ops & PM_OP_VERTADVDIFF) || wA, "wA is NULL");
+  PM_REQUIRE(!vdx_in || b_in, "b_in is needed if vdx_in is provided");
+  if (c.ncols == 0 || nsteps == 0 || ops == 0) return PM_OK;
+  int G = lanes_per_col ? lanes_per_col : auto_lanes_per_col(c.ncols, c.nz);
+  PM_REQUIRE(G == 16 || G == 32 || G == 64, "lanes_per_col must be 0, 16, 32 or 64");
+  int P = pick_levels_per_lane((c.nz + G - 1) / G);
+  while (P < 0 && G < 64) {
+    G *= 2;
+    P = pick_levels_per_lane((c.nz + G - 1) / G);
+  }
+  PM_REQUIRE(P > 0, "nz=%d does not fit %d lanes", c.nz, G);
+  hipStream_t st = resolve_stream(stream);
+  switch (G) {
+    case 16: return dispatch_column_steps_P<16>(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
+    case 32: return dispatch_column_steps_P<32>(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
+    default: return dispatch_column_steps_P<64>(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
+  }
+}
+
+int pm_selftest_lane_shift(int32_t *mismatches) {
+  PM_REQUIRE(mismatches, "mismatches is NULL");
+  int *d = nullptr;
+  PM_HIP(hipMalloc((void **)&d, sizeof(int)));
+  hipStream_t st = resolve_stream(nullptr);
+  PM_HIP(hipMemsetAsync(d, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_selftest_lane_shift, dim3(8), dim3(256), 0, st, d);
+  PM_HIP(hipGetLastError());
+  PM_HIP(hipMemcpyAsync(mismatches, d, sizeof(int), hipMemcpyDeviceToHost, st));
+  PM_HIP(hipStreamSynchronize(st));
+  PM_HIP(hipFree(d));
+  return PM_OK;
+}
+
+}  // extern "C"
