@@ -1,0 +1,13 @@
+"""pymoc_amd -- MI355X (gfx950) engine for the PyMOC timestep() path.
+
+Host code is Python + ctypes over the C-ABI of libpymoc_hip.so (include/pymoc_hip.h);
+there is no CPU fallback and no PyTorch in the product path.
+"""
+__version__ = "0.1.0"
+
+from . import _lib
+from .device import DeviceArray, Stream, Event, Graph, synchronize
+from .columns import ColumnBatch
+from . import modules
+from . import utils
+from .modules import Column

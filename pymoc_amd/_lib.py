@@ -1,0 +1,111 @@
+"""ctypes binding of libpymoc_hip.so (the C-ABI declared in include/pymoc_hip.h).
+
+The engine has no CPU fallback: if the shared library is missing, importing this module
+raises; if no HIP device is visible, the first call that needs one raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpymoc_hip.so")
+
+PM_OK, PM_EINVAL, PM_EHIP, PM_ENCCL, PM_ENODEV = 0, 1, 2, 3, 4
+
+PM_COL_DO_CONV, PM_COL_BZBOT = 1, 2
+PM_OP_CONVECT, PM_OP_VERTADVDIFF, PM_OP_HORADV, PM_OP_TIMESTEP = 1, 2, 4, 7
+
+c_dp = C.c_void_p  # device pointers travel as plain addresses
+
+
+class PmError(RuntimeError):
+  def __init__(self, code, text):
+    super().__init__("pymoc_hip error %d: %s" % (code, text))
+    self.code = code
+
+
+class pm_columns(C.Structure):
+  """Mirror of `struct pm_columns` (include/pymoc_hip.h)."""
+  _fields_ = [
+      ("ncols", C.c_int32), ("nz", C.c_int32), ("nsel", C.c_int32),
+      ("reserved", C.c_int32), ("z", c_dp), ("b", c_dp), ("kappa", c_dp),
+      ("area", c_dp), ("dAkappa", c_dp), ("bs", c_dp), ("bbot", c_dp), ("bzbot", c_dp),
+      ("N2min", c_dp), ("flags", c_dp), ("ksel", c_dp), ("nonfinite", c_dp)
+  ]
+
+
+if not os.path.exists(LIB_PATH):
+  raise ImportError(
+      "pymoc_amd: %s is missing. Build it with `make lib` (hipcc --offload-arch=gfx950) "
+      "or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU "
+      "fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+# name -> (restype, argtypes); every symbol include/pymoc_hip.h declares
+SIGNATURES = {
+    "pm_version": (C.c_char_p, []),
+    "pm_last_error": (C.c_char_p, []),
+    "pm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pm_set_device": (C.c_int, [C.c_int]),
+    "pm_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int),
+                                 C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "pm_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "pm_free": (C.c_int, [C.c_void_p]),
+    "pm_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "pm_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pm_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pm_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pm_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "pm_stream_destroy": (C.c_int, [C.c_void_p]),
+    "pm_stream_sync": (C.c_int, [C.c_void_p]),
+    "pm_device_sync": (C.c_int, []),
+    "pm_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "pm_event_destroy": (C.c_int, [C.c_void_p]),
+    "pm_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pm_event_sync": (C.c_int, [C.c_void_p]),
+    "pm_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "pm_graph_begin_capture": (C.c_int, [C.c_void_p]),
+    "pm_graph_end_capture": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pm_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pm_graph_destroy": (C.c_int, [C.c_void_p]),
+    "pm_column_steps": (C.c_int, [C.POINTER(pm_columns), c_dp, c_dp, c_dp, C.c_double,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "pm_selftest_lane_shift": (C.c_int, [C.POINTER(C.c_int32)]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+  _fn = getattr(lib, _name)  # AttributeError here = header/library mismatch
+  _fn.restype = _res
+  _fn.argtypes = _args
+
+
+def check(rc):
+  if rc != PM_OK:
+    raise PmError(rc, lib.pm_last_error().decode("utf-8", "replace"))
+
+
+_device_ready = False
+
+
+def require_device(device=None):
+  """Select the HIP device once; raises PmError(PM_ENODEV) when none is visible."""
+  global _device_ready
+  if _device_ready and device is None:
+    return
+  n = C.c_int(0)
+  check(lib.pm_device_count(C.byref(n)))
+  if n.value <= 0:
+    raise PmError(PM_ENODEV, "no HIP device visible; pymoc_amd has no CPU fallback")
+  if device is None:
+    device = int(os.environ.get("LOCAL_RANK", "0")) % n.value
+  check(lib.pm_set_device(int(device)))
+  _device_ready = True
+
+
+def device_info():
+  require_device()
+  name = C.create_string_buffer(256)
+  cus, mem, clk = C.c_int(0), C.c_size_t(0), C.c_int(0)
+  check(lib.pm_device_info(name, 256, C.byref(cus), C.byref(mem), C.byref(clk)))
+  return {"name": name.value.decode(), "compute_units": cus.value,
+          "hbm_bytes": mem.value, "clock_mhz": clk.value}

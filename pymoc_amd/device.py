@@ -1,0 +1,158 @@
+"""Device memory, streams and events on top of the C-ABI (no PyTorch)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+class Stream(object):
+  def __init__(self):
+    _lib.require_device()
+    h = C.c_void_p()
+    check(lib.pm_stream_create(C.byref(h)))
+    self.handle = h
+
+  def sync(self):
+    check(lib.pm_stream_sync(self.handle))
+
+  def __del__(self):
+    try:
+      if self.handle:
+        lib.pm_stream_destroy(self.handle)
+        self.handle = None
+    except Exception:
+      pass
+
+
+def _sh(stream):
+  return stream.handle if stream is not None else None
+
+
+class Event(object):
+  def __init__(self):
+    _lib.require_device()
+    h = C.c_void_p()
+    check(lib.pm_event_create(C.byref(h)))
+    self.handle = h
+
+  def record(self, stream=None):
+    check(lib.pm_event_record(self.handle, _sh(stream)))
+
+  def sync(self):
+    check(lib.pm_event_sync(self.handle))
+
+  def elapsed_ms(self, later):
+    ms = C.c_float(0)
+    check(lib.pm_event_elapsed_ms(self.handle, later.handle, C.byref(ms)))
+    return ms.value
+
+  def __del__(self):
+    try:
+      if self.handle:
+        lib.pm_event_destroy(self.handle)
+        self.handle = None
+    except Exception:
+      pass
+
+
+class Graph(object):
+  """A captured launch sequence (hipGraph): `with Graph.capture(stream) as g: ...`."""
+
+  def __init__(self, handle):
+    self.handle = handle
+
+  class _Capture(object):
+    def __init__(self, stream):
+      self.stream = stream
+      self.graph = None
+
+    def __enter__(self):
+      check(lib.pm_graph_begin_capture(_sh(self.stream)))
+      return self
+
+    def __exit__(self, et, ev, tb):
+      h = C.c_void_p()
+      rc = lib.pm_graph_end_capture(_sh(self.stream), C.byref(h))
+      if et is None:
+        check(rc)
+        self.graph = Graph(h)
+      return False
+
+  @staticmethod
+  def capture(stream=None):
+    return Graph._Capture(stream)
+
+  def launch(self, stream=None):
+    check(lib.pm_graph_launch(self.handle, _sh(stream)))
+
+  def __del__(self):
+    try:
+      if self.handle:
+        lib.pm_graph_destroy(self.handle)
+        self.handle = None
+    except Exception:
+      pass
+
+
+class DeviceArray(object):
+  """A dense fp64 / int32 array in HBM, owned by this object."""
+
+  def __init__(self, shape, dtype=np.float64):
+    _lib.require_device()
+    self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+    self.dtype = np.dtype(dtype)
+    self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+    p = C.c_void_p()
+    check(lib.pm_malloc(C.byref(p), self.nbytes))
+    self.ptr = p.value or 0
+
+  @classmethod
+  def from_host(cls, arr, dtype=None, stream=None):
+    arr = np.ascontiguousarray(arr, dtype=dtype if dtype is not None else
+                               (np.int32 if np.asarray(arr).dtype.kind in "iub"
+                                else np.float64))
+    d = cls(arr.shape, arr.dtype)
+    d.upload(arr, stream)
+    return d
+
+  @classmethod
+  def zeros(cls, shape, dtype=np.float64, stream=None):
+    d = cls(shape, dtype)
+    check(lib.pm_memset(d.ptr, 0, d.nbytes, _sh(stream)))
+    return d
+
+  def upload(self, arr, stream=None):
+    arr = np.ascontiguousarray(arr, dtype=self.dtype)
+    if arr.nbytes != self.nbytes:
+      raise ValueError("upload size mismatch: %r vs %r" % (arr.shape, self.shape))
+    check(lib.pm_memcpy_h2d(self.ptr, arr.ctypes.data, self.nbytes, _sh(stream)))
+
+  def download(self, out=None, stream=None):
+    if out is None:
+      out = np.empty(self.shape, dtype=self.dtype)
+    if out.nbytes != self.nbytes or not out.flags.c_contiguous or out.dtype != self.dtype:
+      raise ValueError("download buffer mismatch")
+    check(lib.pm_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, _sh(stream)))
+    return out
+
+  def copy_from(self, other, stream=None):
+    if other.nbytes != self.nbytes:
+      raise ValueError("copy size mismatch")
+    check(lib.pm_memcpy_d2d(self.ptr, other.ptr, self.nbytes, _sh(stream)))
+
+  def free(self):
+    if getattr(self, "ptr", 0):
+      lib.pm_free(self.ptr)
+      self.ptr = 0
+
+  def __del__(self):
+    try:
+      self.free()
+    except Exception:
+      pass
+
+
+def synchronize():
+  check(lib.pm_device_sync())

@@ -1,0 +1,33 @@
+"""Host-side coercion helpers with the reference's contract.
+
+Mirrors `pymoc.utils.make_func` (src/pymoc/utils/make_func.py:4-45) and
+`pymoc.utils.make_array` (src/pymoc/utils/make_array.py:4-37): accepted types are
+callable / numpy.ndarray / float (ints are rejected), ndarray inputs are NOT copied
+(the returned closure / array aliases the caller's object), and the error is the
+2-tuple TypeError whose text the reference's tests pin.
+"""
+import numpy as np
+
+_MSG = 'needs to be either function, numpy array, or float'
+
+
+def make_func(myst, axis, name):
+  """callable | ndarray on `axis` | float  ->  callable f(x)."""
+  if callable(myst):
+    return myst
+  if isinstance(myst, np.ndarray):
+    return lambda x: np.interp(x, axis, myst)
+  if isinstance(myst, float):
+    return lambda x: myst + 0 * x
+  raise TypeError(name, _MSG)
+
+
+def make_array(myst, axis, name):
+  """ndarray | callable | float  ->  ndarray along `axis`."""
+  if isinstance(myst, np.ndarray):
+    return myst
+  if callable(myst):
+    return myst(axis)
+  if isinstance(myst, float):
+    return myst + 0 * axis
+  raise TypeError(name, _MSG)

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+  config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_golden(name):
+  return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def relerr(a, ref):
+  """max-norm error relative to max|ref| (NaNs must coincide)."""
+  a, ref = np.asarray(a, dtype=float), np.asarray(ref, dtype=float)
+  assert a.shape == ref.shape, (a.shape, ref.shape)
+  assert np.array_equal(np.isnan(a), np.isnan(ref)), "NaN pattern differs"
+  scale = np.nanmax(np.abs(ref)) if np.isfinite(ref).any() else 0.0
+  diff = np.nanmax(np.abs(a - ref)) if np.isfinite(ref).any() else 0.0
+  return diff / scale if scale > 0 else diff
+
+
+@pytest.fixture(scope="session")
+def gpu():
+  """The engine on cuda:0 -- fails loudly (no skip, no fallback) when unusable."""
+  import pymoc_amd
+  pymoc_amd._lib.require_device()
+  return pymoc_amd

@@ -1,0 +1,442 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Run only in the build container, where the reference checkout is mounted read-only:
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tests/golden/make_golden.py
+
+The reference (pymoc 0.0.1rc5, /root/reference/src) is imported, never copied; the
+fixtures hold inputs and the reference's outputs only.  Every fixture records the
+NumPy / SciPy versions that produced it (SciPy's solve_bvp / brentq are third-party
+arithmetic under the reference).  Profiles are always passed as
+ARRAYS: callable initial profiles change the first thermal-wind solve (hazard H7).
+
+Sets:
+  G1 column_steps      Column.timestep single/three-step I/O over grids and flags
+  G2 config1_traj      single column + thermal wind every step, 1000 steps, nz=100
+  G3 thermwind         Psi_Thermwind.solve / Psib / Psibz I/O incl. zero-thickness cells
+  G4 twocol            example_twocol physics, nz=100, steps {1,24,25,26,1000,4800}
+  G5 psi_so            Psi_SO.solve I/O (c None/0.1/1.0, tapers, tau array, no outcrop)
+  G6 twocol_so         example_twocol_plusSO physics, nz=100, steps {1,24,25,26,2400}
+  G7 so_ml, jn2018     SO_ML.timestep I/O; run_JansenNadeau_2018 physics at
+                       nz=81/dt=30d and nz=200/dt=10d, steps {1,12,13,...}
+  G8 sweep             members of the config-2/3/4/5 ensembles run through the reference
+"""
+import os
+import sys
+import warnings
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.environ.get("PYMOC_REFERENCE_SRC", "/root/reference/src"))
+
+import numpy as np
+import scipy
+
+from pymoc.modules import Column, Psi_Thermwind, Psi_SO, SO_ML  # the REFERENCE
+from pymoc_amd import configs  # parameter tables only
+
+warnings.simplefilter("ignore")  # the reference divides by zero in Psib (hazard H6)
+META = dict(numpy_version=np.__version__, scipy_version=scipy.__version__,
+            reference="pymoc 0.0.1rc5")
+
+
+def save(name, **arrays):
+  path = os.path.join(HERE, name + ".npz")
+  np.savez_compressed(path, **META, **arrays)
+  print("%-28s %7.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024.))
+
+
+# ------------------------------------------------------------------------- G1
+def g1_column_steps():
+  rng = np.random.default_rng(0)
+  out = {}
+  k = 0
+  for nz, uniform in [(4, True), (5, False), (80, True), (100, False), (100, True),
+                      (200, True)]:
+    z = np.linspace(-4000, 0, nz) if uniform else -4000 * (np.linspace(1, 0, nz)**1.5)
+    kap = 1e-5 + 3e-4 * np.exp(-z / 1000 - 4)
+    A = 8e13 * (1 + 0.1 * z / 4000)
+    dz = np.min(np.diff(z))
+    dt = min(86400. * 30, 0.4 * dz * dz / kap.max())
+    for do_conv in (False, True):
+      for bzbot in (None, 1e-7):
+        for hor in (False, True):
+          b0 = 0.03 * np.exp(z / 300) - 0.003 + 2e-4 * rng.standard_normal(nz)
+          wA = A * 3e-8 * np.sin(np.pi * z / 4000 * 3)
+          vdx = rng.standard_normal(nz) * 1e3
+          b_in = b0 + 1e-3 * rng.standard_normal(nz)
+          c = Column(z=z, kappa=kap.copy(), Area=A.copy(), b=b0.copy(), bs=0.025,
+                     bbot=-0.003, bzbot=bzbot, N2min=1e-7)
+          kw = dict(vdx_in=vdx, b_in=b_in) if hor else {}
+          c.timestep(wA=wA, dt=dt, do_conv=do_conv, **kw)
+          b1 = c.b.copy()
+          c.timestep(wA=wA, dt=dt, do_conv=do_conv, **kw)
+          c.timestep(wA=wA, dt=dt, do_conv=do_conv, **kw)
+          p = "c%02d_" % k
+          out.update({p + "z": z, p + "kappa": kap, p + "Area": A, p + "b0": b0,
+                      p + "wA": wA, p + "vdx": vdx, p + "b_in": b_in,
+                      p + "par": np.array([dt, do_conv, np.nan if bzbot is None else bzbot,
+                                           hor, 0.025, -0.003, 1e-7]),
+                      p + "b1": b1, p + "b3": c.b.copy()})
+          k += 1
+  # all-convecting and nothing-convecting columns, separate convect()/horadv()/vertadvdiff()
+  z = np.linspace(-1000, 0, 12)
+  for name, b0 in (("allconv", 0.03 + 0 * z), ("noconv", 0.01 * np.exp(z / 300)),
+                   ("holes", np.where(np.arange(12) % 3 == 0, 0.03, 0.01) + 0 * z)):
+    c = Column(z=z, kappa=1e-4, Area=1e14, b=b0.copy(), bs=0.025, N2min=2e-7)
+    c.convect()
+    out.update({"conv_%s_z" % name: z, "conv_%s_b0" % name: b0,
+                "conv_%s_b" % name: c.b.copy()})
+  out["ncases"] = np.array(k)
+  save("column_steps", **out)
+
+
+# ------------------------------------------------------------------------- G2
+def g2_config1():
+  cfg = configs.config1(nz=100)
+  z = cfg['z']
+  basin = Column(z=z, kappa=cfg['kappa'].copy(), Area=cfg['Area'], b=cfg['b0'].copy(),
+                 bs=cfg['bs'], bbot=cfg['bbot'])
+  AMOC = Psi_Thermwind(z=z, b1=cfg['b0'].copy(), f=cfg['f'])
+  AMOC.solve()
+  steps, bs_, psis = [], [], []
+  for ii in range(cfg['nsteps']):
+    basin.timestep(wA=AMOC.Psi * 1e6, dt=cfg['dt'])
+    AMOC.update(b1=basin.b)
+    AMOC.solve()
+    if (ii + 1) % 100 == 0 or ii == 0:
+      steps.append(ii + 1)
+      bs_.append(basin.b.copy())
+      psis.append(AMOC.Psi.copy())
+  save("config1_traj", steps=np.array(steps), b=np.array(bs_), Psi=np.array(psis))
+
+
+# ------------------------------------------------------------------------- G3
+def thermwind_cases():
+  rng = np.random.default_rng(3)
+  cases = []
+  for nz in (80, 100, 200):
+    z = np.linspace(-4000, 0, nz)
+    b1 = 0.03 * np.exp(z / 300) - 0.003 + 1e-5 * np.sort(rng.standard_normal(nz))
+    b2 = 1e-3 * 0.03 * np.exp(z / 300) - 0.0029
+    cases.append((z, b1, b2, 1.2e-4))
+  z = np.linspace(-4000, 0, 100)
+  # convectively adjusted north column
+  b1 = 0.03 * np.exp(z / 300)
+  b2 = np.minimum(0.004 * np.exp(z / 300), 0.0 + 1e-7 * (z + 1500))
+  cases.append((z, b1, b2, 1e-4))
+  # zero-thickness cells at the bottom (hazard H6: 0/0 in Psib)
+  b1 = 0.03 * np.exp(z / 300)
+  b1[0] = b1[1]
+  b2 = -0.001 * (z / z[0])**2
+  b2[:3] = b2[3]
+  cases.append((z, b1, b2, 1.2e-4))
+  # identical columns (Psi == 0), and a north column lighter than the basin aloft
+  cases.append((z, b1.copy(), b1.copy(), 1.2e-4))
+  cases.append((z, 0.02 * np.exp(z / 500), 0.025 * np.exp(z / 200) - 0.002, 1.2e-4))
+  # non-uniform grid
+  zn = -4000 * (np.linspace(1, 0, 90)**1.7)
+  cases.append((zn, 0.03 * np.exp(zn / 300) - 0.001, 0.002 * np.exp(zn / 800) - 0.001,
+                1.2e-4))
+  return cases
+
+
+def g3_thermwind():
+  out = {}
+  for k, (z, b1, b2, f) in enumerate(thermwind_cases()):
+    T = Psi_Thermwind(z=z, b1=b1.copy(), b2=b2.copy(), f=f)
+    T.solve()
+    psib = T.Psib()
+    pz = T.Psibz()
+    p = "c%02d_" % k
+    out.update({p + "z": z, p + "b1": b1, p + "b2": b2, p + "f": np.array(f),
+                p + "Psi": T.Psi.copy(), p + "bgrid": T.bgrid.copy(), p + "psib": psib,
+                p + "psibz1": pz[0], p + "psibz2": pz[1]})
+  out["ncases"] = np.array(k + 1)
+  save("thermwind", **out)
+
+
+# --------------------------------------------------------------------- G4 / G6
+def ref_twocol(m, nsteps, snaps, so=False):
+  z = m['z']
+  AMOC = Psi_Thermwind(z=z, b1=m['b_basin0'].copy(), b2=m['b_north0'].copy(), f=m['f'])
+  AMOC.solve()
+  pib, pin = AMOC.Psibz()
+  if so:
+    SO = Psi_SO(z=z, y=m['y'], b=m['b_basin0'].copy(), bs=m['bs_SO'].copy(),
+                tau=float(m['tau']), f=m['f'], L=m['L'], KGM=float(m['KGM']), c=m['c'],
+                bvp_with_Ek=m['bvp_with_Ek'])
+    SO.solve()
+  kap = m['kappa'] + 0 * z
+  basin = Column(z=z, kappa=kap.copy(), Area=float(m['A_basin']), b=m['b_basin0'].copy(),
+                 bs=float(m['bs']), bbot=float(m['bbot']))
+  north = Column(z=z, kappa=kap.copy(), Area=float(m['A_north']), b=m['b_north0'].copy(),
+                 bs=float(m['bs_north']), bbot=float(m['bbot']))
+  out = {}
+  for ii in range(nsteps):
+    wAb = (pib - SO.Psi) * 1e6 if so else pib * 1e6
+    wAN = -pin * 1e6
+    basin.timestep(wA=wAb, dt=m['dt'])
+    north.timestep(wA=wAN, dt=m['dt'], do_conv=True)
+    if ii % m['MOC_up_iters'] == 0:
+      AMOC.update(b1=basin.b, b2=north.b)
+      AMOC.solve()
+      pib, pin = AMOC.Psibz()
+      if so:
+        SO.update(b=basin.b)
+        SO.solve()
+    if ii + 1 in snaps:
+      out[ii + 1] = dict(b_basin=basin.b.copy(), b_north=north.b.copy(),
+                         Psi=AMOC.Psi.copy(), Psi_iso_b=pib.copy(), Psi_iso_n=pin.copy(),
+                         Psi_SO=SO.Psi.copy() if so else 0 * z)
+  return out
+
+
+def pack(prefix, snaps):
+  out = {}
+  for step, fields in snaps.items():
+    for k, v in fields.items():
+      out["%ss%05d_%s" % (prefix, step, k)] = v
+  return out
+
+
+def g4_twocol():
+  m = configs.twocol_member(nz=100, kappa_4k=2.5e-4)
+  snaps = ref_twocol(m, 4800, {1, 24, 25, 26, 1000, 4800})
+  save("twocol", **pack("", snaps))
+
+
+def g6_twocol_so():
+  m = configs.twocol_so_member(nz=100, ny=40)
+  snaps = ref_twocol(m, 2400, {1, 24, 25, 26, 2400}, so=True)
+  save("twocol_so", **pack("", snaps))
+
+
+# ------------------------------------------------------------------------- G5
+def psi_so_cases():
+  cases = []
+  for nz in (80, 100):
+    z = np.linspace(-4000, 0, nz)
+    y = np.linspace(0, 2e6, 40)
+    b = 0.03 * np.exp(z / 300) - 0.0005 + 0.0004 * z / 4000
+    bs = 0.03 * (y / y[-1])**2
+    tau_arr = 0.13 * (1 + 0.3 * np.sin(np.pi * y / y[-1]))
+    for kw in [dict(), dict(c=0.1), dict(c=0.1, bvp_with_Ek=True),
+               dict(c=1.0, bvp_with_Ek=True),
+               dict(Hsill=500., HEk=100., Htapertop=200., Htaperbot=300.),
+               dict(c=0.1, bvp_with_Ek=True, Htapertop=200., Htaperbot=300., Hsill=500.)]:
+      for tau in (0.13, tau_arr):
+        cases.append((z, y, b, bs, tau, dict(f=1e-4, L=5e6, KGM=1000., **kw)))
+  # JN2018-like: bs with a minimum away from y[0], c=None, b colder than any bs at depth
+  m = configs.jn2018_member(nz=81)
+  bs = m['bs_SO0'].copy()
+  bs[1:6] -= 2e-4 * np.array([1, 2, 3, 2, 1])
+  cases.append((m['z'], m['y'], m['b_basin0'], bs, 0.12, dict(f=1.2e-4, L=4e6, KGM=800.)))
+  cases.append((m['z'], m['y'], m['b_basin0'] + 0.001, bs, 0.12,
+                dict(f=1.2e-4, L=4e6, KGM=800., smax=0.002)))
+  return cases
+
+
+def g5_psi_so():
+  out = {}
+  for k, (z, y, b, bs, tau, kw) in enumerate(psi_so_cases()):
+    S = Psi_SO(z=z, y=y, b=b.copy(), bs=bs.copy(),
+               tau=tau if np.isscalar(tau) else tau.copy(), **kw)
+    S.solve()
+    ys = np.array([S.ys(bb) for bb in b])
+    p = "c%02d_" % k
+    out.update({p + "z": z, p + "y": y, p + "b": b, p + "bs": bs,
+                p + "tau": np.asarray(tau), p + "Psi": S.Psi.copy(),
+                p + "Psi_Ek": S.Psi_Ek.copy(), p + "Psi_GM": S.Psi_GM.copy(),
+                p + "ys": ys})
+    for name in ("f", "rho", "L", "KGM", "c", "Hsill", "HEk", "Htapertop", "Htaperbot",
+                 "smax"):
+      v = getattr(S, name)
+      out[p + "kw_" + name] = np.array(np.nan if v is None else v, dtype=float)
+    out[p + "kw_bvp_with_Ek"] = np.array(bool(S.bvp_with_Ek))
+  out["ncases"] = np.array(k + 1)
+  save("psi_so", **out)
+
+
+# ------------------------------------------------------------------------- G7
+def g7_so_ml():
+  rng = np.random.default_rng(7)
+  m = configs.jn2018_member(nz=81)
+  z, y = m['z'], m['y']
+  out = {"y": y, "z": z, "surflux": m['surflux'], "rest_mask": m['rest_mask'],
+         "b_rest": m['b_rest'], "b_basin": m['b_basin0'],
+         "par": np.array([m['Ks'], m['h'], m['L'], m['v_pist']])}
+  k = 0
+  for case in range(4):
+    Psi_b = 5 * np.sin(np.pi * z / 4000 * (1 + case)) * (-1)**case
+    if case == 2:
+      Psi_b[:10] = 0.
+    if case == 3:
+      Psi_b = -np.abs(Psi_b) - 0.1
+    for dt in (86400. * 30, 86400. * 10):
+      bs0 = m['bs_SO_init'] + 1e-4 * rng.standard_normal(y.size)
+      ch = SO_ML(y=y, h=m['h'], L=m['L'], Ks=m['Ks'], surflux=m['surflux'].copy(),
+                 rest_mask=m['rest_mask'].copy(), b_rest=m['b_rest'].copy(),
+                 v_pist=m['v_pist'], bs=bs0.copy())
+      ch.timestep(b_basin=m['b_basin0'], Psi_b=Psi_b, dt=dt)
+      bs1, ps1 = ch.bs.copy(), ch.Psi_s.copy()
+      for _ in range(4):
+        ch.timestep(b_basin=m['b_basin0'], Psi_b=Psi_b, dt=dt)
+      p = "c%02d_" % k
+      out.update({p + "Psi_b": Psi_b, p + "dt": np.array(dt), p + "bs0": bs0,
+                  p + "bs1": bs1, p + "Psi_s1": ps1, p + "bs5": ch.bs.copy(),
+                  p + "Psi_s5": ch.Psi_s.copy()})
+      k += 1
+  out["ncases"] = np.array(k)
+  save("so_ml", **out)
+
+
+def ref_jn2018(m, nsteps, snaps):
+  z, y = m['z'], m['y']
+  kappa, kappaeff = configs.jn2018_kappa, configs.jn2018_kappaeff
+  b_basin, b_north, bs_SO = m['b_basin0'].copy(), m['b_north0'].copy(), m['bs_SO_init'].copy()
+  AMOC = Psi_Thermwind(z=z, b1=b_basin, b2=b_north, f=m['f'])
+  AMOC.solve()
+  PsiSO = Psi_SO(z=z, y=y, b=b_basin, bs=bs_SO, tau=float(m['tau']), f=m['f'], L=m['L'],
+                 KGM=float(m['KGM']))
+  PsiSO.solve()
+  bs_SO[-1] = m['bs']
+  basin = Column(z=z, kappa=kappaeff, Area=m['A_basin'], b=b_basin, bs=float(m['bs']),
+                 bbot=b_basin[0])
+  north = Column(z=z, kappa=kappaeff, Area=m['A_north'], b=b_north,
+                 bs=float(m['bs_north']), bbot=b_north[0])
+  channel = SO_ML(y=y, h=m['h'], L=m['L'], Ks=m['Ks'], surflux=m['surflux'],
+                  rest_mask=m['rest_mask'], b_rest=m['b_rest'], v_pist=m['v_pist'],
+                  bs=bs_SO)
+  out = {}
+  for ii in range(nsteps):
+    if ii % m['MOC_up_iters'] == 0:
+      AMOC.update(b1=basin.b, b2=north.b)
+      AMOC.solve()
+      [Psi_res_b, Psi_res_n] = AMOC.Psibz(nb=m['nb'])
+      PsiSO.update(b=basin.b, bs=channel.bs)
+      PsiSO.solve()
+    wAb = (Psi_res_b - PsiSO.Psi) * 1e6
+    wAN = -Psi_res_n * 1e6
+    if PsiSO.Psi[1] < 0:
+      basin.bbot = channel.bs[0]
+      basin.kappa = kappaeff
+    if Psi_res_b[1] > 0 and north.b[0] < basin.b[1] and north.b[0] < channel.bs[0]:
+      basin.bbot = north.b[0]
+      basin.kappa = kappaeff
+    elif PsiSO.Psi[1] >= 0:
+      basin.bbot = basin.b[1]
+      basin.kappa = kappa
+    if Psi_res_n[1] < 0 and basin.b[0] < north.b[1]:
+      north.bbot = basin.b[0]
+      north.kappa = kappaeff
+    else:
+      north.bbot = north.b[1]
+      north.kappa = kappa
+    basin.timestep(wA=wAb, dt=m['dt'], do_conv=True)
+    north.timestep(wA=wAN, dt=m['dt'], do_conv=True)
+    channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi, dt=m['dt'])
+    if ii + 1 in snaps:
+      out[ii + 1] = dict(b_basin=basin.b.copy(), b_north=north.b.copy(),
+                         bs_SO=channel.bs.copy(), Psi=AMOC.Psi.copy(),
+                         Psi_SO=PsiSO.Psi.copy(), Psi_iso_b=Psi_res_b.copy(),
+                         Psi_iso_n=Psi_res_n.copy(), Psi_s=channel.Psi_s.copy())
+  return out
+
+
+def g7_jn2018():
+  m = configs.jn2018_member(nz=81, dt_days=30.)
+  save("jn2018_nz81", **pack("", ref_jn2018(m, 1200, {1, 12, 13, 14, 240, 1200})))
+  m = configs.jn2018_member(nz=200, dt_days=10.)
+  save("jn2018_nz200", **pack("", ref_jn2018(m, 1200, {1, 36, 37, 38, 360, 1200})))
+
+
+# ------------------------------------------------------------------------- G8
+def member_of(cfg, i, keys_1d=(), keys_2d=()):
+  m = dict(cfg)
+  for k in keys_1d:
+    m[k] = cfg[k][i]
+  for k in keys_2d:
+    m[k] = cfg[k][i]
+  return m
+
+
+def g8_sweep():
+  out = {}
+  # config 2: 16 members x 200 steps of Column.timestep with static wA
+  c2 = configs.config2(N=1024)
+  pick = np.arange(0, 1024, 64)
+  res = []
+  for i in pick:
+    col = Column(z=c2['z'], kappa=c2['kappa'][i].copy(), Area=c2['Area'][i].copy(),
+                 b=c2['b0'][i].copy(), bs=float(c2['bs'][i]), bbot=float(c2['bbot'][i]),
+                 N2min=float(c2['N2min'][i]))
+    for _ in range(200):
+      col.timestep(wA=c2['wA'][i], dt=c2['dt'], do_conv=bool(c2['do_conv'][i]))
+    res.append(col.b.copy())
+  out.update(c2_members=pick, c2_nsteps=np.array(200), c2_b=np.array(res))
+  # config 3: 16 members x 241 steps
+  c3 = configs.config3(N=4096)
+  pick = np.arange(0, 4096, 256)
+  rb, rn, rp = [], [], []
+  for i in pick:
+    m = member_of(c3, i, ('A_basin', 'A_north', 'bs', 'bs_north', 'bbot'),
+                  ('kappa', 'b_basin0', 'b_north0'))
+    s = ref_twocol(m, 241, {241})[241]
+    rb.append(s['b_basin'])
+    rn.append(s['b_north'])
+    rp.append(s['Psi'])
+  out.update(c3_members=pick, c3_nsteps=np.array(241), c3_b_basin=np.array(rb),
+             c3_b_north=np.array(rn), c3_Psi=np.array(rp))
+  # config 4: 8 members x 121 steps
+  c4 = configs.config4(N=8192)
+  pick = np.arange(0, 8192, 1024)
+  rb, rn, rp, rs = [], [], [], []
+  for i in pick:
+    m = member_of(c4, i, ('A_basin', 'A_north', 'bs', 'bs_north', 'bbot', 'tau', 'KGM'),
+                  ('kappa', 'b_basin0', 'b_north0', 'bs_SO'))
+    s = ref_twocol(m, 121, {121}, so=True)[121]
+    rb.append(s['b_basin'])
+    rn.append(s['b_north'])
+    rp.append(s['Psi'])
+    rs.append(s['Psi_SO'])
+  out.update(c4_members=pick, c4_nsteps=np.array(121), c4_b_basin=np.array(rb),
+             c4_b_north=np.array(rn), c4_Psi=np.array(rp), c4_Psi_SO=np.array(rs))
+  # config 5 (nz=200, dt=10 d): 8 members x 72 steps, and x 399 steps for the members whose
+  # trajectory is comparable that long.  Longer windows hit the reference's own
+  # discontinuity: under the no-flux bottom BC b[0] is the PREVIOUS step's b[1], so the
+  # bottom cell's thickness b[1]-b[0] is last-bit noise whose sign decides whether Psib
+  # counts that cell's transport (hazard H6); members 0 and 512 flip at steps 145 / 73.
+  c5 = configs.config5(N=4096)
+  pick = np.arange(0, 4096, 512)
+  keys = ('b_basin', 'b_north', 'bs_SO', 'Psi_SO')
+  short = {k: [] for k in keys}
+  long_ = {k: [] for k in keys}
+  for i in pick:
+    m = member_of(c5, i, ('bs', 'bs_north', 'KGM', 'tau'),
+                  ('surflux', 'b_rest', 'bs_SO_init', 'bs_SO0', 'b_basin0', 'b_north0'))
+    s = ref_jn2018(m, 399, {72, 399})
+    for k in keys:
+      short[k].append(s[72][k])
+      if i >= 1024:
+        long_[k].append(s[399][k])
+  out.update(c5_members=pick, c5_nsteps=np.array(72), c5_long_members=pick[2:],
+             c5_long_nsteps=np.array(399))
+  for k in keys:
+    out["c5_" + k] = np.array(short[k])
+    out["c5_long_" + k] = np.array(long_[k])
+  save("sweep", **out)
+
+
+if __name__ == "__main__":
+  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+  table = dict(g1=[g1_column_steps], g2=[g2_config1], g3=[g3_thermwind], g4=[g4_twocol],
+               g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
+               g8=[g8_sweep])
+  for w in which:
+    for fn in table[w]:
+      fn()
