@@ -118,6 +118,26 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
                     const double *b_in, double dt, int32_t nsteps, int32_t ops,
                     int32_t lanes_per_col, pm_stream_t stream);
 
+/* ------------------------------------------------------------------ RCCL
+ * One process per GPU.  The ensemble is sharded by member, stepping needs no
+ * communication; the only exchange is the gather of per-member output at diagnostic
+ * time (the reference has no distributed path: SURVEY.md section 5/8e).  librccl.so is
+ * dlopen()ed on first use, so single-GPU runs never load it.
+ * Bootstrap: rank 0 calls pm_comm_unique_id and ships the 128 bytes to the other ranks
+ * by any host channel; then every rank calls pm_comm_init.                          */
+#define PM_COMM_ID_BYTES 128
+int pm_comm_unique_id(void *id128);
+int pm_comm_init(pm_comm_t *comm, int32_t nranks, int32_t rank, const void *id128);
+int pm_comm_destroy(pm_comm_t comm);
+/* recv[nranks][count] <- send[count] of every rank (fp64, device pointers) */
+int pm_comm_allgather(pm_comm_t comm, const void *send, void *recv, size_t count,
+                      pm_stream_t stream);
+/* elementwise max over ranks (fp64, device pointers; in place allowed) */
+int pm_comm_allreduce_max(pm_comm_t comm, const void *send, void *recv, size_t count,
+                          pm_stream_t stream);
+/* all ranks have reached this point AND their `stream` work before it is done */
+int pm_comm_barrier(pm_comm_t comm, pm_stream_t stream);
+
 /* debug/test: lane-shift primitive self check (DPP wave shifts vs ds_bpermute) */
 int pm_selftest_lane_shift(int32_t *mismatches);
 

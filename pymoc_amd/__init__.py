@@ -11,3 +11,5 @@ from .columns import ColumnBatch
 from . import modules
 from . import utils
 from .modules import Column
+from . import configs
+from . import sharding

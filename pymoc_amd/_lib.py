@@ -70,6 +70,12 @@ SIGNATURES = {
     "pm_graph_destroy": (C.c_int, [C.c_void_p]),
     "pm_column_steps": (C.c_int, [C.POINTER(pm_columns), c_dp, c_dp, c_dp, C.c_double,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "pm_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pm_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
+    "pm_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pm_comm_allgather": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_size_t, C.c_void_p]),
+    "pm_comm_allreduce_max": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_size_t, C.c_void_p]),
+    "pm_comm_barrier": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pm_selftest_lane_shift": (C.c_int, [C.POINTER(C.c_int32)]),
 }
 

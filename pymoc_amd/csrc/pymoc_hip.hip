@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include "common.hip.h"
 #include "column.hip.h"
+#include "comm.hip.h"
 
 namespace pm {
 
@@ -175,7 +176,7 @@ int pm_graph_end_capture(pm_stream_t stream, pm_graph_t *graph) {
   PM_HIP(hipStreamEndCapture(resolve_stream(stream), &g));
   hipGraphExec_t ge = nullptr;
   hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-  hipGraphDestroy(g);
+  (void)hipGraphDestroy(g);
   if (e != hipSuccess)
     return fail(PM_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
   *graph = (pm_graph_t)ge;
@@ -220,6 +221,77 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
     case 32: return dispatch_column_steps_P<32>(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
     default: return dispatch_column_steps_P<64>(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
   }
+}
+
+// ---------------------------------------------------------------------- RCCL
+int pm_comm_unique_id(void *id128) {
+  PM_REQUIRE(id128, "id128 is NULL");
+  if (!nccl().ok) return fail(PM_ENCCL, "librccl.so could not be loaded: %s", dlerror());
+  NcclId id;
+  PM_NCCL(nccl().GetUniqueId(&id));
+  memcpy(id128, id.internal, PM_COMM_ID_BYTES);
+  return PM_OK;
+}
+
+int pm_comm_init(pm_comm_t *comm, int32_t nranks, int32_t rank, const void *id128) {
+  PM_REQUIRE(comm && id128, "NULL argument");
+  PM_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
+  if (!nccl().ok) return fail(PM_ENCCL, "librccl.so could not be loaded: %s", dlerror());
+  Comm *c = new Comm();
+  c->nranks = nranks;
+  c->rank = rank;
+  NcclId id;
+  memcpy(id.internal, id128, PM_COMM_ID_BYTES);
+  int r = nccl().CommInitRank(&c->comm, nranks, id, rank);
+  if (r != 0) {
+    delete c;
+    return fail(PM_ENCCL, "ncclCommInitRank failed: %s", nccl().GetErrorString(r));
+  }
+  hipError_t e = hipMalloc((void **)&c->scratch, 2 * sizeof(double));
+  if (e != hipSuccess) {
+    nccl().CommDestroy(c->comm);
+    delete c;
+    return fail(PM_EHIP, "hipMalloc: %s", hipGetErrorString(e));
+  }
+  *comm = (pm_comm_t)c;
+  return PM_OK;
+}
+
+int pm_comm_destroy(pm_comm_t comm) {
+  if (!comm) return PM_OK;
+  Comm *c = (Comm *)comm;
+  if (c->scratch) (void)hipFree(c->scratch);
+  int r = nccl().CommDestroy(c->comm);
+  delete c;
+  if (r != 0) return fail(PM_ENCCL, "ncclCommDestroy: %s", nccl().GetErrorString(r));
+  return PM_OK;
+}
+
+int pm_comm_allgather(pm_comm_t comm, const void *send, void *recv, size_t count,
+                      pm_stream_t stream) {
+  PM_REQUIRE(comm && send && recv, "NULL argument");
+  Comm *c = (Comm *)comm;
+  PM_NCCL(nccl().AllGather(send, recv, count, NCCL_FLOAT64, c->comm, resolve_stream(stream)));
+  return PM_OK;
+}
+
+int pm_comm_allreduce_max(pm_comm_t comm, const void *send, void *recv, size_t count,
+                          pm_stream_t stream) {
+  PM_REQUIRE(comm && send && recv, "NULL argument");
+  Comm *c = (Comm *)comm;
+  PM_NCCL(nccl().AllReduce(send, recv, count, NCCL_FLOAT64, NCCL_MAX, c->comm,
+                           resolve_stream(stream)));
+  return PM_OK;
+}
+
+int pm_comm_barrier(pm_comm_t comm, pm_stream_t stream) {
+  PM_REQUIRE(comm, "comm is NULL");
+  Comm *c = (Comm *)comm;
+  hipStream_t st = resolve_stream(stream);
+  PM_HIP(hipMemsetAsync(c->scratch, 0, 2 * sizeof(double), st));
+  PM_NCCL(nccl().AllReduce(c->scratch, c->scratch + 1, 1, NCCL_FLOAT64, NCCL_MAX, c->comm, st));
+  PM_HIP(hipStreamSynchronize(st));
+  return PM_OK;
 }
 
 int pm_selftest_lane_shift(int32_t *mismatches) {

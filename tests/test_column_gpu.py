@@ -1,0 +1,127 @@
+"""GPU parity of K1 (pm_column_steps) through the C-ABI: bit-exact against the oracle
+and against the reference's golden vectors."""
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import load_golden
+from pymoc_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lane_shift_selftest(gpu):
+  import ctypes
+  from pymoc_amd._lib import lib, check
+  n = ctypes.c_int32(-1)
+  check(lib.pm_selftest_lane_shift(ctypes.byref(n)))
+  assert n.value == 0
+
+
+@pytest.mark.parametrize("G", [0, 16, 32, 64])
+def test_column_golden_bitwise(gpu, G):
+  g = load_golden("column_steps")
+  for k in range(int(g["ncases"])):
+    p = "c%02d_" % k
+    dt, do_conv, bzbot, hor, bs, bbot, N2min = g[p + "par"]
+    batch = gpu.ColumnBatch(g[p + "z"], g[p + "kappa"], g[p + "Area"], g[p + "b0"], bs=bs,
+                            bbot=bbot, bzbot=None if np.isnan(bzbot) else bzbot,
+                            N2min=N2min, do_conv=bool(do_conv))
+    kw = dict(vdx_in=g[p + "vdx"], b_in=g[p + "b_in"]) if hor else {}
+    batch.steps(g[p + "wA"], dt, 1, lanes_per_col=G, **kw)
+    assert np.array_equal(batch.get_b()[0], g[p + "b1"]), (k, G)
+    batch.steps(g[p + "wA"], dt, 2, lanes_per_col=G, **kw)  # two fused steps
+    assert np.array_equal(batch.get_b()[0], g[p + "b3"]), (k, G)
+    assert batch.get_nonfinite()[0] == 0
+
+
+@pytest.mark.parametrize("name", ["allconv", "noconv", "holes"])
+def test_convect_golden_bitwise(gpu, name):
+  from pymoc_amd import _lib
+  g = load_golden("column_steps")
+  z = g["conv_%s_z" % name]
+  for G in (16, 64):
+    batch = gpu.ColumnBatch(z, 1e-4, 1e14, g["conv_%s_b0" % name], bs=0.025, N2min=2e-7,
+                            do_conv=True)
+    batch.steps(None, 1.0, 1, ops=_lib.PM_OP_CONVECT, lanes_per_col=G)
+    assert np.array_equal(batch.get_b()[0], g["conv_%s_b" % name])
+
+
+@pytest.mark.parametrize("nz", [2, 3, 17, 64, 65, 100, 128, 129, 200, 257, 513, 1024])
+def test_column_ragged_sizes_vs_oracle(gpu, nz):
+  rng = np.random.default_rng(nz)
+  ncols = 37
+  z = np.sort(rng.uniform(-4000, 0, nz))
+  z[-1] = 0.
+  kap = 1e-5 + 1e-4 * rng.random((ncols, nz))
+  area = 8e13 * (1 + 0.2 * rng.random((ncols, nz)))
+  dzmin = np.diff(z).min()
+  dt = 0.3 * dzmin**2 / kap.max()
+  b0 = np.sort(0.03 * rng.random((ncols, nz)), axis=1) + 1e-3 * rng.standard_normal(
+      (ncols, nz))
+  wA = area * 1e-7 * dzmin / 40. * rng.standard_normal((ncols, nz))
+  do_conv = rng.random(ncols) < 0.5
+  bs = rng.uniform(0.01, 0.03, ncols)
+  bbot = rng.uniform(-0.003, 0., ncols)
+  N2min = np.full(ncols, 1e-7)
+  for G in (0, 16, 32, 64):
+    batch = gpu.ColumnBatch(z, kap, area, b0, bs=bs, bbot=bbot, N2min=N2min,
+                            do_conv=do_conv)
+    batch.steps(wA, dt, 5, lanes_per_col=G)
+    ref = O.column_ensemble_steps(z, kap, area, b0, wA, dt, do_conv, bs, bbot, N2min, 5)
+    assert np.array_equal(batch.get_b(), ref), (nz, G)
+
+
+def test_empty_batch_and_zero_steps(gpu):
+  z = np.linspace(-100., 0., 10)
+  batch = gpu.ColumnBatch(z, 1e-4, 1e14, np.zeros((3, 10)) + 0.01)
+  b0 = batch.get_b()
+  batch.steps(np.zeros((3, 10)), 1.0, 0)
+  assert np.array_equal(batch.get_b(), b0)
+
+
+def test_nonfinite_members_are_flagged_not_raised(gpu):
+  z = np.linspace(-100., 0., 10)
+  b = np.zeros((4, 10)) + 0.01
+  b[2, 5] = np.nan
+  batch = gpu.ColumnBatch(z, 1e-4, 1e14, b)
+  batch.steps(np.zeros((4, 10)), 1.0, 1)
+  assert list(batch.get_nonfinite()) == [0, 0, 1, 0]
+
+
+def test_config2_members_match_reference_golden(gpu):
+  """BASELINE config 2 members, 200 fused steps, vs the reference run member by member."""
+  g = load_golden("sweep")
+  c = configs.config2(N=1024)
+  batch = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"], bs=c["bs"],
+                          bbot=c["bbot"], N2min=c["N2min"], do_conv=c["do_conv"])
+  batch.steps(c["wA"], c["dt"], int(g["c2_nsteps"]))
+  b = batch.get_b()
+  assert np.array_equal(b[g["c2_members"]], g["c2_b"])
+  assert batch.get_nonfinite().sum() == 0
+
+
+def test_config2_full_size_properties(gpu):
+  """Full BASELINE size (1024 x 100, 1000 steps): step-splitting invariance (1000 fused
+  == 10 x 100 == 40 x 25 launches), lane-geometry invariance, and a 64-member slice
+  against the oracle."""
+  c = configs.config2(N=1024)
+  def run(chunks, G):
+    batch = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"], bs=c["bs"],
+                            bbot=c["bbot"], N2min=c["N2min"], do_conv=c["do_conv"])
+    for n in chunks:
+      batch.steps(c["wA"], c["dt"], n, lanes_per_col=G)
+    return batch.get_b()
+  b_one = run([1000], 0)
+  assert np.isfinite(b_one).all()
+  assert np.array_equal(b_one, run([100] * 10, 16))
+  assert np.array_equal(b_one, run([25] * 40, 32))
+  sl = slice(480, 544)
+  ref = O.column_ensemble_steps(c["z"], c["kappa"][sl], c["Area"][sl], c["b0"][sl],
+                                c["wA"][sl], c["dt"], c["do_conv"][sl], c["bs"][sl],
+                                c["bbot"][sl], c["N2min"][sl], 1000)
+  assert np.array_equal(b_one[sl], ref)
+  # boundary conditions hold exactly
+  assert np.array_equal(b_one[:, 0], c["bbot"])
+  noconv = ~c["do_conv"]
+  assert np.array_equal(b_one[noconv, -1], c["bs"][noconv])

@@ -1,0 +1,138 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol the header
+declares, host-side coercion and error text match the reference's contract, config
+generators are shard-invariant.  No compute call is made (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _header_symbols():
+  text = open(os.path.join(ROOT, "include", "pymoc_hip.h")).read()
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  return sorted(set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+  from pymoc_amd import _lib
+  names = _header_symbols()
+  assert len(names) >= 20
+  for n in names:
+    assert hasattr(_lib.lib, n), "libpymoc_hip.so does not export %s" % n
+    assert n in _lib.SIGNATURES, "no ctypes signature for %s" % n
+  assert set(_lib.SIGNATURES) == set(names)
+  assert b"gfx950" in _lib.lib.pm_version()
+
+
+def test_struct_layout_matches_header():
+  from pymoc_amd import _lib
+  # 4 int32 + 12 pointers
+  assert ctypes.sizeof(_lib.pm_columns) == 16 + 12 * 8
+
+
+def test_no_device_fails_loudly():
+  from pymoc_amd import _lib
+  n = ctypes.c_int(-1)
+  rc = _lib.lib.pm_device_count(ctypes.byref(n))
+  if rc == 0 and n.value > 0:
+    pytest.skip("a GPU is visible here")
+  with pytest.raises(_lib.PmError):
+    _lib.require_device()
+  import pymoc_amd
+  col = pymoc_amd.Column(z=np.linspace(-4000., 0., 10), kappa=1e-5, Area=1e14, b=0.01)
+  with pytest.raises(_lib.PmError):
+    col.timestep(wA=0., dt=1.)
+
+
+def test_product_does_not_import_oracle():
+  pkg = os.path.join(ROOT, "pymoc_amd")
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith((".py", ".h", ".hip")):
+        src = open(os.path.join(dirpath, f)).read()
+        assert "import oracle" not in src and "from oracle" not in src, f
+        assert "pymoc_oracle" not in src, f
+        assert "import torch" not in src, f
+
+
+# ---- utils contract (reference tests/utils/test_make_func.py, test_make_array.py)
+def test_make_func_contract():
+  from pymoc_amd.utils import make_func
+  z = np.linspace(-10., 0., 5)
+  f = lambda x: 2 * x  # noqa: E731
+  assert make_func(f, z, 'f') is f
+  arr = np.arange(5.)
+  g = make_func(arr, z, 'g')
+  assert np.array_equal(g(z), arr)
+  arr[2] = 99.  # closure aliases the caller's array (make_func.py:32-37)
+  assert g(z[2]) == 99.
+  h = make_func(3.0, z, 'h')
+  assert np.array_equal(h(z), 3.0 + 0 * z)
+  with pytest.raises(TypeError) as e:
+    make_func(1, z, 'myst')
+  assert str(e.value) == "('myst', 'needs to be either function, numpy array, or float')"
+
+
+def test_make_array_contract():
+  from pymoc_amd.utils import make_array
+  z = np.linspace(-10., 0., 5)
+  arr = np.arange(5.)
+  assert make_array(arr, z, 'a') is arr
+  assert np.array_equal(make_array(lambda x: x**2, z, 'a'), z**2)
+  assert np.array_equal(make_array(1.5, z, 'a'), 1.5 + 0 * z)
+  with pytest.raises(TypeError) as e:
+    make_array(1, z, 'myst')
+  assert str(e.value) == "('myst', 'needs to be either function, numpy array, or float')"
+
+
+def test_column_constructor_contract():
+  from pymoc_amd import Column
+  z = np.linspace(-4000., 0., 20)
+  with pytest.raises(TypeError) as e:
+    Column(z=1, kappa=1e-5, Area=1e14)
+  assert str(e.value) == 'z needs to be numpy array providing grid levels'
+  with pytest.raises(TypeError) as e:
+    Column(z=np.array([]), kappa=1e-5, Area=1e14)
+  assert str(e.value) == 'z needs to be numpy array providing grid levels'
+  with pytest.raises(TypeError) as e:
+    Column(z=z, kappa=1, Area=1e14)
+  assert str(e.value) == "('kappa', 'needs to be either function, numpy array, or float')"
+  with pytest.raises(TypeError) as e:
+    Column(z=z, kappa=1e-5, Area=1e14, b=1)
+  assert str(e.value) == "('b', 'needs to be either function, numpy array, or float')"
+  b = 0.02 * np.exp(z / 300.)
+  c = Column(z=z, kappa=lambda x: 1e-5 + 0 * x, Area=8e13, b=b, bs=0.02, bbot=0.001,
+             bzbot=None, N2min=2e-7)
+  assert c.z is z and c.b is b  # arrays are aliased, not copied (column.py:54,67)
+  assert (c.bs, c.bbot, c.bzbot, c.N2min) == (0.02, 0.001, None, 2e-7)
+  assert np.array_equal(c.bz, np.gradient(b, z))
+  assert np.array_equal(c.Akappa(z), 8e13 * (1e-5 + 0 * z))
+  assert np.array_equal(c.dAkappa_dz(z), np.gradient(8e13 * (1e-5 + 0 * z), z))
+
+
+def test_configs_are_shard_invariant():
+  from pymoc_amd import configs
+  full = configs.config2(N=64)
+  part = configs.config2(N=64, members=(16, 48))
+  for k in ("kappa", "Area", "wA", "b0", "bs", "do_conv"):
+    assert np.array_equal(full[k][16:48], part[k])
+  full = configs.config3(N=32)
+  part = configs.config3(N=32, members=(8, 9))
+  assert np.array_equal(full["kappa"][8:9], part["kappa"])
+  full = configs.config4(N=32)
+  part = configs.config4(N=32, members=(30, 32))
+  assert np.array_equal(full["tau"][30:32], part["tau"])
+  full = configs.config5(N=8)
+  part = configs.config5(N=8, members=(2, 5))
+  assert np.array_equal(full["b_basin0"][2:5], part["b_basin0"])
+
+
+def test_explicit_scheme_limits_hold_for_the_bench_configs():
+  from pymoc_amd import configs
+  for c in (configs.config2(N=256), configs.config3(N=256), configs.config4(N=256)):
+    dz = np.diff(c["z"]).min()
+    assert (c["kappa"].max() * c["dt"] / dz**2) < 0.5
