@@ -118,6 +118,41 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
                     const double *b_in, double dt, int32_t nsteps, int32_t ops,
                     int32_t lanes_per_col, pm_stream_t stream);
 
+/* ------------------------------------------------------------------ Psi_Thermwind
+ * Replaces pymoc.modules.Psi_Thermwind for n independent members on one grid z[nz]:
+ *   Psi_Thermwind.solve  src/pymoc/modules/psi_thermwind.py:125-135  (PM_TW_SOLVE)
+ *   Psi_Thermwind.Psib   src/pymoc/modules/psi_thermwind.py:137-185  (PM_TW_PSIB)
+ *   Psi_Thermwind.Psibz  src/pymoc/modules/psi_thermwind.py:187-208  (PM_TW_PSIBZ,
+ *                        needs PM_TW_PSIB in the same call)
+ * and, optionally, the drivers' coupling to the columns (examples/example_twocol.py
+ * :87-88, example_twocol_plusSO.py:105-106): wA1 = (psibz1 - Psi_SO)*1e6 (Psi_SO NULL
+ * -> psibz1*1e6), wA2 = -psibz2*1e6.  Without PM_TW_SOLVE, Psi is an input.          */
+#define PM_TW_SOLVE 1
+#define PM_TW_PSIB 2
+#define PM_TW_PSIBZ 4
+#define PM_TW_WA_PSI 8 /* with PM_TW_SOLVE: wA1 = Psi*1e6 (example_timestepping.py:75) */
+
+typedef struct pm_thermwind {
+  int32_t n;            /* members                                               */
+  int32_t nz;           /* levels (2 <= nz <= 1024)                              */
+  int32_t nb;           /* isopycnal classes of Psib (reference default 500)     */
+  int32_t reserved;
+  const double *z;      /* [nz]    shared grid                                   */
+  const double *b1;     /* [n][nz] buoyancy of the basin column                  */
+  const double *b2;     /* [n][nz] buoyancy of the northern column               */
+  const double *f;      /* [n]     Coriolis parameter                            */
+  double *Psi;          /* [n][nz] overturning, Sv (out with PM_TW_SOLVE, else in)*/
+  double *bgrid;        /* [n][nb] out, may be NULL                              */
+  double *psib;         /* [n][nb] out, may be NULL                              */
+  double *psibz1;       /* [n][nz] out, may be NULL                              */
+  double *psibz2;       /* [n][nz] out, may be NULL                              */
+  const double *Psi_SO; /* [n][nz] in, may be NULL                               */
+  double *wA1;          /* [n][nz] out, may be NULL                              */
+  double *wA2;          /* [n][nz] out, may be NULL                              */
+} pm_thermwind;
+
+int pm_thermwind_update(const pm_thermwind *tw, int32_t ops, pm_stream_t stream);
+
 /* ------------------------------------------------------------------ RCCL
  * One process per GPU.  The ensemble is sharded by member, stepping needs no
  * communication; the only exchange is the gather of per-member output at diagnostic

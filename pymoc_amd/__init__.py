@@ -8,8 +8,10 @@ __version__ = "0.1.0"
 from . import _lib
 from .device import DeviceArray, Stream, Event, Graph, synchronize
 from .columns import ColumnBatch
+from .thermwind import ThermwindBatch
 from . import modules
 from . import utils
-from .modules import Column
+from .modules import Column, Psi_Thermwind
 from . import configs
 from . import sharding
+from .ensembles import ColumnThermwindEnsemble, TwoColEnsemble

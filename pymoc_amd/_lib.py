@@ -33,6 +33,19 @@ class pm_columns(C.Structure):
   ]
 
 
+PM_TW_SOLVE, PM_TW_PSIB, PM_TW_PSIBZ, PM_TW_WA_PSI = 1, 2, 4, 8
+
+
+class pm_thermwind(C.Structure):
+  """Mirror of `struct pm_thermwind` (include/pymoc_hip.h)."""
+  _fields_ = [
+      ("n", C.c_int32), ("nz", C.c_int32), ("nb", C.c_int32), ("reserved", C.c_int32),
+      ("z", c_dp), ("b1", c_dp), ("b2", c_dp), ("f", c_dp), ("Psi", c_dp),
+      ("bgrid", c_dp), ("psib", c_dp), ("psibz1", c_dp), ("psibz2", c_dp),
+      ("Psi_SO", c_dp), ("wA1", c_dp), ("wA2", c_dp)
+  ]
+
+
 if not os.path.exists(LIB_PATH):
   raise ImportError(
       "pymoc_amd: %s is missing. Build it with `make lib` (hipcc --offload-arch=gfx950) "
@@ -70,6 +83,7 @@ SIGNATURES = {
     "pm_graph_destroy": (C.c_int, [C.c_void_p]),
     "pm_column_steps": (C.c_int, [C.POINTER(pm_columns), c_dp, c_dp, c_dp, C.c_double,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "pm_thermwind_update": (C.c_int, [C.POINTER(pm_thermwind), C.c_int32, C.c_void_p]),
     "pm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pm_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "pm_comm_destroy": (C.c_int, [C.c_void_p]),

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include "common.hip.h"
 #include "column.hip.h"
+#include "thermwind.hip.h"
 #include "comm.hip.h"
 
 namespace pm {
@@ -221,6 +222,20 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
     case 32: return dispatch_column_steps_P<32>(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
     default: return dispatch_column_steps_P<64>(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
   }
+}
+
+// ------------------------------------------------------------- Psi_Thermwind
+int pm_thermwind_update(const pm_thermwind *tw, int32_t ops, pm_stream_t stream) {
+  PM_REQUIRE(tw, "tw is NULL");
+  const pm_thermwind &a = *tw;
+  PM_REQUIRE(a.n >= 0 && a.nz >= 2 && a.nz <= 1024, "bad shape n=%d nz=%d", a.n, a.nz);
+  PM_REQUIRE((ops & ~15) == 0 && ops != 0, "bad ops 0x%x", ops);
+  PM_REQUIRE(!(ops & PM_TW_PSIBZ) || (ops & PM_TW_PSIB), "PM_TW_PSIBZ needs PM_TW_PSIB");
+  PM_REQUIRE(!(ops & PM_TW_PSIB) || a.nb >= 1, "nb must be >= 1");
+  PM_REQUIRE(a.z && a.b1 && a.b2 && a.Psi, "pm_thermwind has a NULL required pointer");
+  PM_REQUIRE(!(ops & PM_TW_SOLVE) || a.f, "f is NULL");
+  if (a.n == 0) return PM_OK;
+  return dispatch_thermwind(a, ops, resolve_stream(stream));
 }
 
 // ---------------------------------------------------------------------- RCCL

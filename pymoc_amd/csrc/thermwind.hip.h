@@ -1,0 +1,392 @@
+// thermwind.hip.h -- K2/K3: thermal-wind overturning and its isopycnal remap.
+//
+// Arithmetic restated from the reference (nothing copied):
+//   Psi_Thermwind.solve  src/pymoc/modules/psi_thermwind.py:125-135 (+ode :95-123, bc :72-93)
+//   Psi_Thermwind.Psib   src/pymoc/modules/psi_thermwind.py:137-185
+//   Psi_Thermwind.Psibz  src/pymoc/modules/psi_thermwind.py:187-208
+//
+// One wavefront per ensemble member; lane l owns the P contiguous levels [l*P, l*P+P).
+//  * solve: the reference hands  Psi'' = (b2-b1)/f, Psi(z0)=Psi(zn)=0  to SciPy's
+//    4th-order collocation solver.  For np.interp profiles the right-hand side is
+//    piecewise linear and the collocation equations reduce exactly to two running
+//    Simpson integrals.  Increments are formed in parallel; the two
+//    prefix sums are taken in level order (through LDS, every lane redundantly) so the
+//    result is bit-identical to the oracle's sequential loop.
+//  * Psib: lanes own isopycnal classes, the nz-1 cells are broadcast from LDS; the
+//    per-class sum runs in NumPy's pairwise order (8 accumulators, tree, tail), so
+//    psib is bit-identical to np.sum in the reference, NaN/inf cases included.
+//  * Psibz: np.interp on the uniform bgrid -- direct index + fix-up instead of a search.
+#pragma once
+#include "common.hip.h"
+
+namespace pm {
+
+constexpr int TW_WAVES_PER_BLOCK = 4;
+constexpr int TW_JT = 4;  // isopycnal classes per lane per pass
+
+__device__ __forceinline__ double np_clip01(double v) {
+  // np.clip(v, 0, 1) = minimum(maximum(v, 0), 1); both propagate NaN
+  if (v != v) return v;
+  v = v < 0. ? 0. : v;
+  return v > 1. ? 1. : v;
+}
+
+// value of np.linspace(start, stop, num)[i]  (numpy/_core/function_base.py)
+struct Linspace {
+  double start, stop, delta, step;
+  int num;
+  __device__ __forceinline__ void init(double a, double b, int n) {
+    start = a;
+    stop = b;
+    num = n;
+    delta = b - a;
+    step = (n > 1) ? delta / (double)(n - 1) : 0.;
+  }
+  __device__ __forceinline__ double at(int i) const {
+    if (i == num - 1 && num > 1) return stop;
+    if (num == 1) return start;
+    if (step == 0.) return ((double)i / (double)(num - 1)) * delta + start;
+    return (double)i * step + start;
+  }
+};
+
+// np.interp(x, bgrid, psib) for one query, bgrid = lin (ascending, uniform), psib in LDS
+__device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
+                                                 const double *psib, int nb) {
+  if (x != x) return x;
+  const double lval = psib[0], rval = psib[nb - 1];
+  if (nb == 1) return (x < lin.start) ? lval : ((x > lin.start) ? rval : psib[0]);
+  if (x > lin.stop) return rval;
+  if (x < lin.start) return lval;
+  // largest j with bgrid[j] <= x
+  int j;
+  if (lin.step > 0. && lin.step < 1e300) {
+    double q = (x - lin.start) / lin.step;
+    j = (int)q;
+    j = j < 0 ? 0 : (j > nb - 1 ? nb - 1 : j);
+    while (j > 0 && x < lin.at(j)) --j;
+    while (j < nb - 1 && x >= lin.at(j + 1)) ++j;
+  } else {
+    int lo = 0, hi = nb;  // upper bound
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      if (x >= lin.at(mid))
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    j = lo - 1;
+    if (j < 0) return lval;
+  }
+  if (j == nb - 1) return psib[j];
+  const double xj = lin.at(j);
+  if (xj == x) return psib[j];
+  const double fj = psib[j], fj1 = psib[j + 1];
+  const double slope = (fj1 - fj) / (lin.at(j + 1) - xj);
+  double r = slope * (x - xj) + fj;
+  if (r != r) {  // numpy: nan in one direction, try the other
+    r = slope * (x - lin.at(j + 1)) + fj1;
+    if (r != r && fj == fj1) r = fj;
+  }
+  return r;
+}
+
+// One isopycnal class: sum_k clip((top_k - bg)/(top_k - bot_k), 0, 1) * u_k over cells
+// [k0, k0+n) in NumPy's pairwise order, for TW_JT classes at once.
+__device__ void psib_block_sum(const double *top, const double *bot, const double *u,
+                               int k0, int n, const double (&bg)[TW_JT],
+                               double (&res)[TW_JT]) {
+  if (n < 8) {
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) res[j] = 0.;
+    for (int k = k0; k < k0 + n; ++k) {
+      const double t = top[k], d = t - bot[k], uk = u[k];
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) res[j] += np_clip01((t - bg[j]) / d) * uk;
+    }
+    return;
+  }
+  double r[8][TW_JT];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const double t = top[k0 + a], d = t - bot[k0 + a], uk = u[k0 + a];
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) r[a][j] = np_clip01((t - bg[j]) / d) * uk;
+  }
+  const int nfull = n - (n % 8);
+  for (int k = 8; k < nfull; k += 8) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const double t = top[k0 + k + a], d = t - bot[k0 + k + a], uk = u[k0 + k + a];
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) r[a][j] += np_clip01((t - bg[j]) / d) * uk;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TW_JT; ++j)
+    res[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) +
+             ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
+  for (int k = nfull; k < n; ++k) {
+    const double t = top[k0 + k], d = t - bot[k0 + k], uk = u[k0 + k];
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) res[j] += np_clip01((t - bg[j]) / d) * uk;
+  }
+}
+
+// np.add.reduce pairwise recursion (blocks of <= 128, left half rounded down to a
+// multiple of 8).  D bounds the recursion depth: D=4 covers n <= 128*16.
+template <int D>
+__device__ __forceinline__ void psib_pairwise(const double *top, const double *bot,
+                                              const double *u, int k0, int n,
+                                              const double (&bg)[TW_JT],
+                                              double (&res)[TW_JT]) {
+  if constexpr (D == 0) {
+    psib_block_sum(top, bot, u, k0, n, bg, res);
+  } else {
+    if (n <= 128) {
+      psib_block_sum(top, bot, u, k0, n, bg, res);
+      return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    double l[TW_JT], r[TW_JT];
+    psib_pairwise<D - 1>(top, bot, u, k0, n2, bg, l);
+    psib_pairwise<D - 1>(top, bot, u, k0 + n2, n - n2, bg, r);
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) res[j] = l[j] + r[j];
+  }
+}
+
+// in-place exclusive running sum in index order: s[i] <- sum_{k<i} s[k], i = 0..n-1
+// (s[n-1] on entry is ignored).  Every lane executes it redundantly (wave-uniform LDS
+// addresses broadcast); returns the total s[0]+...+s[n-2].
+__device__ __forceinline__ double serial_prefix_inplace(double *s, int n) {
+  double acc = 0.;
+  int i = 0;
+  for (; i + 4 <= n - 1; i += 4) {
+    const double d0 = s[i], d1 = s[i + 1], d2 = s[i + 2], d3 = s[i + 3];
+    s[i] = acc;
+    acc = acc + d0;
+    s[i + 1] = acc;
+    acc = acc + d1;
+    s[i + 2] = acc;
+    acc = acc + d2;
+    s[i + 3] = acc;
+    acc = acc + d3;
+  }
+  for (; i < n - 1; ++i) {
+    const double d = s[i];
+    s[i] = acc;
+    acc = acc + d;
+  }
+  s[n - 1] = acc;
+  return acc;
+}
+
+template <int P, bool BIG>
+__global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermwind a,
+                                                                       int ops) {
+  extern __shared__ double lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m_raw = blockIdx.x * TW_WAVES_PER_BLOCK + wave;
+  const bool m_ok = m_raw < a.n;
+  const int m = m_ok ? m_raw : a.n - 1;
+  const int nz = a.nz, nb = a.nb;
+  const int per_wave = 3 * nz + nb;
+  double *s_a = lds_all + (size_t)wave * per_wave;  // [nz]  increments / top
+  double *s_b = s_a + nz;                           // [nz]  bot
+  double *s_c = s_b + nz;                           // [nz]  u
+  double *s_psib = s_c + nz;                        // [nb]
+  const size_t base = (size_t)m * nz;
+
+  double z[P], zu[P], b1[P], b2[P], b1u[P], b2u[P], Psi[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    const int ic = i < nz ? i : nz - 1;
+    const int iu = ic + 1 < nz ? ic + 1 : nz - 1;
+    z[p] = a.z[ic];
+    zu[p] = a.z[iu];
+    b1[p] = a.b1[base + ic];
+    b2[p] = a.b2[base + ic];
+    b1u[p] = a.b1[base + iu];
+    b2u[p] = a.b2[base + iu];
+    Psi[p] = 0.;
+  }
+
+  if (ops & PM_TW_SOLVE) {
+    const double rf = 1. / a.f[m];  // psi_thermwind.py:123
+    double g[P], gu[P], h[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      g[p] = rf * (b2[p] - b1[p]);
+      gu[p] = rf * (b2u[p] - b1u[p]);
+      h[p] = zu[p] - z[p];
+      if (i < nz - 1) {
+        const double zm = z[p] + 0.5 * h[p];
+        const double s1 = (b1u[p] - b1[p]) / h[p], s2 = (b2u[p] - b2[p]) / h[p];
+        const double b1m = s1 * (zm - z[p]) + b1[p], b2m = s2 * (zm - z[p]) + b2[p];
+        const double gm = rf * (b2m - b1m);
+        s_a[i] = h[p] / 6. * (g[p] + gu[p] + 4. * gm);  // dG over [z_i, z_i+1]
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    serial_prefix_inplace(s_a, nz);  // s_a[i] = G_i, in level order
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      if (i < nz - 1) {
+        const double Gl = s_a[i], Gu = s_a[i + 1];
+        const double Gm = 0.5 * (Gl + Gu) - 0.125 * h[p] * (gu[p] - g[p]);
+        s_b[i] = h[p] / 6. * (Gl + Gu + 4. * Gm);  // dI
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double Iend = serial_prefix_inplace(s_b, nz);  // s_b[i] = I_i
+    __builtin_amdgcn_wave_barrier();
+    double Il[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      Il[p] = s_b[i < nz ? i : nz - 1];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double z0 = a.z[0], span = a.z[nz - 1] - z0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      Psi[p] = (Il[p] - Iend * ((z[p] - z0) / span)) / 1e6;  // Sv
+      if (i < nz && m_ok) {
+        a.Psi[base + i] = Psi[p];
+        // z-space coupling wA = AMOC.Psi * 1e6 (examples/example_timestepping.py:75)
+        if ((ops & PM_TW_WA_PSI) && a.wA1) a.wA1[base + i] = Psi[p] * 1e6;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      Psi[p] = a.Psi[base + (i < nz ? i : nz - 1)];
+    }
+  }
+
+  if (!(ops & PM_TW_PSIB)) return;  // wave-uniform
+
+  // ---- Psib (psi_thermwind.py:170-185)
+  double mn = b1[0], mx = b1[0];
+  bool has_nan = false;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if (lane * P + p < nz) {
+      has_nan |= (b1[p] != b1[p]) || (b2[p] != b2[p]);
+      mn = b1[p] < mn ? b1[p] : mn;
+      mn = b2[p] < mn ? b2[p] : mn;
+      mx = b1[p] > mx ? b1[p] : mx;
+      mx = b2[p] > mx ? b2[p] : mx;
+    }
+  }
+  // lanes past the last level hold copies of b[nz-1]: harmless for min/max
+  mn = group_min<64>(mn);
+  mx = group_max<64>(mx);
+  if (__ballot(has_nan) != 0ull) mn = mx = __builtin_nan("");
+  Linspace lin;
+  lin.init(mn, mx, nb);
+
+  const double Psi_up0 = from_next_lane(Psi[0]);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int k = lane * P + p;
+    if (k < nz - 1) {
+      const double Pu = (p < P - 1) ? Psi[p + 1 < P ? p + 1 : p] : Psi_up0;
+      const double u = -(Pu - Psi[p]);  // :175
+      const bool north = u < 0;         // :179-181
+      s_a[k] = north ? b2u[p] : b1u[p];  // top
+      s_b[k] = north ? b2[p] : b1[p];    // bot
+      s_c[k] = u;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int nc = nz - 1;
+  for (int i0 = 0; i0 < nb; i0 += 64 * TW_JT) {
+    double bg[TW_JT], res[TW_JT];
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) {
+      const int i = i0 + j * 64 + lane;
+      bg[j] = lin.at(i < nb ? i : nb - 1);
+    }
+    if constexpr (BIG)
+      psib_pairwise<4>(s_a, s_b, s_c, 0, nc, bg, res);
+    else
+      psib_block_sum(s_a, s_b, s_c, 0, nc, bg, res);  // nc <= 128: one pairwise block
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) {
+      const int i = i0 + j * 64 + lane;
+      if (i < nb) {
+        s_psib[i] = res[j];
+        if (m_ok && a.psib) a.psib[(size_t)m * nb + i] = res[j];
+        if (m_ok && a.bgrid) a.bgrid[(size_t)m * nb + i] = bg[j];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  if (!(ops & PM_TW_PSIBZ)) return;
+  // ---- Psibz (psi_thermwind.py:203-208) and the drivers' wA coupling
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    if (i < nz && m_ok) {
+      const double p1 = interp_uniform(b1[p], lin, s_psib, nb);
+      const double p2 = interp_uniform(b2[p], lin, s_psib, nb);
+      if (a.psibz1) a.psibz1[base + i] = p1;
+      if (a.psibz2) a.psibz2[base + i] = p2;
+      if (a.wA1) {  // (Psi_iso_b - SO.Psi) * 1e6   (example_twocol_plusSO.py:105)
+        const double v = a.Psi_SO ? (p1 - a.Psi_SO[base + i]) : p1;
+        a.wA1[base + i] = v * 1e6;
+      }
+      if (a.wA2) a.wA2[base + i] = (-p2) * 1e6;  // -Psi_iso_n * 1e6 (:106)
+    }
+  }
+}
+
+template <int P, bool BIG>
+int launch_thermwind_impl(const pm_thermwind &a, int ops, hipStream_t st) {
+  const size_t per_wave = (size_t)(3 * a.nz + a.nb) * sizeof(double);
+  const size_t lds = per_wave * TW_WAVES_PER_BLOCK;
+  if (lds > 160 * 1024) return fail(PM_EINVAL, "thermwind needs %zu B of LDS", lds);
+  const unsigned grid = (unsigned)((a.n + TW_WAVES_PER_BLOCK - 1) / TW_WAVES_PER_BLOCK);
+  if (lds > 64 * 1024)
+    PM_HIP(hipFuncSetAttribute((const void *)k_thermwind<P, BIG>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_thermwind<P, BIG>), dim3(grid), dim3(64 * TW_WAVES_PER_BLOCK), lds, st,
+                     a, ops);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
+template <int P>
+int launch_thermwind(const pm_thermwind &a, int ops, hipStream_t st) {
+  if constexpr (P <= 3) {
+    if (a.nz - 1 <= 128) return launch_thermwind_impl<P, false>(a, ops, st);
+  }
+  return launch_thermwind_impl<P, true>(a, ops, st);
+}
+
+inline int dispatch_thermwind(const pm_thermwind &a, int ops, hipStream_t st) {
+  const int P = (a.nz + 63) / 64;
+  switch (P) {
+#define PM_CASE(PP) \
+  case PP:          \
+    return launch_thermwind<PP>(a, ops, st);
+    PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
+    PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASE(11) PM_CASE(12) PM_CASE(13) PM_CASE(14)
+    PM_CASE(15) PM_CASE(16)
+#undef PM_CASE
+  }
+  return fail(PM_EINVAL, "nz=%d unsupported by thermwind (max 1024)", a.nz);
+}
+
+}  // namespace pm

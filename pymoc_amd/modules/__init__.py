@@ -1,1 +1,2 @@
 from .column import Column
+from .psi_thermwind import Psi_Thermwind

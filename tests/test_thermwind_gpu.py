@@ -1,0 +1,156 @@
+"""GPU parity of K2/K3 (pm_thermwind_update) and of the coupled two-column driver."""
+import numpy as np
+import pytest
+
+import oracle as O
+from oracle import drivers
+from conftest import load_golden, relerr
+from pymoc_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+TOL_TW = 1e-13
+
+
+def _run(gpu, z, b1, b2, f, nb=500):
+  from pymoc_amd.device import DeviceArray
+  t = gpu.ThermwindBatch(z, b1.shape[0], f=f, nb=nb)
+  d1, d2 = DeviceArray.from_host(b1), DeviceArray.from_host(b2)
+  t.update(d1, d2)
+  return (t.Psi.download(), t.bgrid.download(), t.psib.download(), t.psibz1.download(),
+          t.psibz2.download())
+
+
+def test_thermwind_golden(gpu):
+  g = load_golden("thermwind")
+  for k in range(int(g["ncases"])):
+    p = "c%02d_" % k
+    z, b1, b2, f = g[p + "z"], g[p + "b1"], g[p + "b2"], float(g[p + "f"])
+    Psi, bgrid, psib, o1, o2 = _run(gpu, z, b1[None], b2[None], f)
+    # solve: bit-identical to the oracle's closed form, 1e-13 from SciPy's collocation
+    assert np.array_equal(Psi[0], O.thermwind_solve(z, b1, b2, f)), k
+    assert relerr(Psi[0], g[p + "Psi"]) <= TOL_TW or np.abs(g[p + "Psi"]).max() < 1e-12, k
+    # remap fed with the REFERENCE's Psi: bit-identical to the reference, NaNs included
+    from pymoc_amd import _lib
+    from pymoc_amd.device import DeviceArray
+    t = gpu.ThermwindBatch(z, 1, f=f, nb=500)
+    t.Psi.upload(g[p + "Psi"][None])
+    t.update(DeviceArray.from_host(b1[None]), DeviceArray.from_host(b2[None]),
+             ops=_lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ)
+    assert np.array_equal(t.bgrid.download()[0], g[p + "bgrid"]), k
+    assert np.array_equal(t.psib.download()[0], g[p + "psib"], equal_nan=True), k
+    assert np.array_equal(t.psibz1.download()[0], g[p + "psibz1"], equal_nan=True), k
+    assert np.array_equal(t.psibz2.download()[0], g[p + "psibz2"], equal_nan=True), k
+
+
+@pytest.mark.parametrize("nz,nb", [(2, 5), (3, 500), (9, 64), (64, 1), (65, 257), (100, 500),
+                                   (129, 500), (130, 100), (200, 500), (513, 300),
+                                   (1024, 500)])
+def test_thermwind_ragged_sizes_vs_oracle_bitwise(gpu, nz, nb):
+  rng = np.random.default_rng(nz * 7 + nb)
+  n = 9
+  z = np.sort(rng.uniform(-4000, 0, nz))
+  b1 = np.sort(0.03 * rng.random((n, nz)), axis=1)
+  b2 = np.sort(0.01 * rng.random((n, nz)), axis=1) - 0.002
+  b2[3] = b1[3]            # identical columns
+  b1[4, :2] = b1[4, min(2, nz - 1)]  # zero-thickness cells
+  b2[5] = 0.0
+  f = rng.uniform(0.8e-4, 1.4e-4, n)
+  Psi, bgrid, psib, o1, o2 = _run(gpu, z, b1, b2, f, nb)
+  for m in range(n):
+    rP = O.thermwind_solve(z, b1[m], b2[m], f[m])
+    assert np.array_equal(Psi[m], rP), (nz, nb, m)
+    rg, rp, r1, r2 = O.thermwind_psibz(b1[m], b2[m], rP, nb)
+    assert np.array_equal(bgrid[m], rg), (nz, nb, m)
+    assert np.array_equal(psib[m], rp, equal_nan=True), (nz, nb, m)
+    assert np.array_equal(o1[m], r1, equal_nan=True), (nz, nb, m)
+    assert np.array_equal(o2[m], r2, equal_nan=True), (nz, nb, m)
+
+
+def test_psi_thermwind_wrapper_api(gpu):
+  g = load_golden("thermwind")
+  p = "c03_"
+  z, b1, b2 = g[p + "z"], g[p + "b1"], g[p + "b2"]
+  T = gpu.Psi_Thermwind(z=z, b1=b1.copy(), b2=b2.copy(), f=float(g[p + "f"]))
+  T.solve()
+  assert relerr(T.Psi, g[p + "Psi"]) <= TOL_TW
+  T.Psi = g[p + "Psi"].copy()
+  psib = T.Psib()
+  assert np.array_equal(psib, g[p + "psib"], equal_nan=True)
+  assert np.array_equal(T.bgrid, g[p + "bgrid"])
+  pz = T.Psibz()
+  assert np.array_equal(pz[0], g[p + "psibz1"]) and np.array_equal(pz[1], g[p + "psibz2"])
+  assert T.Psib(nb=37).shape == (37,) and T.bgrid.shape == (37,)
+  # update() accepts floats and arrays (reference tests/modules/test_psi_thermwind.py:195-205)
+  T.update(b1=0.01, b2=b2)
+  T.solve()
+  assert np.array_equal(T.Psi, O.thermwind_solve(z, 0.01 + 0 * z, b2, float(g[p + "f"])))
+  with pytest.raises(TypeError) as e:
+    gpu.Psi_Thermwind(z=1, b1=b1)
+  assert str(e.value) == 'z needs to be numpy array providing grid levels'
+  with pytest.raises(TypeError) as e:
+    gpu.Psi_Thermwind(z=z, b1=1)
+  assert str(e.value) == "('b1', 'needs to be either function, numpy array, or float')"
+
+
+def test_config1_trajectory(gpu):
+  """BASELINE config 1 (single column + thermal wind every step, 1000 steps, nz=100)
+  against the reference's golden trajectory and bit for bit against the oracle."""
+  g = load_golden("config1_traj")
+  cfg = configs.config1(nz=100)
+  ens = gpu.ColumnThermwindEnsemble(cfg)
+  steps = [int(s) for s in g["steps"]]
+  orc = drivers.run_config1(cfg, 1000, steps)
+  done = 0
+  for i, s in enumerate(steps):
+    ens.run(s - done)
+    done = s
+    st = ens.state()
+    assert relerr(st["b"][0], g["b"][i]) <= 1e-12
+    assert relerr(st["Psi"][0], g["Psi"][i]) <= 1e-12
+    assert np.array_equal(st["b"][0], orc[s]["b"])
+    assert np.array_equal(st["Psi"][0], orc[s]["Psi"])
+
+
+def test_twocol_trajectory_golden(gpu):
+  """example_twocol physics, nz=100: 4800 steps vs the reference's snapshots; the engine
+  is bit-identical to the oracle all the way."""
+  g = load_golden("twocol")
+  m = configs.twocol_member(nz=100, kappa_4k=2.5e-4)
+  cfg = dict(m, kappa=m["kappa"][None], b_basin0=m["b_basin0"][None],
+             b_north0=m["b_north0"][None])
+  ens = gpu.TwoColEnsemble(cfg)
+  snaps = (1, 24, 25, 26, 1000, 4800)
+  orc = drivers.run_twocol(m, 4800, set(snaps))
+  done = 0
+  for s in snaps:
+    ens.run(s - done)
+    done = s
+    st = ens.state()
+    for k in ("b_basin", "b_north", "Psi", "Psi_iso_b", "Psi_iso_n"):
+      assert relerr(st[k][0], g["s%05d_%s" % (s, k)]) <= 1e-12, (s, k)
+      assert np.array_equal(st[k][0], orc[s][k]), (s, k)
+
+
+def test_config3_sweep_members_vs_reference(gpu):
+  """BASELINE config 3 ensemble (4096 two-column members): 241 steps; the 16 members the
+  reference was run on agree to 1e-12, 64 more are bit-identical to the oracle."""
+  g = load_golden("sweep")
+  c = configs.config3(N=4096)
+  ens = gpu.TwoColEnsemble(c)
+  n = int(g["c3_nsteps"])
+  ens.run(n)
+  st = ens.state()
+  idx = g["c3_members"]
+  assert relerr(st["b_basin"][idx], g["c3_b_basin"]) <= 1e-12
+  assert relerr(st["b_north"][idx], g["c3_b_north"]) <= 1e-12
+  assert relerr(st["Psi"][idx], g["c3_Psi"]) <= 1e-12
+  assert ens.nonfinite_members().size == 0
+  keys = ("A_basin", "A_north", "bs", "bs_north", "bbot", "kappa", "b_basin0", "b_north0")
+  for i in range(17, 4096, 64):
+    m = dict(c)
+    for k in keys:
+      m[k] = c[k][i]
+    s = drivers.run_twocol(m, n, {n})[n]
+    for k in ("b_basin", "b_north", "Psi", "Psi_iso_b"):
+      assert np.array_equal(st[k][i], s[k]), (i, k)
