@@ -153,6 +153,49 @@ typedef struct pm_thermwind {
 
 int pm_thermwind_update(const pm_thermwind *tw, int32_t ops, pm_stream_t stream);
 
+/* ------------------------------------------------------------------ Psi_SO
+ * Replaces pymoc.modules.Psi_SO for n independent members on shared grids z[nz], y[ny]:
+ *   Psi_SO.ys          src/pymoc/modules/psi_SO.py:106-140
+ *   Psi_SO.calc_Ekman  src/pymoc/modules/psi_SO.py:218-243   (PM_SO_OP_EKMAN)
+ *   Psi_SO.calc_GM     src/pymoc/modules/psi_SO.py:277-331   (PM_SO_OP_GM; without
+ *                      PM_SO_OP_EKMAN it reads Psi_Ek as the caller's self.Psi_Ek)
+ *   Psi_SO.solve       src/pymoc/modules/psi_SO.py:333-354   (PM_SO_OP_SOLVE)
+ * Scalar options of the constructor are shared by the batch; KGM and tau vary per member. */
+#define PM_SO_HAS_C 1          /* c is not None: F2010 boundary-value smoother       */
+#define PM_SO_BVP_WITH_EK 2
+#define PM_SO_HAS_HSILL 4
+#define PM_SO_HAS_HEK 8
+#define PM_SO_HAS_HTAPERTOP 16
+#define PM_SO_HAS_HTAPERBOT 32
+#define PM_SO_TAU_ARRAY 64     /* tau is [n][ny] on y instead of one scalar per member */
+
+#define PM_SO_OP_EKMAN 1
+#define PM_SO_OP_GM 2
+#define PM_SO_OP_SOLVE 3
+
+typedef struct pm_psi_so {
+  int32_t n, nz, ny, flags;
+  int32_t bvp_refine;   /* sub-intervals per grid interval for the GM BVP (0 -> 8)   */
+  int32_t reserved;
+  const double *z;      /* [nz] */
+  const double *y;      /* [ny] */
+  const double *b;      /* [n][nz] basin buoyancy at the northern end of the channel */
+  const double *bs;     /* [n][ny] surface buoyancy                                  */
+  const double *tau;    /* [n] or, with PM_SO_TAU_ARRAY, [n][ny]                     */
+  const double *KGM;    /* [n] */
+  double f, rho, L, smax, c, Hsill, HEk, Htapertop, Htaperbot;
+  double *Psi;          /* [n][nz] out, Sv                                           */
+  double *Psi_Ek;       /* [n][nz] out, Sv (in when PM_SO_OP_GM alone)               */
+  double *Psi_GM;       /* [n][nz] out, Sv                                           */
+  double *Ek_raw;       /* [n][nz] out, m^3/s: calc_Ekman() return value (may be NULL)*/
+  double *GM_raw;       /* [n][nz] out, m^3/s: calc_GM() return value (may be NULL)  */
+  double *ys;           /* [n][nz] out: outcrop latitude of b[i] (may be NULL)        */
+  int32_t *status;      /* [n] out: bit0 bs not monotone north of its minimum (root
+                           ambiguous), bit1 non-finite Psi, bit2 NaN in bs (may be NULL) */
+} pm_psi_so;
+
+int pm_psi_so_update(const pm_psi_so *so, int32_t ops, pm_stream_t stream);
+
 /* ------------------------------------------------------------------ RCCL
  * One process per GPU.  The ensemble is sharded by member, stepping needs no
  * communication; the only exchange is the gather of per-member output at diagnostic

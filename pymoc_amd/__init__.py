@@ -9,9 +9,10 @@ from . import _lib
 from .device import DeviceArray, Stream, Event, Graph, synchronize
 from .columns import ColumnBatch
 from .thermwind import ThermwindBatch
+from .psi_so import PsiSOBatch
 from . import modules
 from . import utils
-from .modules import Column, Psi_Thermwind
+from .modules import Column, Psi_Thermwind, Psi_SO
 from . import configs
 from . import sharding
 from .ensembles import ColumnThermwindEnsemble, TwoColEnsemble

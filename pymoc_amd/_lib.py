@@ -46,6 +46,25 @@ class pm_thermwind(C.Structure):
   ]
 
 
+(PM_SO_HAS_C, PM_SO_BVP_WITH_EK, PM_SO_HAS_HSILL, PM_SO_HAS_HEK, PM_SO_HAS_HTAPERTOP,
+ PM_SO_HAS_HTAPERBOT, PM_SO_TAU_ARRAY) = 1, 2, 4, 8, 16, 32, 64
+PM_SO_OP_EKMAN, PM_SO_OP_GM, PM_SO_OP_SOLVE = 1, 2, 3
+
+
+class pm_psi_so(C.Structure):
+  """Mirror of `struct pm_psi_so` (include/pymoc_hip.h)."""
+  _fields_ = [
+      ("n", C.c_int32), ("nz", C.c_int32), ("ny", C.c_int32), ("flags", C.c_int32),
+      ("bvp_refine", C.c_int32), ("reserved", C.c_int32),
+      ("z", c_dp), ("y", c_dp), ("b", c_dp), ("bs", c_dp), ("tau", c_dp), ("KGM", c_dp),
+      ("f", C.c_double), ("rho", C.c_double), ("L", C.c_double), ("smax", C.c_double),
+      ("c", C.c_double), ("Hsill", C.c_double), ("HEk", C.c_double),
+      ("Htapertop", C.c_double), ("Htaperbot", C.c_double),
+      ("Psi", c_dp), ("Psi_Ek", c_dp), ("Psi_GM", c_dp), ("Ek_raw", c_dp),
+      ("GM_raw", c_dp), ("ys", c_dp), ("status", c_dp)
+  ]
+
+
 if not os.path.exists(LIB_PATH):
   raise ImportError(
       "pymoc_amd: %s is missing. Build it with `make lib` (hipcc --offload-arch=gfx950) "
@@ -84,6 +103,7 @@ SIGNATURES = {
     "pm_column_steps": (C.c_int, [C.POINTER(pm_columns), c_dp, c_dp, c_dp, C.c_double,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "pm_thermwind_update": (C.c_int, [C.POINTER(pm_thermwind), C.c_int32, C.c_void_p]),
+    "pm_psi_so_update": (C.c_int, [C.POINTER(pm_psi_so), C.c_int32, C.c_void_p]),
     "pm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pm_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "pm_comm_destroy": (C.c_int, [C.c_void_p]),

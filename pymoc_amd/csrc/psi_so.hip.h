@@ -1,0 +1,427 @@
+// psi_so.hip.h -- K4: Southern-Ocean residual overturning Psi = Psi_Ek + Psi_GM.
+//
+// Arithmetic restated from the reference (nothing copied):
+//   Psi_SO.ys          src/pymoc/modules/psi_SO.py:106-140
+//   Psi_SO.calc_N2     src/pymoc/modules/psi_SO.py:142-162
+//   tapers             src/pymoc/modules/psi_SO.py:164-216
+//   Psi_SO.calc_Ekman  src/pymoc/modules/psi_SO.py:218-243
+//   Psi_SO.calc_GM     src/pymoc/modules/psi_SO.py:277-331 (+bc_GM :245-275)
+//   Psi_SO.solve       src/pymoc/modules/psi_SO.py:333-354
+//
+// One wavefront per member, lane l owns levels [l*P, l*P+P).
+//  * ys(b): the reference root-finds bs(y) = b with scipy brentq (xtol 2e-12); bs(y) is an
+//    np.interp closure, i.e. piecewise linear, so the root is taken directly: first
+//    crossing north of argmin(bs), one linear solve.  Agrees with brentq to ~1e-15
+//    relative; members whose bs is not monotone north of its minimum are flagged.
+//  * GM boundary-value problem (c != None): the reference calls scipy solve_bvp
+//    (4th-order Lobatto IIIA collocation, adaptive mesh, tol 1e-3).  Here the same
+//    collocation scheme runs on the grid refined R-fold; u' is eliminated interval by
+//    interval, each lane condenses its R sub-intervals to one 2x2 element (static
+//    condensation), and the remaining nz-point tridiagonal system is solved by a Thomas
+//    sweep staged through LDS.
+#pragma once
+#include "common.hip.h"
+
+namespace pm {
+
+constexpr int SO_WAVES_PER_BLOCK = 4;
+
+// np.interp(x, xp, fp) for sorted xp (LDS), single query
+__device__ __forceinline__ double interp_sorted(double x, const double *xp, const double *fp,
+                                                int n) {
+  if (x != x) return x;
+  if (n == 1) return (x < xp[0]) ? fp[0] : ((x > xp[0]) ? fp[n - 1] : fp[0]);
+  if (x > xp[n - 1]) return fp[n - 1];
+  if (x < xp[0]) return fp[0];
+  int lo = 0, hi = n;  // upper bound: first index with xp > x
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (x >= xp[mid])
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  const int j = lo - 1;
+  if (j == n - 1) return fp[j];
+  if (xp[j] == x) return fp[j];
+  const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+  double r = slope * (x - xp[j]) + fp[j];
+  if (r != r) {
+    r = slope * (x - xp[j + 1]) + fp[j + 1];
+    if (r != r && fp[j] == fp[j + 1]) r = fp[j];
+  }
+  return r;
+}
+
+__device__ __forceinline__ double np_maximum(double a, double b) {
+  // np.maximum propagates NaN
+  if (a != a) return a;
+  if (b != b) return b;
+  return a > b ? a : b;
+}
+
+struct SoElem {  // condensed 2x2 element of an interval: rows for its left/right node
+  double a11, a12, c1, a21, a22, c2;
+};
+
+// Collocation element of one sub-interval [x0, x1] of  u'' = q (u - T), q = N2/c^2:
+// S = u'_0 + u'_1 and D = u'_1 - u'_0 as affine functions of (u_0, u_1).
+__device__ __forceinline__ SoElem so_sub_element(double h, double q0, double q1, double qm,
+                                                 double r0, double r1, double rm) {
+  const double al = 1. + h * h * qm / 12.;
+  const double sA = -(2. / h) * (1. + h * h * q0 / 12.);
+  const double sB = (2. / h) * (1. + h * h * q1 / 12.);
+  const double sC = -(h / 6.) * (r1 - r0);
+  const double dA = (h / 6.) * (q0 + 2. * qm) / al;
+  const double dB = (h / 6.) * (q1 + 2. * qm) / al;
+  const double dC = -(h / 6.) * (r0 + r1 + 4. * rm) / al;
+  SoElem e;
+  e.a11 = sA - dA;
+  e.a12 = sB - dB;
+  e.c1 = -(sC - dC);
+  e.a21 = -(sA + dA);
+  e.a22 = -(sB + dB);
+  e.c2 = sC + dC;
+  return e;
+}
+
+// eliminate the node shared by E (left) and e (right)
+__device__ __forceinline__ SoElem so_merge(const SoElem &E, const SoElem &e) {
+  const double D = E.a22 + e.a11;
+  const double w1 = E.a12 / D, w2 = e.a21 / D;
+  const double cc = E.c2 + e.c1;
+  SoElem o;
+  o.a11 = E.a11 - w1 * E.a21;
+  o.a12 = -w1 * e.a12;
+  o.c1 = E.c1 - w1 * cc;
+  o.a21 = -w2 * E.a21;
+  o.a22 = e.a22 - w2 * e.a12;
+  o.c2 = e.c2 - w2 * cc;
+  return o;
+}
+
+template <int P>
+__global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a, int ops) {
+  extern __shared__ double lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m_raw = blockIdx.x * (blockDim.x >> 6) + wave;
+  const bool m_ok = m_raw < a.n;
+  const int m = m_ok ? m_raw : a.n - 1;
+  const int nz = a.nz, ny = a.ny;
+  const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
+  const bool tau_arr = (a.flags & PM_SO_TAU_ARRAY) != 0;
+  const int per_wave = 3 * ny + (has_c ? 11 * nz : 0);
+  double *s_y = lds_all + (size_t)wave * per_wave;
+  double *s_bs = s_y + ny;
+  double *s_tau = s_bs + ny;
+  double *s_w = s_tau + ny;  // BVP workspace: 11 arrays of nz
+  const size_t base = (size_t)m * nz;
+
+  // ---- stage the member's surface profiles; min / argmin of bs (np.min, np.argmin)
+  double mn = __builtin_inf();
+  int mi = 0x7fffffff;
+  bool nanv = false;
+  for (int j = lane; j < ny; j += 64) {
+    const double v = a.bs[(size_t)m * ny + j];
+    s_y[j] = a.y[j];
+    s_bs[j] = v;
+    s_tau[j] = tau_arr ? a.tau[(size_t)m * ny + j] : 0.;
+    nanv |= (v != v);
+    if (v < mn) {
+      mn = v;
+      mi = j;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(mn, o, 64);
+    const int oi = __shfl_xor(mi, o, 64);
+    if (ov < mn || (ov == mn && oi < mi)) {
+      mn = ov;
+      mi = oi;
+    }
+  }
+  const bool bs_nan = __ballot(nanv) != 0ull;
+  __builtin_amdgcn_wave_barrier();
+  const int minind = mi < ny ? mi : 0;
+  const double bsmin = mn, bs_last = s_bs[ny - 1];
+  const double y0g = s_y[0], yN = s_y[ny - 1];
+  bool nonmono = false;
+  for (int j = minind + lane; j < ny - 1; j += 64) nonmono |= s_bs[j + 1] < s_bs[j];
+  const bool ambiguous = __ballot(nonmono) != 0ull;
+
+  // ---- per level: outcrop latitude ys (psi_SO.py:106-140)
+  double z[P], b[P], ys[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    const int ic = i < nz ? i : nz - 1;
+    z[p] = a.z[ic];
+    b[p] = a.b[base + ic];
+    double yv;
+    if (b[p] < bsmin) {
+      yv = y0g - 1e3;
+    } else if (b[p] > bs_last) {
+      yv = yN;
+    } else if (b[p] != b[p] || bs_nan) {
+      yv = __builtin_nan("");
+    } else {
+      int j = minind;
+      while (j < ny - 2 && !(s_bs[j + 1] >= b[p])) ++j;  // first crossing north of argmin
+      const double f0 = s_bs[j], f1 = s_bs[j + 1];
+      if (f0 == b[p])
+        yv = s_y[j];
+      else if (f1 == b[p])
+        yv = s_y[j + 1];
+      else
+        yv = s_y[j] + (b[p] - f0) / ((f1 - f0) / (s_y[j + 1] - s_y[j]));
+    }
+    ys[p] = yv;
+    if (a.ys && i < nz && m_ok) a.ys[base + i] = yv;
+  }
+
+  // ---- calc_Ekman (psi_SO.py:218-243)
+  const double tau_s = tau_arr ? 0. : a.tau[m];
+  double tmean_scalar = 0.;
+  if (!tau_arr) {
+    // np.mean of 100 copies of tau (pairwise: 8 accumulators x 12 rounds, tree, 4 tail)
+    double r8 = tau_s;
+    for (int k = 1; k < 12; ++k) r8 += tau_s;
+    double res = ((r8 + r8) + (r8 + r8)) + ((r8 + r8) + (r8 + r8));
+    for (int k = 96; k < 100; ++k) res += tau_s;
+    tmean_scalar = res / 100.;
+  }
+  double ek_sv[P], ekraw[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    double tau_ave;
+    if (!tau_arr) {
+      // tau + 0*y is tau unless the outcrop latitude is non-finite
+      tau_ave = (ys[p] - ys[p] == 0.) ? tmean_scalar : __builtin_nan("");
+    } else {
+      Linspace lin;
+      lin.init(ys[p], yN, 100);
+      double r[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r[k] = interp_sorted(lin.at(k), s_y, s_tau, ny);
+      for (int k = 8; k < 96; k += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] += interp_sorted(lin.at(k + q), s_y, s_tau, ny);
+      }
+      double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+      for (int k = 96; k < 100; ++k) res += interp_sorted(lin.at(k), s_y, s_tau, ny);
+      tau_ave = res / 100.;
+    }
+    double sill = 1., ekt = 1.;
+    if (a.flags & PM_SO_HAS_HSILL) {
+      double mm = a.z[0] + a.Hsill - z[p];
+      mm = mm > 0. ? mm : 0.;
+      sill = 1. - (mm * mm) / (a.Hsill * a.Hsill);
+    }
+    if (a.flags & PM_SO_HAS_HEK) {
+      double mm = z[p] + a.HEk;
+      mm = mm > 0 ? mm : 0;
+      ekt = 1 - (mm * mm) / (a.HEk * a.HEk);
+    } else if (i == nz - 1) {
+      ekt = 0.;  // taper = ones with last element 0 (psi_SO.py:213-216)
+    }
+    ekraw[p] = tau_ave / a.f / a.rho * a.L * sill * ekt;  // :243
+    ek_sv[p] = ekraw[p] / 1e6;                             // :349
+    if (!(ops & PM_SO_OP_EKMAN))  // calc_GM() alone reads the caller's self.Psi_Ek
+      ek_sv[p] = a.Psi_Ek[base + (i < nz ? i : nz - 1)];
+    else if (a.Ek_raw && i < nz && m_ok)
+      a.Ek_raw[base + i] = ekraw[p];
+  }
+  if (!(ops & PM_SO_OP_GM)) {  // calc_Ekman() alone
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      if (i < nz && m_ok) a.Psi_Ek[base + i] = ek_sv[p];
+    }
+    return;
+  }
+
+  // ---- calc_GM (psi_SO.py:277-331)
+  const double KGM = a.KGM[m];
+  double dy[P], temp[P], bott[P], topt[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const double d = yN - ys[p];
+    dy[p] = (0.1 > d) ? 0.1 : d;  // Python max(d, eps): eps only if eps > d (NaN stays)
+    bott[p] = 1.;
+    topt[p] = 1.;
+    if (a.flags & PM_SO_HAS_HTAPERBOT) {
+      double mm = a.z[0] + a.Htaperbot - z[p];
+      mm = mm > 0. ? mm : 0.;
+      bott[p] = 1. - (mm * mm) / (a.Htaperbot * a.Htaperbot);
+    }
+    if (a.flags & PM_SO_HAS_HTAPERTOP) {
+      double mm = z[p] + a.Htapertop;
+      mm = mm > 0 ? mm : 0;
+      topt[p] = 1 - (mm * mm) / (a.Htapertop * a.Htapertop);
+    }
+  }
+  if (!has_c) {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      temp[p] = KGM * np_maximum(z[p] / dy[p], -a.smax) * a.L * topt[p] * bott[p];  // :325
+  } else {
+    // --- F2010 boundary-value smoother (psi_SO.py:308-323)
+    double *s_T = s_w, *s_N2 = s_w + nz;
+    double *e11 = s_w + 2 * nz, *e12 = e11 + nz, *ec1 = e12 + nz, *e21 = ec1 + nz,
+           *e22 = e21 + nz, *ec2 = e22 + nz;
+    double *s_cp = ec2 + nz, *s_dp = s_cp + nz, *s_u = s_dp + nz;
+    const double c2 = a.c * a.c;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      if (i < nz) {
+        s_T[i] = KGM * z[p] / dy[p] * a.L * topt[p] * bott[p];  // :310
+        double n2;  // calc_N2, :154-160
+        if (i == 0)
+          n2 = (a.b[base + 1] - b[p]) / (a.z[1] - z[p]);
+        else if (i == nz - 1)
+          n2 = (b[p] - a.b[base + nz - 2]) / (z[p] - a.z[nz - 2]);
+        else
+          n2 = (a.b[base + i + 1] - a.b[base + i - 1]) /
+               ((a.z[i + 1] - z[p]) + (z[p] - a.z[i - 1]));
+        s_N2[i] = n2;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int R = a.bvp_refine > 0 ? a.bvp_refine : 8;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int k = lane * P + p;  // interval [z_k, z_k+1]
+      if (k < nz - 1) {
+        const double zk = z[p], hz = a.z[k + 1] - zk;
+        const double N0 = s_N2[k], N1 = s_N2[k + 1], T0 = s_T[k], T1 = s_T[k + 1];
+        const double sN = (N1 - N0) / hz, sT = (T1 - T0) / hz;
+        SoElem E;
+        double xl = zk, ql = N0 / c2, rl = ql * T0;
+        for (int j = 0; j < R; ++j) {
+          double xr, qr, rr;
+          if (j == R - 1) {
+            xr = a.z[k + 1];
+            qr = N1 / c2;
+            rr = qr * T1;
+          } else {
+            xr = zk + hz * ((double)(j + 1) / R);
+            qr = (sN * (xr - zk) + N0) / c2;
+            rr = qr * (sT * (xr - zk) + T0);
+          }
+          const double h = xr - xl, xm = xl + 0.5 * h;
+          const double qm = (sN * (xm - zk) + N0) / c2;
+          const double rm = qm * (sT * (xm - zk) + T0);
+          const SoElem e = so_sub_element(h, ql, qr, qm, rl, rr, rm);
+          E = (j == 0) ? e : so_merge(E, e);
+          xl = xr;
+          ql = qr;
+          rl = rr;
+        }
+        e11[k] = E.a11;
+        e12[k] = E.a12;
+        ec1[k] = E.c1;
+        e21[k] = E.a21;
+        e22[k] = E.a22;
+        ec2[k] = E.c2;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // boundary values (bc_GM, :270-275); Psi_Ek[0], Psi_Ek[-1] live in lanes 0 / last
+    double ua = 0., ub = 0.;
+    if (a.flags & PM_SO_BVP_WITH_EK) {
+      const int last_lane = (nz - 1) / P, last_p = (nz - 1) % P;
+      double v_last = 0.;
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (p == last_p) v_last = ek_sv[p];
+      ua = -(__shfl(ek_sv[0], 0, 64) * 1e6);
+      ub = -(__shfl(v_last, last_lane, 64) * 1e6);
+    }
+    // Thomas sweep over the nz condensed nodes, every lane redundantly via LDS
+    {
+      double cp = 0., dp = ua;  // row 0: u_0 = ua
+      s_cp[0] = cp;
+      s_dp[0] = dp;
+      for (int i = 1; i < nz - 1; ++i) {
+        const double lo = e21[i - 1], di = e22[i - 1] + e11[i], up = e12[i];
+        const double rh = ec2[i - 1] + ec1[i];
+        const double den = di - lo * cp;
+        cp = up / den;
+        dp = (rh - lo * dp) / den;
+        s_cp[i] = cp;
+        s_dp[i] = dp;
+      }
+      double u = ub;
+      s_u[nz - 1] = u;
+      for (int i = nz - 2; i >= 1; --i) {
+        u = s_dp[i] - s_cp[i] * u;
+        s_u[i] = u;
+      }
+      s_u[0] = ua;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      temp[p] = s_u[i < nz ? i : nz - 1];
+    }
+  }
+  // limit Psi_GM to -Psi_Ek on isopycnals that do not outcrop (:329-330)
+  const double width = yN - y0g;
+  bool bad = false;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    if (dy[p] > width) temp[p] = np_maximum(temp[p], -ek_sv[p] * 1e6);
+    const double gm = temp[p] / 1e6;        // :350
+    double psi = ek_sv[p] + gm;             // :351
+    if (i == 0) psi = 0.;                   // :354
+    if (i < nz && m_ok) {
+      if (ops & PM_SO_OP_EKMAN) a.Psi_Ek[base + i] = ek_sv[p];
+      a.Psi_GM[base + i] = gm;
+      a.Psi[base + i] = psi;
+      if (a.GM_raw) a.GM_raw[base + i] = temp[p];
+      bad |= !isfinite(psi);
+    }
+  }
+  if (a.status) {
+    const bool anybad = __ballot(bad) != 0ull;
+    if (lane == 0 && m_ok)
+      a.status[m] = (ambiguous ? 1 : 0) | (anybad ? 2 : 0) | (bs_nan ? 4 : 0);
+  }
+}
+
+template <int P>
+int launch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
+  const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
+  const size_t per_wave = (size_t)(3 * a.ny + (has_c ? 11 * a.nz : 0)) * sizeof(double);
+  int wpb = SO_WAVES_PER_BLOCK;
+  while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
+  const size_t lds = per_wave * wpb;
+  if (lds > 160 * 1024) return fail(PM_EINVAL, "psi_so needs %zu B of LDS per member", lds);
+  if (lds > 64 * 1024)
+    PM_HIP(hipFuncSetAttribute((const void *)k_psi_so<P>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const unsigned grid = (unsigned)((a.n + wpb - 1) / wpb);
+  hipLaunchKernelGGL((k_psi_so<P>), dim3(grid), dim3(64 * wpb), lds, st, a, ops);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
+inline int dispatch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
+  const int P = (a.nz + 63) / 64;
+  switch (P) {
+#define PM_CASE(PP) \
+  case PP:          \
+    return launch_psi_so<PP>(a, ops, st);
+    PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7) PM_CASE(8)
+#undef PM_CASE
+  }
+  return fail(PM_EINVAL, "nz=%d unsupported by psi_so (max 512)", a.nz);
+}
+
+}  // namespace pm

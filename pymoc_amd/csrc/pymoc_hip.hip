@@ -6,6 +6,7 @@
 #include "common.hip.h"
 #include "column.hip.h"
 #include "thermwind.hip.h"
+#include "psi_so.hip.h"
 #include "comm.hip.h"
 
 namespace pm {
@@ -236,6 +237,21 @@ int pm_thermwind_update(const pm_thermwind *tw, int32_t ops, pm_stream_t stream)
   PM_REQUIRE(!(ops & PM_TW_SOLVE) || a.f, "f is NULL");
   if (a.n == 0) return PM_OK;
   return dispatch_thermwind(a, ops, resolve_stream(stream));
+}
+
+// -------------------------------------------------------------------- Psi_SO
+int pm_psi_so_update(const pm_psi_so *so, int32_t ops, pm_stream_t stream) {
+  PM_REQUIRE(so, "so is NULL");
+  const pm_psi_so &a = *so;
+  PM_REQUIRE(a.n >= 0 && a.nz >= 2 && a.nz <= 512 && a.ny >= 2 && a.ny <= 2048,
+             "bad shape n=%d nz=%d ny=%d", a.n, a.nz, a.ny);
+  PM_REQUIRE(ops >= 1 && ops <= 3, "bad ops %d", ops);
+  PM_REQUIRE(a.z && a.y && a.b && a.bs && a.tau && a.KGM && a.Psi_Ek,
+             "pm_psi_so has a NULL required pointer");
+  PM_REQUIRE(!(ops & PM_SO_OP_GM) || (a.Psi && a.Psi_GM), "Psi / Psi_GM is NULL");
+  PM_REQUIRE(a.bvp_refine >= 0 && a.bvp_refine <= 256, "bad bvp_refine");
+  if (a.n == 0) return PM_OK;
+  return dispatch_psi_so(a, ops, resolve_stream(stream));
 }
 
 // ---------------------------------------------------------------------- RCCL

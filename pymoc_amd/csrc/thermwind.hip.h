@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
   extern __shared__ double lds_all[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int m_raw = blockIdx.x * TW_WAVES_PER_BLOCK + wave;
+  const int m_raw = blockIdx.x * (blockDim.x >> 6) + wave;
   const bool m_ok = m_raw < a.n;
   const int m = m_ok ? m_raw : a.n - 1;
   const int nz = a.nz, nb = a.nb;
@@ -355,14 +355,15 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
 template <int P, bool BIG>
 int launch_thermwind_impl(const pm_thermwind &a, int ops, hipStream_t st) {
   const size_t per_wave = (size_t)(3 * a.nz + a.nb) * sizeof(double);
-  const size_t lds = per_wave * TW_WAVES_PER_BLOCK;
-  if (lds > 160 * 1024) return fail(PM_EINVAL, "thermwind needs %zu B of LDS", lds);
-  const unsigned grid = (unsigned)((a.n + TW_WAVES_PER_BLOCK - 1) / TW_WAVES_PER_BLOCK);
+  int wpb = TW_WAVES_PER_BLOCK;
+  while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
+  const size_t lds = per_wave * wpb;
+  if (lds > 160 * 1024) return fail(PM_EINVAL, "thermwind needs %zu B of LDS per member", lds);
   if (lds > 64 * 1024)
     PM_HIP(hipFuncSetAttribute((const void *)k_thermwind<P, BIG>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_thermwind<P, BIG>), dim3(grid), dim3(64 * TW_WAVES_PER_BLOCK), lds, st,
-                     a, ops);
+  const unsigned grid = (unsigned)((a.n + wpb - 1) / wpb);
+  hipLaunchKernelGGL((k_thermwind<P, BIG>), dim3(grid), dim3(64 * wpb), lds, st, a, ops);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }

@@ -13,6 +13,7 @@ import numpy as np
 from . import _lib
 from .columns import ColumnBatch
 from .device import DeviceArray
+from .psi_so import PsiSOBatch
 from .thermwind import ThermwindBatch
 
 _TW_ALL = _lib.PM_TW_SOLVE | _lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ
@@ -91,7 +92,16 @@ class TwoColEnsemble(object):
     self.wA = DeviceArray.zeros((2 * n, nz))
     self._off = n * nz * 8
     self.ii = 0
-    self._update()  # AMOC.solve(); AMOC.Psibz() on the initial profiles (:58-62)
+    self.so = None
+    if 'y' in cfg and 'bs_SO' in cfg:  # example_twocol_plusSO.py:69-81
+      ny = cfg['y'].size
+      self.so = PsiSOBatch(z, cfg['y'], n, tau=cfg['tau'], KGM=cfg['KGM'], f=cfg['f'],
+                           L=cfg['L'], c=cfg.get('c'), bvp_with_Ek=cfg.get('bvp_with_Ek', False),
+                           bvp_refine=cfg.get('bvp_refine', 0), stream=stream,
+                           z_dev=self.cols.z)
+      self.bs_SO = DeviceArray.from_host(_rows(cfg['bs_SO'], n, ny) if np.ndim(cfg['bs_SO']) == 1
+                                         else cfg['bs_SO'])
+    self._update()  # AMOC.solve(); AMOC.Psibz() [; SO.solve()] on the initial profiles
 
   # device views
   @property
@@ -103,9 +113,13 @@ class TwoColEnsemble(object):
     return self.cols.b.ptr + self._off
 
   def _psi_so(self):
-    return None
+    return self.so.Psi if self.so is not None else None
 
   def _update(self):
+    # SO.solve() and AMOC.solve() both read basin.b only, so the SO update may run first
+    # and feed wAb = (Psi_iso_b - SO.Psi)*1e6 inside the thermal-wind launch
+    if self.so is not None:
+      self.so.update(self._b_basin, self.bs_SO)
     self.tw.update(self._b_basin, self._b_north, ops=_TW_ALL, Psi_SO=self._psi_so(),
                    wA1=self.wA.ptr, wA2=self.wA.ptr + self._off)
 
@@ -124,8 +138,12 @@ class TwoColEnsemble(object):
 
   def state(self):
     b = self.cols.get_b()
-    return dict(b_basin=b[:self.n], b_north=b[self.n:], Psi=self.tw.Psi.download(),
-                Psi_iso_b=self.tw.psibz1.download(), Psi_iso_n=self.tw.psibz2.download())
+    out = dict(b_basin=b[:self.n], b_north=b[self.n:], Psi=self.tw.Psi.download(),
+               Psi_iso_b=self.tw.psibz1.download(), Psi_iso_n=self.tw.psibz2.download())
+    if self.so is not None:
+      out.update(Psi_SO=self.so.Psi.download(), Psi_Ek=self.so.Psi_Ek.download(),
+                 Psi_GM=self.so.Psi_GM.download())
+    return out
 
   def nonfinite_members(self):
     nf = self.cols.get_nonfinite()

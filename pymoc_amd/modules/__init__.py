@@ -1,2 +1,3 @@
 from .column import Column
 from .psi_thermwind import Psi_Thermwind
+from .psi_SO import Psi_SO

@@ -1,0 +1,187 @@
+"""GPU parity of K4 (pm_psi_so_update) and of the two-column + SO driver (config 4)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from oracle import drivers
+from conftest import load_golden, relerr
+from pymoc_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+TOL_DIRECT = 1e-13   # everything but the GM boundary-value problem
+TOL_BVP_ORACLE = 1e-9   # same collocation scheme and mesh as the oracle, other elimination order
+TOL_BVP_REF = 1e-5   # vs SciPy's adaptive solve_bvp (tol=1e-3) in the reference
+
+
+def _kwargs(g, p):
+  kw = {}
+  for name in ("f", "rho", "L", "KGM", "smax"):
+    kw[name] = float(g[p + "kw_" + name])
+  for name in ("c", "Hsill", "HEk", "Htapertop", "Htaperbot"):
+    v = float(g[p + "kw_" + name])
+    kw[name] = None if np.isnan(v) else v
+  kw["bvp_with_Ek"] = bool(g[p + "kw_bvp_with_Ek"])
+  return kw
+
+
+def test_psi_so_golden(gpu):
+  from pymoc_amd.device import DeviceArray
+  g = load_golden("psi_so")
+  for k in range(int(g["ncases"])):
+    p = "c%02d_" % k
+    kw = _kwargs(g, p)
+    tau = g[p + "tau"]
+    tau_in = float(tau) if tau.ndim == 0 else tau[None, :]
+    KGM = kw.pop("KGM")
+    t = gpu.PsiSOBatch(g[p + "z"], g[p + "y"], 1, tau=tau_in, KGM=KGM, bvp_refine=8,
+                       diagnostics=True, **kw)
+    t.update(DeviceArray.from_host(g[p + "b"][None]), DeviceArray.from_host(g[p + "bs"][None]))
+    Psi, Ek, GM = t.Psi.download()[0], t.Psi_Ek.download()[0], t.Psi_GM.download()[0]
+    ys = t.ys.download()[0]
+    assert relerr(ys, g[p + "ys"]) <= 1e-14, k          # direct inverse vs brentq
+    assert relerr(Ek, g[p + "Psi_Ek"]) <= TOL_DIRECT, k
+    tau_o = float(tau) if tau.ndim == 0 else tau
+    oPsi, oEk, oGM, _ = O.psi_so_solve(g[p + "z"], g[p + "y"], g[p + "b"], g[p + "bs"], tau_o,
+                                       KGM=KGM, bvp_refine=8, **kw)
+    if kw["c"] is None:
+      assert relerr(GM, g[p + "Psi_GM"]) <= TOL_DIRECT, k
+      assert relerr(Psi, g[p + "Psi"]) <= TOL_DIRECT, k
+    else:
+      assert relerr(GM, oGM) <= TOL_BVP_ORACLE, k
+      assert relerr(Psi, oPsi) <= TOL_BVP_ORACLE, k
+      assert relerr(GM, g[p + "Psi_GM"]) <= TOL_BVP_REF, k
+      assert relerr(Psi, g[p + "Psi"]) <= TOL_BVP_REF, k
+    assert t.status.download()[0] & 6 == 0
+
+
+@pytest.mark.parametrize("nz,ny,R", [(2, 2, 1), (3, 5, 4), (64, 40, 8), (65, 51, 8),
+                                      (100, 40, 16), (200, 51, 3), (257, 130, 2), (512, 64, 8)])
+def test_psi_so_ragged_sizes_vs_oracle(gpu, nz, ny, R):
+  from pymoc_amd.device import DeviceArray
+  rng = np.random.default_rng(nz + 31 * ny)
+  n = 7
+  z = np.sort(rng.uniform(-4000, 0, nz))
+  z[-1] = 0.
+  y = np.sort(rng.uniform(0, 2e6, ny))
+  b = np.sort(0.03 * rng.random((n, nz)), axis=1) - 0.002
+  bs = np.sort(0.03 * rng.random((n, ny)), axis=1)
+  bs[2, : ny // 3] = bs[2, ny // 3::-1][: ny // 3] if ny > 6 else bs[2, : ny // 3]  # min inside
+  tau = rng.uniform(0.05, 0.2, n)
+  KGM = rng.uniform(500., 1500., n)
+  for kw in (dict(), dict(c=0.1, bvp_with_Ek=True), dict(c=0.3, Hsill=500., HEk=100.,
+                                                           Htapertop=200., Htaperbot=300.)):
+    t = gpu.PsiSOBatch(z, y, n, tau=tau, KGM=KGM, f=1e-4, L=5e6, bvp_refine=R, **kw)
+    t.update(DeviceArray.from_host(b), DeviceArray.from_host(bs))
+    Psi, Ek, GM = t.Psi.download(), t.Psi_Ek.download(), t.Psi_GM.download()
+    for m in range(n):
+      oPsi, oEk, oGM, st = O.psi_so_solve(z, y, b[m], bs[m], float(tau[m]), KGM=KGM[m],
+                                          f=1e-4, L=5e6, bvp_refine=R, **kw)
+      tol = TOL_BVP_ORACLE if "c" in kw else TOL_DIRECT
+      assert relerr(Ek[m], oEk) <= TOL_DIRECT, (nz, ny, kw, m)
+      assert relerr(GM[m], oGM) <= tol, (nz, ny, kw, m)
+      assert relerr(Psi[m], oPsi) <= tol, (nz, ny, kw, m)
+
+
+def test_psi_so_tau_array_and_wrapper_api(gpu):
+  g = load_golden("psi_so")
+  p = "c01_"  # tau array, c None
+  kw = _kwargs(g, p)
+  S = gpu.Psi_SO(z=g[p + "z"], y=g[p + "y"], b=g[p + "b"].copy(), bs=g[p + "bs"].copy(),
+                 tau=g[p + "tau"].copy(), **kw)
+  S.solve()
+  assert relerr(S.Psi, g[p + "Psi"]) <= TOL_DIRECT
+  assert relerr(S.Psi_Ek, g[p + "Psi_Ek"]) <= TOL_DIRECT
+  assert relerr(S.Psi_GM, g[p + "Psi_GM"]) <= TOL_DIRECT
+  assert S.Psi[0] == 0.
+  # calc_Ekman / calc_GM return m^3/s; solve() == their sum in Sv (reference test_solve)
+  ek = S.calc_Ekman()
+  S.Psi_Ek = ek / 1e6
+  gm = S.calc_GM()
+  psi = ek / 1e6 + gm / 1e6
+  psi[0] = 0.
+  assert np.array_equal(psi, S.Psi)
+  # ys: inverse of bs, clamps (reference test_ys)
+  for i in range(len(S.y)):
+    assert np.round(S.ys(S.bs(S.y[i])), 3) == np.round(S.y[i], 3)
+  assert S.ys(-1.0) == S.y[0] - 1e3 and S.ys(1.0) == S.y[-1]
+  S.update(b=10.0, bs=50.0)
+  assert np.all(S.b(S.z) == 10.0) and np.all(S.bs(S.y) == 50.0)
+  for bad, msg in ((dict(z=-2000), "z needs to be numpy array providing grid levels"),
+                   (dict(z=S.z, y=1e6),
+                    "y needs to be numpy array providing horizontal grid (or boundaries) of ACC")):
+    with pytest.raises(TypeError) as e:
+      gpu.Psi_SO(**bad)
+    assert str(e.value) == msg
+  with pytest.raises(TypeError) as e:
+    gpu.Psi_SO(z=S.z, y=S.y, b=S.b)
+  assert str(e.value) == "('bs', 'needs to be either function, numpy array, or float')"
+
+
+def test_reference_unit_tests_of_calc_gm(gpu):
+  """tests/modules/test_psi_SO.py:205-294 re-expressed against the wrapper."""
+  S = gpu.Psi_SO(z=np.linspace(-4000, 0, 81), y=np.linspace(0, 2.0e6, 51),
+                 b=np.linspace(0.03, -0.001, 81), bs=np.linspace(0.05, 0.10, 51), tau=0.12)
+  ek = (S.L * 0.12) / (S.f * S.rho)
+  ekman = np.full(81, ek)
+  ekman[-1] = 0
+  assert np.all(np.around(ekman, 3) == np.around(S.calc_Ekman(), 3))
+  dy_atz = 2001000.0
+  GM = np.array([S.L * S.KGM * z / dy_atz for z in S.z])
+  S.Psi_Ek = S.calc_Ekman()
+  assert np.all(np.around(GM, 3) == np.around(S.calc_GM(), 3))
+  S.b = gpu.utils.make_func(np.linspace(0.3, 0.2, 81), S.z, 'b')   # dy floor -> -smax clip
+  GM = np.full(81, -S.L * S.KGM * S.smax)
+  GM[-1] = 0
+  assert np.all(np.around(GM, 3) == np.around(S.calc_GM(), 3))
+  S2 = gpu.Psi_SO(z=np.linspace(-4000, 0, 81), y=np.linspace(0, 2.0e3, 51),
+                  b=np.linspace(0.03, -0.001, 81), bs=np.linspace(0.05, 0.10, 51), tau=0.12)
+  GM = np.full(81, -S2.L * S2.KGM * 0.01)
+  GM[-1] = 0
+  psi_ek = np.asarray([gm + np.abs(gm / 2.0) for gm in GM])
+  S2.Psi_Ek = psi_ek
+  assert np.all(np.around(-psi_ek * 1e6, 3) == np.around(S2.calc_GM(), 3))
+
+
+def test_twocol_so_trajectory_golden(gpu):
+  """example_twocol_plusSO physics, nz=100, 2400 steps: 1e-5 from the reference (SciPy's
+  adaptive BVP solver sets that floor), 1e-8 from the oracle on the same mesh."""
+  g = load_golden("twocol_so")
+  m = configs.twocol_so_member(nz=100, ny=40)
+  cfg = dict(m, kappa=m["kappa"][None], b_basin0=m["b_basin0"][None],
+             b_north0=m["b_north0"][None], bs_SO=m["bs_SO"][None], bvp_refine=8)
+  ens = gpu.TwoColEnsemble(cfg)
+  snaps = (1, 24, 25, 26, 2400)
+  orc = drivers.run_twocol(m, 2400, set(snaps), so=True, bvp_refine=8)
+  done = 0
+  for s in snaps:
+    ens.run(s - done)
+    done = s
+    st = ens.state()
+    for k in ("b_basin", "b_north", "Psi", "Psi_iso_b", "Psi_iso_n", "Psi_SO"):
+      assert relerr(st[k][0], g["s%05d_%s" % (s, k)]) <= TOL_BVP_REF, (s, k)
+      assert relerr(st[k][0], orc[s][k]) <= 1e-8, (s, k)
+
+
+def test_config4_sweep_members_vs_reference(gpu):
+  g = load_golden("sweep")
+  c = dict(configs.config4(N=8192), bvp_refine=8)
+  ens = gpu.TwoColEnsemble(c)
+  n = int(g["c4_nsteps"])
+  ens.run(n)
+  st = ens.state()
+  idx = g["c4_members"]
+  assert relerr(st["b_basin"][idx], g["c4_b_basin"]) <= TOL_BVP_REF
+  assert relerr(st["b_north"][idx], g["c4_b_north"]) <= TOL_BVP_REF
+  assert relerr(st["Psi"][idx], g["c4_Psi"]) <= TOL_BVP_REF
+  assert relerr(st["Psi_SO"][idx], g["c4_Psi_SO"]) <= TOL_BVP_REF
+  assert ens.nonfinite_members().size == 0
+  keys = ("A_basin", "A_north", "bs", "bs_north", "bbot", "tau", "KGM", "kappa", "b_basin0",
+          "b_north0", "bs_SO")
+  for i in range(5, 8192, 512):
+    m = dict(c)
+    for k in keys:
+      m[k] = c[k][i]
+    s = drivers.run_twocol(m, n, {n}, so=True, bvp_refine=8)[n]
+    for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
+      assert relerr(st[k][i], s[k]) <= 1e-8, (i, k)
