@@ -196,6 +196,46 @@ typedef struct pm_psi_so {
 
 int pm_psi_so_update(const pm_psi_so *so, int32_t ops, pm_stream_t stream);
 
+/* ------------------------------------------------------------------ SO_ML
+ * Replaces pymoc.modules.SO_ML.timestep / advdiff (src/pymoc/modules/SO_ML.py:198-303,
+ * with set_boundary_conditions :77-98, calc_advective_tendency :100-134 and the
+ * Crank-Nicolson calc_implicit_diffusion :136-196 as a Thomas sweep) for n members on a
+ * shared uniform grid y[ny]; the basin profiles live on z with nz levels.               */
+typedef struct pm_so_ml {
+  int32_t n, nz, ny, reserved;
+  const double *y;         /* [ny] uniform meridional grid                            */
+  double *bs;              /* [n][ny] mixed-layer buoyancy, updated in place           */
+  double *Psi_s;           /* [n][ny] out: overturning at the surface, Sv (may be NULL) */
+  const double *b_basin;   /* [n][nz] buoyancy of the adjoining basin                  */
+  const double *Psi_b;     /* [n][nz] SO overturning on the basin's levels, Sv         */
+  const double *surflux;   /* [n][ny] */
+  const double *rest_mask; /* [n][ny] */
+  const double *b_rest;    /* [n][ny] */
+  double Ks, h, L, v_pist;
+  int32_t *status;         /* [n] out: 1 where the reference raises IndexError (Psi_b all
+                              zero / no upwelling level; state left untouched), 2 non-finite
+                              result (may be NULL)                                      */
+} pm_so_ml;
+
+int pm_so_ml_step(const pm_so_ml *ml, double dt, pm_stream_t stream);
+
+/* Per-step bottom boundary condition and bottom-boundary-layer diffusivity selection of the
+ * Jansen & Nadeau driver, examples/run_JansenNadeau_2018.py:233-254.  Columns are stored
+ * basin rows [0, n) then north rows [n, 2n); coefficient set 0 = kappa, 1 = kappaeff.    */
+typedef struct pm_jn2018_bc {
+  int32_t n, nz, ny, reserved;
+  const double *Psi_SO;    /* [n][nz] PsiSO.Psi                                        */
+  const double *Psi_res_b; /* [n][nz] AMOC.Psibz()[0]                                  */
+  const double *Psi_res_n; /* [n][nz] AMOC.Psibz()[1]                                  */
+  const double *b_basin;   /* [n][nz] */
+  const double *b_north;   /* [n][nz] */
+  const double *bs_SO;     /* [n][ny] channel.bs                                       */
+  double *bbot;            /* [2n] in/out: Column.bbot of basin / north columns        */
+  int32_t *ksel;           /* [2n] in/out: coefficient set of basin / north columns    */
+} pm_jn2018_bc;
+
+int pm_jn2018_bc_switch(const pm_jn2018_bc *bc, pm_stream_t stream);
+
 /* ------------------------------------------------------------------ RCCL
  * One process per GPU.  The ensemble is sharded by member, stepping needs no
  * communication; the only exchange is the gather of per-member output at diagnostic

@@ -10,9 +10,10 @@ from .device import DeviceArray, Stream, Event, Graph, synchronize
 from .columns import ColumnBatch
 from .thermwind import ThermwindBatch
 from .psi_so import PsiSOBatch
+from .so_ml import SOMLBatch
 from . import modules
 from . import utils
-from .modules import Column, Psi_Thermwind, Psi_SO
+from .modules import Column, Psi_Thermwind, Psi_SO, SO_ML
 from . import configs
 from . import sharding
-from .ensembles import ColumnThermwindEnsemble, TwoColEnsemble
+from .ensembles import ColumnThermwindEnsemble, TwoColEnsemble, JN2018Ensemble

@@ -65,6 +65,26 @@ class pm_psi_so(C.Structure):
   ]
 
 
+class pm_so_ml(C.Structure):
+  """Mirror of `struct pm_so_ml` (include/pymoc_hip.h)."""
+  _fields_ = [
+      ("n", C.c_int32), ("nz", C.c_int32), ("ny", C.c_int32), ("reserved", C.c_int32),
+      ("y", c_dp), ("bs", c_dp), ("Psi_s", c_dp), ("b_basin", c_dp), ("Psi_b", c_dp),
+      ("surflux", c_dp), ("rest_mask", c_dp), ("b_rest", c_dp),
+      ("Ks", C.c_double), ("h", C.c_double), ("L", C.c_double), ("v_pist", C.c_double),
+      ("status", c_dp)
+  ]
+
+
+class pm_jn2018_bc(C.Structure):
+  """Mirror of `struct pm_jn2018_bc` (include/pymoc_hip.h)."""
+  _fields_ = [
+      ("n", C.c_int32), ("nz", C.c_int32), ("ny", C.c_int32), ("reserved", C.c_int32),
+      ("Psi_SO", c_dp), ("Psi_res_b", c_dp), ("Psi_res_n", c_dp), ("b_basin", c_dp),
+      ("b_north", c_dp), ("bs_SO", c_dp), ("bbot", c_dp), ("ksel", c_dp)
+  ]
+
+
 if not os.path.exists(LIB_PATH):
   raise ImportError(
       "pymoc_amd: %s is missing. Build it with `make lib` (hipcc --offload-arch=gfx950) "
@@ -104,6 +124,8 @@ SIGNATURES = {
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "pm_thermwind_update": (C.c_int, [C.POINTER(pm_thermwind), C.c_int32, C.c_void_p]),
     "pm_psi_so_update": (C.c_int, [C.POINTER(pm_psi_so), C.c_int32, C.c_void_p]),
+    "pm_so_ml_step": (C.c_int, [C.POINTER(pm_so_ml), C.c_double, C.c_void_p]),
+    "pm_jn2018_bc_switch": (C.c_int, [C.POINTER(pm_jn2018_bc), C.c_void_p]),
     "pm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pm_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "pm_comm_destroy": (C.c_int, [C.c_void_p]),

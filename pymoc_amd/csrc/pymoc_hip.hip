@@ -7,6 +7,7 @@
 #include "column.hip.h"
 #include "thermwind.hip.h"
 #include "psi_so.hip.h"
+#include "so_ml.hip.h"
 #include "comm.hip.h"
 
 namespace pm {
@@ -252,6 +253,32 @@ int pm_psi_so_update(const pm_psi_so *so, int32_t ops, pm_stream_t stream) {
   PM_REQUIRE(a.bvp_refine >= 0 && a.bvp_refine <= 256, "bad bvp_refine");
   if (a.n == 0) return PM_OK;
   return dispatch_psi_so(a, ops, resolve_stream(stream));
+}
+
+// --------------------------------------------------------------------- SO_ML
+int pm_so_ml_step(const pm_so_ml *ml, double dt, pm_stream_t stream) {
+  PM_REQUIRE(ml, "ml is NULL");
+  const pm_so_ml &a = *ml;
+  PM_REQUIRE(a.n >= 0 && a.nz >= 2 && a.ny >= 3 && a.nz <= 4096 && a.ny <= 2048,
+             "bad shape n=%d nz=%d ny=%d", a.n, a.nz, a.ny);
+  PM_REQUIRE(a.y && a.bs && a.b_basin && a.Psi_b && a.surflux && a.rest_mask && a.b_rest,
+             "pm_so_ml has a NULL required pointer");
+  if (a.n == 0) return PM_OK;
+  return launch_so_ml(a, dt, resolve_stream(stream));
+}
+
+int pm_jn2018_bc_switch(const pm_jn2018_bc *bc, pm_stream_t stream) {
+  PM_REQUIRE(bc, "bc is NULL");
+  const pm_jn2018_bc &a = *bc;
+  PM_REQUIRE(a.n >= 0 && a.nz >= 2 && a.ny >= 1, "bad shape n=%d nz=%d ny=%d", a.n, a.nz, a.ny);
+  PM_REQUIRE(a.Psi_SO && a.Psi_res_b && a.Psi_res_n && a.b_basin && a.b_north && a.bs_SO &&
+                 a.bbot && a.ksel,
+             "pm_jn2018_bc has a NULL pointer");
+  if (a.n == 0) return PM_OK;
+  hipLaunchKernelGGL(k_jn2018_bc_switch, dim3((a.n + 255) / 256), dim3(256), 0,
+                     resolve_stream(stream), a);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
 }
 
 // ---------------------------------------------------------------------- RCCL

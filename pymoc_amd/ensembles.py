@@ -3,6 +3,7 @@ whole parameter-sweep ensemble with all state resident in HBM.
 
 The reference has no driver class: the loops live in examples/*.py.  The
 classes here reproduce those loops' order of operations and cadence exactly:
+  JN2018Ensemble           examples/run_JansenNadeau_2018.py:201-261 (config 5)
   ColumnThermwindEnsemble  examples/example_timestepping.py:73-80   (BASELINE config 1)
   TwoColEnsemble           examples/example_twocol.py:85-96         (config 3)
                            examples/example_twocol_plusSO.py:99-115 (config 4, with_so)
@@ -14,6 +15,7 @@ from . import _lib
 from .columns import ColumnBatch
 from .device import DeviceArray
 from .psi_so import PsiSOBatch
+from .so_ml import SOMLBatch
 from .thermwind import ThermwindBatch
 
 _TW_ALL = _lib.PM_TW_SOLVE | _lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ
@@ -144,6 +146,106 @@ class TwoColEnsemble(object):
       out.update(Psi_SO=self.so.Psi.download(), Psi_Ek=self.so.Psi_Ek.download(),
                  Psi_GM=self.so.Psi_GM.download())
     return out
+
+  def nonfinite_members(self):
+    nf = self.cols.get_nonfinite()
+    return np.nonzero(nf[:self.n] | nf[self.n:])[0]
+
+
+class JN2018Ensemble(object):
+  """run_JansenNadeau_2018.py with default flags: basin + north columns, thermal wind,
+  SO channel overturning (no BVP smoother) and the SO mixed layer, with the script's
+  per-step bottom-BC / bottom-boundary-layer diffusivity switching.
+
+  Per step: BC switch -> both columns (convective adjustment on) -> mixed layer; every
+  MOC_up_iters steps (before the step) the three diagnostics are refreshed.  With
+  `use_graph` a whole MOC block is captured once into a hipGraph and replayed."""
+
+  def __init__(self, cfg, stream=None, lanes_per_col=0, use_graph=False):
+    import ctypes as C
+    from ._lib import pm_jn2018_bc
+    z, y = cfg['z'], cfg['y']
+    nz, ny = z.size, y.size
+    n = np.atleast_2d(cfg['b_basin0']).shape[0]
+    self.n, self.nz, self.ny = n, nz, ny
+    self.dt, self.M, self.nb = float(cfg['dt']), int(cfg['MOC_up_iters']), int(cfg['nb'])
+    self.lanes, self.stream = lanes_per_col, stream
+    bb0, bn0 = _rows(cfg['b_basin0'], n, nz), _rows(cfg['b_north0'], n, nz)
+    kap = np.broadcast_to(np.asarray(cfg['kappa'], dtype=np.float64), (n, nz))
+    kapeff = np.broadcast_to(np.asarray(cfg['kappaeff'], dtype=np.float64), (n, nz))
+    # Column(kappa=kappaeff, bbot=b[0]) (:159-171); coefficient set 0 = kappa, 1 = kappaeff
+    self.cols = ColumnBatch(
+        z, np.concatenate([kap, kap]),
+        np.concatenate([_rows(cfg['A_basin'], n, nz), _rows(cfg['A_north'], n, nz)]),
+        np.concatenate([bb0, bn0]),
+        bs=np.concatenate([_vec(cfg['bs'], n), _vec(cfg['bs_north'], n)]),
+        bbot=np.concatenate([bb0[:, 0], bn0[:, 0]]), do_conv=True,
+        kappa_alt=np.concatenate([kapeff, kapeff]), stream=stream)
+    self.cols.set_ksel(np.ones(2 * n, dtype=np.int32))
+    self.tw = ThermwindBatch(z, n, f=cfg['f'], nb=self.nb, stream=stream, z_dev=self.cols.z)
+    self.so = PsiSOBatch(z, y, n, tau=cfg['tau'], KGM=cfg['KGM'], f=cfg['f'], L=cfg['L'],
+                         stream=stream, z_dev=self.cols.z)
+    bs0 = cfg['bs_SO0']
+    self.ml = SOMLBatch(y, nz, _rows(bs0, n, ny) if np.ndim(bs0) == 1 else bs0,
+                        surflux=cfg['surflux'], rest_mask=cfg['rest_mask'],
+                        b_rest=cfg['b_rest'], Ks=cfg['Ks'], h=cfg['h'], L=cfg['L'],
+                        v_pist=cfg['v_pist'], stream=stream)
+    self.wA = DeviceArray.zeros((2 * n, nz))
+    self._off = n * nz * 8
+    self._bc = pm_jn2018_bc()
+    d = self._bc
+    d.n, d.nz, d.ny, d.reserved = n, nz, ny, 0
+    d.Psi_SO, d.Psi_res_b, d.Psi_res_n = self.so.Psi.ptr, self.tw.psibz1.ptr, self.tw.psibz2.ptr
+    d.b_basin, d.b_north = self.cols.b.ptr, self.cols.b.ptr + self._off
+    d.bs_SO, d.bbot, d.ksel = self.ml.bs.ptr, self.cols.bbot.ptr, self.cols.ksel.ptr
+    self._C = C
+    self.ii = 0
+    self._graph = None
+    self._use_graph = use_graph
+
+  def _update(self):
+    b_basin, b_north = self.cols.b.ptr, self.cols.b.ptr + self._off
+    self.so.update(b_basin, self.ml.bs)
+    self.tw.update(b_basin, b_north, ops=_TW_ALL, Psi_SO=self.so.Psi, wA1=self.wA.ptr,
+                   wA2=self.wA.ptr + self._off)
+
+  def _step(self):
+    from ._lib import check, lib
+    from .device import _sh
+    check(lib.pm_jn2018_bc_switch(self._C.byref(self._bc), _sh(self.stream)))
+    self.cols.steps(self.wA, self.dt, 1, lanes_per_col=self.lanes)
+    self.ml.step(self.cols.b.ptr, self.so.Psi, self.dt)
+
+  def _block(self):
+    self._update()
+    for _ in range(self.M):
+      self._step()
+
+  def run(self, nsteps):
+    from .device import Graph
+    remaining = int(nsteps)
+    while remaining > 0:
+      if self._use_graph and self.ii % self.M == 0 and remaining >= self.M:
+        if self._graph is None:
+          with Graph.capture(self.stream) as cap:
+            self._block()
+          self._graph = cap.graph
+        self._graph.launch(self.stream)
+        self.ii += self.M
+        remaining -= self.M
+        continue
+      if self.ii % self.M == 0:
+        self._update()
+      self._step()
+      self.ii += 1
+      remaining -= 1
+
+  def state(self):
+    b = self.cols.get_b()
+    return dict(b_basin=b[:self.n], b_north=b[self.n:], bs_SO=self.ml.bs.download(),
+                Psi=self.tw.Psi.download(), Psi_SO=self.so.Psi.download(),
+                Psi_iso_b=self.tw.psibz1.download(), Psi_iso_n=self.tw.psibz2.download(),
+                Psi_s=self.ml.Psi_s.download())
 
   def nonfinite_members(self):
     nf = self.cols.get_nonfinite()

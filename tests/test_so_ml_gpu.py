@@ -1,0 +1,131 @@
+"""GPU parity of K5 (pm_so_ml_step), the JN2018 BC switch and the JN2018 driver (config 5)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from oracle import drivers
+from conftest import load_golden, relerr
+from pymoc_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_so_ml_golden(gpu):
+  from pymoc_amd.device import DeviceArray
+  g = load_golden("so_ml")
+  Ks, h, L, v_pist = g["par"]
+  nz = g["z"].size
+  for k in range(int(g["ncases"])):
+    p = "c%02d_" % k
+    dt = float(g[p + "dt"])
+    t = gpu.SOMLBatch(g["y"], nz, g[p + "bs0"], surflux=g["surflux"], rest_mask=g["rest_mask"],
+                      b_rest=g["b_rest"], Ks=Ks, h=h, L=L, v_pist=v_pist)
+    bb, pb = DeviceArray.from_host(g["b_basin"][None]), DeviceArray.from_host(g[p + "Psi_b"][None])
+    t.step(bb, pb, dt)
+    obs, ops = O.so_ml_advdiff(g["y"], g["surflux"], g["rest_mask"], g["b_rest"], g[p + "bs0"],
+                               g["b_basin"], g[p + "Psi_b"], dt, Ks=Ks, h=h, L=L, v_pist=v_pist)
+    bs1, ps1 = t.bs.download()[0], t.Psi_s.download()[0]
+    assert np.array_equal(bs1, obs) and np.array_equal(ps1, ops), k  # same Thomas sweep
+    assert relerr(bs1, g[p + "bs1"]) <= 1e-14, k  # reference: dense inverse
+    assert relerr(ps1, g[p + "Psi_s1"]) <= 1e-14 or np.abs(g[p + "Psi_s1"]).max() == 0, k
+    for _ in range(4):
+      t.step(bb, pb, dt)
+    assert relerr(t.bs.download()[0], g[p + "bs5"]) <= 1e-13, k
+    assert t.status.download()[0] == 0
+
+
+@pytest.mark.parametrize("nz,ny", [(2, 3), (5, 4), (64, 51), (100, 64), (200, 65), (81, 200),
+                                    (300, 513)])
+def test_so_ml_ragged_sizes_vs_oracle_bitwise(gpu, nz, ny):
+  from pymoc_amd.device import DeviceArray
+  rng = np.random.default_rng(nz * 3 + ny)
+  n = 6
+  y = np.linspace(0, 2e6, ny)
+  b_basin = np.sort(0.03 * rng.random((n, nz)), axis=1) - 0.002
+  Psi_b = 5 * rng.standard_normal((n, nz))
+  Psi_b[1, : nz // 2] = 0.
+  Psi_b[2] = -np.abs(Psi_b[2])
+  bs = np.sort(0.03 * rng.random((n, ny)), axis=1) - 0.001
+  bs[3, : ny // 3 + 1] = bs[3, ny // 3::-1][: ny // 3 + 1]
+  surflux = -1e-9 * rng.random((n, ny))
+  rest = (rng.random((n, ny)) < 0.7).astype(float)
+  b_rest = bs + 1e-3 * rng.standard_normal((n, ny))
+  dt = 86400. * 10
+  t = gpu.SOMLBatch(y, nz, bs, surflux=surflux, rest_mask=rest, b_rest=b_rest, Ks=400., h=50.,
+                    L=4e6, v_pist=1.5 / 86400)
+  bb, pb = DeviceArray.from_host(b_basin), DeviceArray.from_host(Psi_b)
+  for _ in range(3):
+    t.step(bb, pb, dt)
+  out, ps = t.bs.download(), t.Psi_s.download()
+  for m in range(n):
+    o = bs[m]
+    for _ in range(3):
+      o, ops = O.so_ml_advdiff(y, surflux[m], rest[m], b_rest[m], o, b_basin[m], Psi_b[m], dt,
+                               Ks=400., h=50., L=4e6, v_pist=1.5 / 86400)
+    assert np.array_equal(out[m], o), (nz, ny, m)
+    assert np.array_equal(ps[m], ops), (nz, ny, m)
+
+
+def test_so_ml_wrapper_api(gpu):
+  g = load_golden("so_ml")
+  Ks, h, L, v_pist = g["par"]
+  p = "c00_"
+  ch = gpu.SO_ML(y=g["y"], h=h, L=L, Ks=Ks, surflux=g["surflux"].copy(),
+                 rest_mask=g["rest_mask"].copy(), b_rest=g["b_rest"].copy(), v_pist=v_pist,
+                 bs=g[p + "bs0"].copy())
+  ch.timestep(b_basin=g["b_basin"], Psi_b=g[p + "Psi_b"], dt=float(g[p + "dt"]))
+  assert relerr(ch.bs, g[p + "bs1"]) <= 1e-14
+  assert relerr(ch.Psi_s, g[p + "Psi_s1"]) <= 1e-14
+  with pytest.raises(TypeError) as e:
+    ch.timestep(b_basin=1.0, Psi_b=g[p + "Psi_b"])
+  assert str(e.value) == 'b_basin needs to be numpy array providing buoyancy levels in basin'
+  with pytest.raises(TypeError) as e:
+    ch.timestep(b_basin=g["b_basin"], Psi_b=2.0)
+  assert str(e.value) == ('Psi_b needs to be numpy array providing overturning at buoyancy '
+                          'levels given by b_basin')
+  with pytest.raises(IndexError):  # hazard H10: Psi_b identically zero
+    ch.timestep(b_basin=g["b_basin"], Psi_b=0 * g[p + "Psi_b"], dt=86400.)
+  with pytest.raises(TypeError) as e:
+    gpu.SO_ML(y=1.0)
+  assert str(e.value) == 'y needs to be numpy array providing (regular) grid'
+
+
+@pytest.mark.parametrize("name,nz,dtd,steps,use_graph", [
+    ("jn2018_nz81", 81, 30., (1, 12, 13, 14, 240, 1200), False),
+    ("jn2018_nz200", 200, 10., (1, 36, 37, 38, 360, 1200), True),
+])
+def test_jn2018_trajectory_golden(gpu, name, nz, dtd, steps, use_graph):
+  """run_JansenNadeau_2018 physics against the reference's snapshots (1e-10: ys by direct
+  inversion instead of brentq) -- eager launches and hipGraph replay of whole MOC blocks."""
+  g = load_golden(name)
+  m = configs.jn2018_member(nz=nz, dt_days=dtd)
+  cfg = dict(m)
+  for k in ("b_basin0", "b_north0", "bs_SO0", "surflux", "b_rest"):
+    cfg[k] = m[k][None]
+  cfg["rest_mask"] = m["rest_mask"][None]
+  ens = gpu.JN2018Ensemble(cfg, use_graph=use_graph)
+  done = 0
+  for s in steps:
+    ens.run(s - done)
+    done = s
+    st = ens.state()
+    for k in ("b_basin", "b_north", "bs_SO", "Psi", "Psi_SO", "Psi_iso_b", "Psi_iso_n", "Psi_s"):
+      assert relerr(st[k][0], g["s%05d_%s" % (s, k)]) <= 1e-10, (s, k)
+
+
+def test_config5_sweep_members_vs_reference(gpu):
+  g = load_golden("sweep")
+  c = configs.config5(N=4096)
+  c["rest_mask"] = np.repeat(c["rest_mask"][None], 4096, axis=0)
+  ens = gpu.JN2018Ensemble(c, use_graph=True)
+  n, nl = int(g["c5_nsteps"]), int(g["c5_long_nsteps"])
+  ens.run(n)
+  st = ens.state()
+  idx = g["c5_members"]
+  for k in ("b_basin", "b_north", "bs_SO", "Psi_SO"):
+    assert relerr(st[k][idx], g["c5_" + k]) <= 1e-10, k
+  ens.run(nl - n)
+  st = ens.state()
+  idx = g["c5_long_members"]
+  for k in ("b_basin", "b_north", "bs_SO", "Psi_SO"):
+    assert relerr(st[k][idx], g["c5_long_" + k]) <= 1e-9, k
