@@ -1,0 +1,142 @@
+"""The drop-in module classes: the reference's own unit tests
+(tests/modules/test_column.py:247-336) re-expressed against pymoc_amd, and user-style
+loops written exactly like the reference's example scripts."""
+import numpy as np
+import pytest
+
+import oracle as O
+from oracle import drivers
+from conftest import load_golden, relerr
+from pymoc_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_vertadvdiff_reference_unit_test(gpu):
+  dt = 60 * 86400
+  Area = 6e13
+  z = np.asarray(np.linspace(-4000, 0, 80))
+  kappa = 2e-5
+  b = np.linspace(0.03, -0.002, 80)
+  wA = Area * np.sin(z)
+  db_dt1 = (0.0004 / 50.0 / Area) * (-wA)
+  column = gpu.Column(z=z, Area=Area, kappa=kappa, b=b.copy(), bbot=-0.002, bs=0.03)
+  column.vertadvdiff(wA, dt, do_conv=False)
+  assert all(np.around(column.b[2:-2], 3) == np.around(b[2:-2] - dt * db_dt1[2:-2], 3))
+  assert np.array_equal(column.b, O.column_vertadvdiff(z, kappa + 0 * z, Area + 0 * z, b, wA, dt,
+                                                       bs=0.03, bbot=-0.002))
+
+
+def test_convect_reference_unit_test(gpu):
+  N2min = 1.5e-7
+  z = np.asarray([-4000.0, -1000.0, -100.0, 0.0])
+  b = np.asarray([-0.03, -0.02, 0.01, 0.01])
+  column = gpu.Column(z=z, b=b.copy(), bs=0.0, N2min=N2min, kappa=2e-5, Area=6e13)
+  b[2:] = 0.0 + N2min * (z[2:] - z[1])
+  column.convect()
+  assert all(column.b == b)
+
+
+def test_horadv_reference_unit_test(gpu):
+  z = np.asarray([-4000.0, -1000.0, -100.0, 0.0])
+  b = np.asarray([-0.03, 0.01, -0.0025, -0.002])
+  column = gpu.Column(z=z, b=b.copy(), kappa=2e-5, Area=6e13)
+  vdx_in = np.asarray([2e8, 2.5e8, 0.0, 0.0])
+  b_in = np.asarray([-0.02, 0.01, -0.001, 0.001])
+  dt = 60 * 86400
+  b[0] = -0.03 + dt * 2e6 / 6e13
+  column.horadv(vdx_in, b_in, dt)
+  assert all(np.around(column.b, 4) == np.around(b, 4))
+
+
+def test_timestep_composition_reference_unit_test(gpu):
+  Area = 6e13
+  z = np.asarray(np.linspace(-4000, 0, 80))
+  b = np.linspace(-np.sqrt(0.04), 0.0, 80)**2.
+  vdx_in = np.asarray([2e4 for n in z])
+  b_in = np.asarray([-0.02 for n in z])
+  wA = np.sin(z) / Area
+  dt = 30 * 86400
+  mk = lambda: gpu.Column(z=z, b=b.copy(), bs=-0.0, bbot=-0.04, kappa=2e-5, Area=Area)  # noqa
+  c1, c2 = mk(), mk()
+  c1.timestep(wA=wA, dt=dt)
+  c2.vertadvdiff(wA=wA, dt=dt)
+  assert all(c1.b == c2.b)
+  c2.horadv(vdx_in=vdx_in, b_in=b_in, dt=dt)
+  c2.convect()
+  assert any(c1.b != c2.b)
+  c1, c2 = mk(), mk()
+  c1.timestep(wA=wA, dt=dt, b_in=b_in, vdx_in=vdx_in)
+  c2.vertadvdiff(wA=wA, dt=dt)
+  c2.horadv(vdx_in=vdx_in, b_in=b_in, dt=dt)
+  assert all(c1.b == c2.b)
+  c2.convect()
+  assert any(c1.b != c2.b)
+  c1, c2 = mk(), mk()
+  c1.timestep(wA=wA, dt=dt, b_in=b_in, vdx_in=vdx_in, do_conv=True)
+  c2.convect()
+  c2.vertadvdiff(wA=wA, dt=dt)
+  c2.horadv(vdx_in=vdx_in, b_in=b_in, dt=dt)
+  assert all(c1.b == c2.b)
+  c = mk()
+  with pytest.raises(TypeError) as e:
+    c.timestep(wA=wA, dt=dt, vdx_in=vdx_in)
+  assert str(e.value) == "b_in is needed if vdx_in is provided"
+  with pytest.raises(TypeError) as e:
+    c.timestep(wA=1, dt=dt)
+  assert str(e.value) == "('wA', 'needs to be either function, numpy array, or float')"
+
+
+def test_column_updates_users_array_in_place_and_tracks_attribute_pokes(gpu):
+  z = np.linspace(-4000., 0., 50)
+  b = 0.03 * np.exp(z / 300.)
+  col = gpu.Column(z=z, kappa=lambda zz: 1e-5 + 0 * zz, Area=8e13, b=b, bs=0.03, bbot=0.0)
+  assert col.b is b
+  col.timestep(wA=0., dt=86400.)
+  assert col.b is b and b[0] == 0.0          # updated in place (column.py:249)
+  col.bbot = -0.001                          # user pokes between steps
+  col.kappa = lambda zz: 5e-5 + 0 * zz       # (run_JansenNadeau_2018.py:233-254)
+  ref = O.column_timestep(z, 5e-5 + 0 * z, 8e13 + 0 * z, b, 0 * z, 86400., bs=0.03, bbot=-0.001)
+  col.timestep(wA=0., dt=86400.)
+  assert np.array_equal(b, ref)
+
+
+def test_user_loop_like_example_twocol(gpu):
+  """A loop written exactly like examples/example_twocol.py:85-96, with the drop-in classes."""
+  m = configs.twocol_member(nz=80)
+  z = m["z"]
+  AMOC = gpu.Psi_Thermwind(z=z, b1=m["b_basin0"].copy(), b2=m["b_north0"].copy())
+  AMOC.solve()
+  [Psi_iso_b, Psi_iso_n] = AMOC.Psibz()
+  basin = gpu.Column(z=z, kappa=m["kappa"].copy(), Area=m["A_basin"], b=m["b_basin0"].copy(),
+                     bs=m["bs"], bbot=m["bbot"])
+  north = gpu.Column(z=z, kappa=m["kappa"].copy(), Area=m["A_north"], b=m["b_north0"].copy(),
+                     bs=m["bs_north"], bbot=m["bbot"])
+  for ii in range(0, 60):
+    wAb = Psi_iso_b * 1e6
+    wAN = -Psi_iso_n * 1e6
+    basin.timestep(wA=wAb, dt=m["dt"])
+    north.timestep(wA=wAN, dt=m["dt"], do_conv=True)
+    if ii % m["MOC_up_iters"] == 0:
+      AMOC.update(b1=basin.b, b2=north.b)
+      AMOC.solve()
+      [Psi_iso_b, Psi_iso_n] = AMOC.Psibz()
+  ref = drivers.run_twocol(m, 60, {60})[60]
+  assert np.array_equal(basin.b, ref["b_basin"])
+  assert np.array_equal(north.b, ref["b_north"])
+  assert np.array_equal(AMOC.Psi, ref["Psi"])
+
+
+def test_rccl_communicator_single_rank(gpu):
+  """RCCL through the C-ABI on the one GPU of this box: init, barrier, all-gather, max."""
+  from pymoc_amd import sharding
+  from pymoc_amd.device import DeviceArray
+  comm = sharding.RcclCommunicator(rank=0, world=1)
+  a = np.arange(600.).reshape(6, 100)
+  send, recv = DeviceArray.from_host(a), DeviceArray((1, 6, 100))
+  comm.allgather_device(send, recv)
+  comm.barrier()
+  assert np.array_equal(recv.download()[0], a)
+  assert np.array_equal(sharding.gather_members(comm, a, 6), a)
+  assert comm.max_host(3.5) == 3.5
+  comm.close()
