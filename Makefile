@@ -8,15 +8,21 @@ HIPHDR = $(wildcard $(CSRC)/*.h) include/pymoc_hip.h
 
 all: lib oracle
 
+HIPCFLAGS = --offload-arch=$(ARCH) -O3 -ffp-contract=off -fPIC -std=c++17 -Wno-unused-value
+HIPOBJ = $(CSRC)/build/pymoc_hip.o $(CSRC)/build/column_g16.o $(CSRC)/build/column_g32.o $(CSRC)/build/column_g64.o
+
 lib: pymoc_amd/libpymoc_hip.so
-pymoc_amd/libpymoc_hip.so: $(HIPSRC) $(HIPHDR)
-	$(HIPCC) $(HIPFLAGS) -o $@ $(HIPSRC) -ldl
+$(CSRC)/build/%.o: $(CSRC)/%.hip $(HIPHDR)
+	@mkdir -p $(CSRC)/build
+	$(HIPCC) $(HIPCFLAGS) -c -o $@ $<
+pymoc_amd/libpymoc_hip.so: $(HIPOBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIPOBJ) -ldl
 
 oracle: oracle/libpymoc_oracle.so
 oracle/libpymoc_oracle.so: oracle/pymoc_oracle.c oracle/pymoc_oracle.h
 	gcc -O2 -ffp-contract=off -fPIC -shared -std=c99 -Wall -o $@ oracle/pymoc_oracle.c -lm
 
 clean:
-	rm -f pymoc_amd/libpymoc_hip.so oracle/libpymoc_oracle.so
+	rm -rf pymoc_amd/libpymoc_hip.so oracle/libpymoc_oracle.so $(CSRC)/build
 
 .PHONY: all lib oracle clean

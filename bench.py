@@ -133,7 +133,7 @@ def main():
   b_final = batch.get_b()
 
   if rank == 0:
-    lanes = args.lanes or (64 if C <= 4096 else (32 if C <= 16384 else 16))
+    lanes = args.lanes or 64
     value = world * C * K / elapsed
     launch_s = kernel_ms * 1e-3 / launches
     steps_per_launch_eff = K / launches

@@ -132,6 +132,8 @@ SIGNATURES = {
     "pm_comm_allgather": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_size_t, C.c_void_p]),
     "pm_comm_allreduce_max": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_size_t, C.c_void_p]),
     "pm_comm_barrier": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pm_selftest_fastdiv": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32,
+                                      C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "pm_selftest_lane_shift": (C.c_int, [C.POINTER(C.c_int32)]),
 }
 

@@ -26,6 +26,7 @@ struct ColRegs {
   double kap[P];   // kappa(z_i)
   double area[P];  // Area(z_i)
   double dAk[P];   // d(Area*kappa)/dz at z_i (np.gradient, host precomputed)
+  double rdz[P], rdzc[P], rarea[P];  // RN(1/dz), RN(1/dzc), RN(1/area) (FAST path only)
 };
 
 // Column.convect (column.py:251-271).  `zg` is the shared grid in global memory.
@@ -68,8 +69,9 @@ __device__ __forceinline__ void col_convect(double (&b)[P], const double (&z)[P]
   }
 }
 
-// Column.vertadvdiff (column.py:210-249), one explicit step.
-template <int G, int P>
+// Column.vertadvdiff (column.py:210-249), one explicit step.  FAST: the three divisions by
+// static denominators go through div_by_recip (correctly rounded, so still bit-identical).
+template <int G, int P, bool FAST>
 __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA)[P],
                                                 double dt, bool do_conv, double bs,
                                                 double bbot, bool use_bzbot,
@@ -88,25 +90,77 @@ __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA
   // bottom boundary condition (column.py:232-233); level 0 = lane 0, slot 0
   if (lg == 0) r.b[0] = use_bzbot ? (bup[0] - bzbot * r.dz[0]) : bbot;
 
+  // Every stage below is written across the P slots so that the in-order wave always has
+  // P independent dependency chains in flight (one wave per SIMD is latency-bound).
   double bz[P];  // (b[i+1]-b[i])/dz[i]  (column.py:235)
+  {
+    double num[P], q[P], rr[P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const int i = lg * P + p;
-    bz[p] = (i < nz - 1) ? (bup[p] - r.b[p]) / r.dz[p] : 0.0;
+    for (int p = 0; p < P; ++p) num[p] = bup[p] - r.b[p];
+    if constexpr (FAST) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) q[p] = num[p] * r.rdz[p];
+#pragma unroll
+      for (int p = 0; p < P; ++p) rr[p] = __builtin_fma(-r.dz[p], q[p], num[p]);
+#pragma unroll
+      for (int p = 0; p < P; ++p) q[p] = __builtin_fma(rr[p], r.rdz[p], q[p]);
+#pragma unroll
+      for (int p = 0; p < P; ++p) rr[p] = __builtin_fma(-r.dz[p], q[p], num[p]);
+#pragma unroll
+      for (int p = 0; p < P; ++p) q[p] = __builtin_fma(rr[p], r.rdz[p], q[p]);
+    } else {
+#pragma unroll
+      for (int p = 0; p < P; ++p) q[p] = num[p] / r.dz[p];
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) bz[p] = (lg * P + p < nz - 1) ? q[p] : 0.0;
   }
   const double pbz = from_prev_lane(bz[P - 1]);
+  double bz_dn[P], dbz[P], flx[P], bzz[P], adv[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    bz_dn[p] = (p > 0) ? bz[p > 0 ? p - 1 : 0] : pbz;
+    dbz[p] = bz[p] - bz_dn[p];
+    const double weff = wA[p] - r.dAk[p];                // column.py:241
+    const double bzu = (weff < 0.0) ? bz[p] : bz_dn[p];  // column.py:242-243
+    flx[p] = (-weff) * bzu;
+  }
+  if constexpr (FAST) {  // bzz = dbz/dzc (:238) and adv = flx/Area (:246), interleaved
+    double r1[P], r2[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      bzz[p] = dbz[p] * r.rdzc[p];
+      adv[p] = flx[p] * r.rarea[p];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        r1[p] = __builtin_fma(-r.dzc[p], bzz[p], dbz[p]);
+        r2[p] = __builtin_fma(-r.area[p], adv[p], flx[p]);
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        bzz[p] = __builtin_fma(r1[p], r.rdzc[p], bzz[p]);
+        adv[p] = __builtin_fma(r2[p], r.rarea[p], adv[p]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      bzz[p] = dbz[p] / r.dzc[p];
+      adv[p] = flx[p] / r.area[p];
+    }
+  }
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int i = lg * P + p;
-    if (i >= 1 && i <= nz - 2) {
-      const double bz_up = bz[p];
-      const double bz_dn = (p > 0) ? bz[p > 0 ? p - 1 : 0] : pbz;
-      const double bzz = (bz_up - bz_dn) / r.dzc[p];          // column.py:238
-      const double weff = wA[p] - r.dAk[p];                   // column.py:241
-      const double bzu = (weff < 0.0) ? bz_up : bz_dn;        // column.py:242-243
-      const double db_dt = (-weff) * bzu / r.area[p] + r.kap[p] * bzz;  // :245-248
-      r.b[p] = r.b[p] + dt * db_dt;                           // column.py:249
-    }
+    const bool interior = (i >= 1) && (i <= nz - 2);
+    const double db_dt = adv[p] + r.kap[p] * bzz[p];  // column.py:245-248
+    // column.py:249.  Boundary / padding slots advance with dt = 0 (b + 0*x == b for the
+    // finite x they hold) instead of a select, which the compiler would turn back into
+    // one exec-masked block per slot and serialise the chains.
+    r.b[p] = r.b[p] + (interior ? dt : 0.0) * db_dt;
   }
 }
 
@@ -145,10 +199,13 @@ __device__ __forceinline__ void col_load_static(ColRegs<P> &r, const pm_columns 
     r.kap[p] = c.kappa[sbase + ic];
     r.dAk[p] = c.dAkappa[sbase + ic];
     r.area[p] = c.area[base + ic];
+    r.rdz[p] = 1.0 / r.dz[p];
+    r.rdzc[p] = 1.0 / r.dzc[p];
+    r.rarea[p] = 1.0 / r.area[p];
   }
 }
 
-template <int G, int P>
+template <int G, int P, bool FAST>
 __global__ __launch_bounds__(256) void k_column_steps(
     pm_columns c, const double *__restrict__ wA_g, const double *__restrict__ vdx_g,
     const double *__restrict__ bin_g, double dt, int nsteps, int ops) {
@@ -186,7 +243,7 @@ __global__ __launch_bounds__(256) void k_column_steps(
     if ((ops & PM_OP_CONVECT) && do_conv)
       col_convect<G, P>(r.b, r.z, bs, N2min, lg, lane, nz, c.z);
     if (ops & PM_OP_VERTADVDIFF)
-      col_vertadvdiff<G, P>(r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lg, nz);
+      col_vertadvdiff<G, P, FAST>(r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lg, nz);
     if ((ops & PM_OP_HORADV) && vdx_g) col_horadv<P>(r, vdx, bin, dt, lg, nz);
   }
 
@@ -206,10 +263,19 @@ __global__ __launch_bounds__(256) void k_column_steps(
 }
 
 // ------------------------------------------------------------------ dispatch
-inline int pick_levels_per_lane(int need) {
-  static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13, 16};
-  for (int v : sup)
-    if (v >= need) return v;
+// The <G,P,FAST> instantiations are compiled in three translation units (column_g16.hip,
+// column_g32.hip, column_g64.hip) so that the build parallelises.
+inline int pick_levels_per_lane(int G, int need) {
+  // narrow groups only up to 8 levels per lane; taller columns go to wider groups
+  static const int sup64[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13, 16};
+  static const int sup[] = {1, 2, 3, 4, 5, 6, 7, 8};
+  if (G == 64) {
+    for (int v : sup64)
+      if (v >= need) return v;
+  } else {
+    for (int v : sup)
+      if (v >= need) return v;
+  }
   return -1;
 }
 
@@ -219,32 +285,32 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
                         hipStream_t st) {
   const int cols_per_block = 256 / G;
   const unsigned grid = (unsigned)((c.ncols + cols_per_block - 1) / cols_per_block);
-  hipLaunchKernelGGL((k_column_steps<G, P>), dim3(grid), dim3(256), 0, st, c, wA, vdx,
-                     bin, dt, nsteps, ops);
+  // the reciprocal path pays 3 true divisions per level up front: worth it from 3 steps on
+  if (nsteps >= 3)
+    hipLaunchKernelGGL((k_column_steps<G, P, true>), dim3(grid), dim3(256), 0, st, c, wA, vdx,
+                       bin, dt, nsteps, ops);
+  else
+    hipLaunchKernelGGL((k_column_steps<G, P, false>), dim3(grid), dim3(256), 0, st, c, wA, vdx,
+                       bin, dt, nsteps, ops);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
 
-template <int G>
-int dispatch_column_steps_P(int P, const pm_columns &c, const double *wA,
-                            const double *vdx, const double *bin, double dt, int nsteps,
-                            int ops, hipStream_t st) {
-  switch (P) {
-#define PM_CASE(PP) \
-  case PP:          \
-    return launch_column_steps<G, PP>(c, wA, vdx, bin, dt, nsteps, ops, st);
-    PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
-    PM_CASE(8) PM_CASE(10) PM_CASE(13) PM_CASE(16)
-#undef PM_CASE
-  }
-  return fail(PM_EINVAL, "unsupported levels-per-lane %d", P);
-}
+int column_steps_g16(int P, const pm_columns &c, const double *wA, const double *vdx,
+                     const double *bin, double dt, int nsteps, int ops, hipStream_t st);
+int column_steps_g32(int P, const pm_columns &c, const double *wA, const double *vdx,
+                     const double *bin, double dt, int nsteps, int ops, hipStream_t st);
+int column_steps_g64(int P, const pm_columns &c, const double *wA, const double *vdx,
+                     const double *bin, double dt, int nsteps, int ops, hipStream_t st);
 
 inline int auto_lanes_per_col(int ncols, int nz) {
   // Few columns: one wave per column keeps every SIMD busy (1024 SIMDs on the chip).
   // Many columns: narrower groups raise per-lane ILP and cut idle padding lanes.
-  int G = ncols <= 4096 ? 64 : (ncols <= 16384 ? 32 : 16);
-  while (G < 64 && pick_levels_per_lane((nz + G - 1) / G) < 0) G *= 2;
+  // measured on MI355X (profiles/r01_sweep_columns.txt): one wave per column wins at every
+  // ensemble size from 1024 to 65536 columns at nz=100
+  (void)ncols;
+  int G = 64;
+  while (G < 64 && pick_levels_per_lane(G, (nz + G - 1) / G) < 0) G *= 2;
   return G;
 }
 

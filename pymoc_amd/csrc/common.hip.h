@@ -56,6 +56,26 @@ __device__ __forceinline__ double from_prev_lane(double x) {
 #endif
 }
 
+// ---------------------------------------------------------------- exact division
+// a / d with a precomputed y = RN(1/d) (itself from a true IEEE division): two
+// Markstein correction steps.  q0 = RN(a*y) is within 1.5 ulp of a/d; after the first
+// step q1 is faithful, and for a faithful q1 and correctly rounded y the second step
+// returns the correctly rounded quotient (Markstein 1990; Muller et al., Handbook of
+// Floating-Point Arithmetic, sec. 4.7).  Valid for finite operands whose quotient and
+// residuals stay in the normal range -- every use in this library (buoyancy gradients,
+// fluxes over areas) is ~100 binades away from the limits; non-finite inputs give NaN
+// where IEEE division gives +-inf, which only matters for members already blown up.
+// 5 FMA-class instructions instead of the ~12-instruction v_div_scale / v_rcp / v_fma /
+// v_div_fmas / v_div_fixup sequence.  pm_selftest_fastdiv() checks it against `/`.
+__device__ __forceinline__ double div_by_recip(double a, double d, double y) {
+  double q = a * y;
+  double r = __builtin_fma(-d, q, a);
+  q = __builtin_fma(r, y, q);
+  r = __builtin_fma(-d, q, a);
+  q = __builtin_fma(r, y, q);
+  return q;
+}
+
 // 64-bit mask of the G lanes of this lane's group inside the wave.
 template <int G>
 __device__ __forceinline__ unsigned long long group_mask(int lane) {

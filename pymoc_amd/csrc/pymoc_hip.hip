@@ -49,6 +49,44 @@ __global__ void k_selftest_lane_shift(int *mismatch) {
   if (bad) atomicAdd(mismatch, 1);
 }
 
+// ---- fast exact division self test -----------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long &x) {
+  x += 0x9E3779B97F4A7C15ull;
+  unsigned long long z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ double random_double(unsigned long long &st, int emax) {
+  const unsigned long long r = splitmix64(st);
+  unsigned long long mant = r & 0xFFFFFFFFFFFFFull;
+  const unsigned kind = (unsigned)(r >> 60) & 7u;  // 3/8 of the draws: edge mantissas
+  if (kind == 0) mant = 0xFFFFFFFFFFFFFull - ((r >> 52) & 15ull);
+  if (kind == 1) mant = (r >> 52) & 15ull;
+  if (kind == 2) mant = 0x8000000000000ull + ((r >> 52) & 15ull) - 8ull;
+  const unsigned long long r2 = splitmix64(st);
+  const int e = (int)(r2 % (unsigned long long)(2 * emax + 1)) - emax;
+  const unsigned long long bits = ((r2 >> 63) << 63) | ((unsigned long long)(1023 + e) << 52) | mant;
+  return __longlong_as_double((long long)bits);
+}
+__global__ void k_selftest_fastdiv(unsigned long long seed, int per_thread, int emax,
+                                   unsigned long long *mismatch) {
+  unsigned long long st = seed + 0x1234567ull * (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x);
+  unsigned long long bad = 0;
+  for (int i = 0; i < per_thread; ++i) {
+    const double d = random_double(st, emax);
+    const double y = 1.0 / d;
+    // several numerators per denominator, as in the kernels (static d, changing a)
+    for (int k = 0; k < 4; ++k) {
+      const double a = random_double(st, emax);
+      const double q_ref = a / d;
+      const double q_fast = div_by_recip(a, d, y);
+      bad += (__double_as_longlong(q_ref) != __double_as_longlong(q_fast)) ? 1ull : 0ull;
+    }
+  }
+  if (bad) atomicAdd(mismatch, bad);
+}
+
 }  // namespace pm
 
 using namespace pm;
@@ -212,17 +250,17 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
   if (c.ncols == 0 || nsteps == 0 || ops == 0) return PM_OK;
   int G = lanes_per_col ? lanes_per_col : auto_lanes_per_col(c.ncols, c.nz);
   PM_REQUIRE(G == 16 || G == 32 || G == 64, "lanes_per_col must be 0, 16, 32 or 64");
-  int P = pick_levels_per_lane((c.nz + G - 1) / G);
+  int P = pick_levels_per_lane(G, (c.nz + G - 1) / G);
   while (P < 0 && G < 64) {
     G *= 2;
-    P = pick_levels_per_lane((c.nz + G - 1) / G);
+    P = pick_levels_per_lane(G, (c.nz + G - 1) / G);
   }
   PM_REQUIRE(P > 0, "nz=%d does not fit %d lanes", c.nz, G);
   hipStream_t st = resolve_stream(stream);
   switch (G) {
-    case 16: return dispatch_column_steps_P<16>(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
-    case 32: return dispatch_column_steps_P<32>(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
-    default: return dispatch_column_steps_P<64>(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
+    case 16: return column_steps_g16(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
+    case 32: return column_steps_g32(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
+    default: return column_steps_g64(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
   }
 }
 
@@ -349,6 +387,26 @@ int pm_comm_barrier(pm_comm_t comm, pm_stream_t stream) {
   PM_HIP(hipMemsetAsync(c->scratch, 0, 2 * sizeof(double), st));
   PM_NCCL(nccl().AllReduce(c->scratch, c->scratch + 1, 1, NCCL_FLOAT64, NCCL_MAX, c->comm, st));
   PM_HIP(hipStreamSynchronize(st));
+  return PM_OK;
+}
+
+int pm_selftest_fastdiv(uint64_t seed, int32_t blocks, int32_t per_thread, int32_t emax,
+                        uint64_t *tested, uint64_t *mismatches) {
+  PM_REQUIRE(tested && mismatches, "NULL output");
+  PM_REQUIRE(blocks > 0 && per_thread > 0 && emax >= 0 && emax <= 400, "bad sizes");
+  unsigned long long *d = nullptr;
+  PM_HIP(hipMalloc((void **)&d, sizeof(unsigned long long)));
+  hipStream_t st = resolve_stream(nullptr);
+  PM_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_selftest_fastdiv, dim3(blocks), dim3(256), 0, st,
+                     (unsigned long long)seed, per_thread, emax, d);
+  PM_HIP(hipGetLastError());
+  unsigned long long h = 0;
+  PM_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, st));
+  PM_HIP(hipStreamSynchronize(st));
+  PM_HIP(hipFree(d));
+  *mismatches = h;
+  *tested = 4ull * (unsigned long long)per_thread * 256ull * (unsigned long long)blocks;
   return PM_OK;
 }
 

@@ -93,7 +93,7 @@ __device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
 
 // One isopycnal class: sum_k clip((top_k - bg)/(top_k - bot_k), 0, 1) * u_k over cells
 // [k0, k0+n) in NumPy's pairwise order, for TW_JT classes at once.
-__device__ void psib_block_sum(const double *top, const double *bot, const double *u,
+__device__ __forceinline__ void psib_block_sum(const double *top, const double *bot, const double *u,
                                int k0, int n, const double (&bg)[TW_JT],
                                double (&res)[TW_JT]) {
   if (n < 8) {
@@ -133,6 +133,15 @@ __device__ void psib_block_sum(const double *top, const double *bot, const doubl
   }
 }
 
+// out-of-line copy for the recursive (nz > 129) path: 16 inlined copies per kernel cost
+// minutes of compile time and every register
+__device__ __noinline__ void psib_block_sum_call(const double *top, const double *bot,
+                                                 const double *u, int k0, int n,
+                                                 const double (&bg)[TW_JT],
+                                                 double (&res)[TW_JT]) {
+  psib_block_sum(top, bot, u, k0, n, bg, res);
+}
+
 // np.add.reduce pairwise recursion (blocks of <= 128, left half rounded down to a
 // multiple of 8).  D bounds the recursion depth: D=4 covers n <= 128*16.
 template <int D>
@@ -141,10 +150,10 @@ __device__ __forceinline__ void psib_pairwise(const double *top, const double *b
                                               const double (&bg)[TW_JT],
                                               double (&res)[TW_JT]) {
   if constexpr (D == 0) {
-    psib_block_sum(top, bot, u, k0, n, bg, res);
+    psib_block_sum_call(top, bot, u, k0, n, bg, res);
   } else {
     if (n <= 128) {
-      psib_block_sum(top, bot, u, k0, n, bg, res);
+      psib_block_sum_call(top, bot, u, k0, n, bg, res);
       return;
     }
     int n2 = n / 2;
