@@ -236,6 +236,25 @@ typedef struct pm_jn2018_bc {
 
 int pm_jn2018_bc_switch(const pm_jn2018_bc *bc, pm_stream_t stream);
 
+/* Fused Jansen & Nadeau time loop (examples/run_JansenNadeau_2018.py:228-261): nsteps x
+ * [bottom-BC switch -> basin.timestep(do_conv) -> north.timestep(do_conv) ->
+ * channel.timestep] per member in ONE launch, with wA / Psi_SO / Psibz held fixed (they only
+ * change at MOC updates, :204-217).  Bit-identical to issuing pm_jn2018_bc_switch +
+ * pm_column_steps + pm_so_ml_step per step.  `cols` holds 2n columns (basin rows [0,n),
+ * north rows [n,2n), nsel = 2, bbot / ksel updated in place); `ml.b_basin` / `ml.Psi_b` are
+ * ignored (the basin column and Psi_SO are used).  nz <= 256.                          */
+typedef struct pm_jn2018 {
+  int32_t n, reserved0, reserved1, reserved2;
+  pm_columns cols;
+  const double *wA;        /* [2n][nz] */
+  const double *Psi_SO;    /* [n][nz]  */
+  const double *Psi_res_b; /* [n][nz]  */
+  const double *Psi_res_n; /* [n][nz]  */
+  pm_so_ml ml;
+} pm_jn2018;
+
+int pm_jn2018_steps(const pm_jn2018 *jn, double dt, int32_t nsteps, pm_stream_t stream);
+
 /* ------------------------------------------------------------------ RCCL
  * One process per GPU.  The ensemble is sharded by member, stepping needs no
  * communication; the only exchange is the gather of per-member output at diagnostic

@@ -85,6 +85,15 @@ class pm_jn2018_bc(C.Structure):
   ]
 
 
+class pm_jn2018(C.Structure):
+  """Mirror of `struct pm_jn2018` (include/pymoc_hip.h)."""
+  _fields_ = [
+      ("n", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32),
+      ("reserved2", C.c_int32), ("cols", pm_columns), ("wA", c_dp), ("Psi_SO", c_dp),
+      ("Psi_res_b", c_dp), ("Psi_res_n", c_dp), ("ml", pm_so_ml)
+  ]
+
+
 if not os.path.exists(LIB_PATH):
   raise ImportError(
       "pymoc_amd: %s is missing. Build it with `make lib` (hipcc --offload-arch=gfx950) "
@@ -126,6 +135,7 @@ SIGNATURES = {
     "pm_psi_so_update": (C.c_int, [C.POINTER(pm_psi_so), C.c_int32, C.c_void_p]),
     "pm_so_ml_step": (C.c_int, [C.POINTER(pm_so_ml), C.c_double, C.c_void_p]),
     "pm_jn2018_bc_switch": (C.c_int, [C.POINTER(pm_jn2018_bc), C.c_void_p]),
+    "pm_jn2018_steps": (C.c_int, [C.POINTER(pm_jn2018), C.c_double, C.c_int32, C.c_void_p]),
     "pm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pm_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "pm_comm_destroy": (C.c_int, [C.c_void_p]),

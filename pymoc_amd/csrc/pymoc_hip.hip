@@ -319,6 +319,31 @@ int pm_jn2018_bc_switch(const pm_jn2018_bc *bc, pm_stream_t stream) {
   return PM_OK;
 }
 
+int pm_jn2018_steps(const pm_jn2018 *jn, double dt, int32_t nsteps, pm_stream_t stream) {
+  PM_REQUIRE(jn, "jn is NULL");
+  const pm_jn2018 &a = *jn;
+  const pm_columns &c = a.cols;
+  PM_REQUIRE(a.n >= 0 && c.ncols == 2 * a.n && a.ml.n == a.n && a.ml.nz == c.nz,
+             "inconsistent batch sizes n=%d ncols=%d ml.n=%d", a.n, c.ncols, a.ml.n);
+  PM_REQUIRE(c.nz >= 2 && c.nz <= 256 && a.ml.ny >= 3 && a.ml.ny <= 2048,
+             "bad shape nz=%d ny=%d (fused loop needs nz <= 256)", c.nz, a.ml.ny);
+  PM_REQUIRE(c.nsel == 2 && c.ksel && c.z && c.b && c.kappa && c.area && c.dAkappa && c.bs &&
+                 c.bbot && c.N2min,
+             "pm_jn2018.cols has a NULL pointer or nsel != 2");
+  PM_REQUIRE(a.wA && a.Psi_SO && a.Psi_res_b && a.Psi_res_n, "pm_jn2018 has a NULL pointer");
+  PM_REQUIRE(a.ml.y && a.ml.bs && a.ml.surflux && a.ml.rest_mask && a.ml.b_rest,
+             "pm_jn2018.ml has a NULL pointer");
+  PM_REQUIRE(nsteps >= 0, "nsteps < 0");
+  if (a.n == 0 || nsteps == 0) return PM_OK;
+  hipStream_t st = resolve_stream(stream);
+  switch ((c.nz + 63) / 64) {
+    case 1: return launch_jn2018_steps<1>(a, dt, nsteps, st);
+    case 2: return launch_jn2018_steps<2>(a, dt, nsteps, st);
+    case 3: return launch_jn2018_steps<3>(a, dt, nsteps, st);
+    default: return launch_jn2018_steps<4>(a, dt, nsteps, st);
+  }
+}
+
 // ---------------------------------------------------------------------- RCCL
 int pm_comm_unique_id(void *id128) {
   PM_REQUIRE(id128, "id128 is NULL");

@@ -1,5 +1,5 @@
-// so_ml.hip.h -- K5: Southern-Ocean mixed-layer buoyancy step, and the per-step bottom-BC
-// switch of the Jansen & Nadeau driver.
+// so_ml.hip.h -- K5: Southern-Ocean mixed-layer buoyancy step; D1: the Jansen & Nadeau
+// driver's per-step bottom-BC switch; and the fused per-member JN2018 time loop.
 //
 // Arithmetic restated from the reference (nothing copied):
 //   SO_ML.set_boundary_conditions   src/pymoc/modules/SO_ML.py:77-98
@@ -7,12 +7,17 @@
 //   SO_ML.calc_implicit_diffusion   src/pymoc/modules/SO_ML.py:136-196
 //   SO_ML.advdiff / timestep        src/pymoc/modules/SO_ML.py:198-303
 //   bottom-BC / kappa switching     examples/run_JansenNadeau_2018.py:233-254
+//   time loop                       examples/run_JansenNadeau_2018.py:201-261
 //
 // One wavefront per member; the meridional profile (ny points) and the basin profiles
 // (nz levels) are staged in LDS.  The Crank-Nicolson solve U x = V bs is the Thomas
 // algorithm swept through LDS (the reference forms inv(U) densely with np.linalg.inv):
-// same forward / backward recurrences, in index order, as the oracle.
+// same forward / backward recurrences, in index order, as the oracle.  U has constant
+// coefficients, so the elimination factors cp[i] = c/den[i] and RN(1/den[i]) are tabulated
+// once per launch; the per-row quotient uses the correctly rounded div_by_recip, so the
+// sweep stays bit-identical to the oracle's plain divisions.
 #pragma once
+#include "column.hip.h"
 #include "common.hip.h"
 
 namespace pm {
@@ -30,51 +35,74 @@ __device__ __forceinline__ int wave_first_index(const double *s, int n, int lane
   return n;
 }
 
-__global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_so_ml_step(pm_so_ml a, double dt) {
-  extern __shared__ double lds_all[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int m_raw = blockIdx.x * (blockDim.x >> 6) + wave;
-  const bool m_ok = m_raw < a.n;
-  const int m = m_ok ? m_raw : a.n - 1;
-  const int nz = a.nz, ny = a.ny;
-  const int per_wave = 2 * nz + 5 * ny;
-  double *s_bb = lds_all + (size_t)wave * per_wave;  // [nz] b_basin
-  double *s_pm = s_bb + nz;                          // [nz] Psi_b -> Psi_mod
-  double *s_bs = s_pm + nz;                          // [ny]
-  double *s_ps = s_bs + ny;                          // [ny] Psi_s
-  double *s_rhs = s_ps + ny;                         // [ny]
-  double *s_cp = s_rhs + ny;                         // [ny]
-  double *s_dp = s_cp + ny;                          // [ny]
-  const size_t bz = (size_t)m * nz, by = (size_t)m * ny;
-
-  for (int i = lane; i < nz; i += 64) {
-    s_bb[i] = a.b_basin[bz + i];
-    s_pm[i] = a.Psi_b[bz + i];
+// LDS workspace of one member's mixed layer
+struct MlLds {
+  double *bb;    // [nz] b_basin
+  double *pm;    // [nz] Psi_b -> Psi_mod
+  double *bs;    // [ny]
+  double *ps;    // [ny] Psi_s
+  double *rhs;   // [ny]
+  double *dp;    // [ny]
+  double *cp;    // [ny] Thomas c'   (constant coefficients: tabulated once per launch)
+  double *den;   // [ny] Thomas denominators
+  double *rden;  // [ny] RN(1/den)
+  __device__ static int doubles(int nz, int ny) { return 2 * nz + 7 * ny; }
+  __device__ void carve(double *base, int nz, int ny) {
+    bb = base;
+    pm = bb + nz;
+    bs = pm + nz;
+    ps = bs + ny;
+    rhs = ps + ny;
+    dp = rhs + ny;
+    cp = dp + ny;
+    den = cp + ny;
+    rden = den + ny;
   }
-  for (int j = lane; j < ny; j += 64) s_bs[j] = a.bs[by + j];
-  __builtin_amdgcn_wave_barrier();
+};
 
-  // Psi_mod: fill below the first non-zero entry (SO_ML.py:228-230); first Psi_b > 0 (:95)
-  const int ind = wave_first_index(s_pm, nz, lane, [](double v) { return v != 0.; });
-  const int first_pos = wave_first_index(s_pm, nz, lane, [](double v) { return v > 0.; });
-  int status = 0;
-  if (ind >= nz) {  // IndexError in the reference: leave the state untouched
-    if (a.status && lane == 0 && m_ok) a.status[m] = 1;
-    return;
+// Psi_mod (SO_ML.py:228-230) in w.pm; returns the reference's IndexError condition.
+// ind = first non-zero of Psi_b, first_pos = first Psi_b > 0 (:95).
+__device__ __forceinline__ bool ml_prepare(const MlLds &w, int nz, int lane, int &first_pos) {
+  const int ind = wave_first_index(w.pm, nz, lane, [](double v) { return v != 0.; });
+  first_pos = wave_first_index(w.pm, nz, lane, [](double v) { return v > 0.; });
+  if (ind >= nz) return false;
+  const double fillv = w.pm[ind];
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < ind; i += 64) w.pm[i] = fillv;
+  __builtin_amdgcn_wave_barrier();
+  return true;
+}
+
+// Thomas factors of U = tridiag(-s/2, 1+s, -s/2) with identity boundary rows (:155-165)
+__device__ __forceinline__ void ml_tables(const MlLds &w, int ny, double s) {
+  const double ta = -s / 2., tb = 1 + s, tc = -s / 2.;
+  double cp = 0.;
+  w.cp[0] = 0.;
+  for (int i = 1; i < ny - 1; ++i) {
+    const double den = tb - ta * cp;
+    cp = tc / den;
+    w.cp[i] = cp;
+    w.den[i] = den;
+    w.rden[i] = 1.0 / den;
   }
-  const double fillv = s_pm[ind];
   __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < ind; i += 64) s_pm[i] = fillv;
-  __builtin_amdgcn_wave_barrier();
+}
 
+// One SO_ML.advdiff step on the member staged in `w` (bs, bb, pm valid; tables valid).
+// Returns false where the reference raises IndexError (state untouched).
+struct MlStatic {
+  const double *surflux, *rest_mask, *b_rest;  // this member's rows in global memory
+  double h, L, v_pist, dy, s;
+};
+__device__ __forceinline__ bool ml_step(const MlLds &w, const MlStatic &c, int nz, int ny,
+                                        int lane, int first_pos, double dt) {
   // Psi_s = np.interp(bs, b_basin, Psi_mod) (:232)
-  for (int j = lane; j < ny; j += 64) s_ps[j] = interp_sorted(s_bs[j], s_bb, s_pm, nz);
+  for (int j = lane; j < ny; j += 64) w.ps[j] = interp_sorted(w.bs[j], w.bb, w.pm, nz);
   // argmin(bs): first minimum, a NaN wins (np.argmin)
   double mn = __builtin_inf();
   int mi = 0x7fffffff;
   for (int j = lane; j < ny; j += 64) {
-    const double v = s_bs[j];
+    const double v = w.bs[j];
     if (v < mn) {
       mn = v;
       mi = j;
@@ -89,138 +117,330 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_so_ml_step(pm_so_ml
       mi = oi;
     }
   }
-  const int first_nan = wave_first_index(s_bs, ny, lane, [](double v) { return v != v; });
+  const int first_nan = wave_first_index(w.bs, ny, lane, [](double v) { return v != v; });
   const int amin = first_nan < ny ? first_nan : (mi < ny ? mi : 0);
   __builtin_amdgcn_wave_barrier();
   for (int j = lane; j < ny; j += 64)
-    if (j < amin || j == 0) s_ps[j] = 0.;  // :240-243
+    if (j < amin || j == 0) w.ps[j] = 0.;  // :240-243
   __builtin_amdgcn_wave_barrier();
 
-  const bool upwell = s_ps[1] > 0;  // set_boundary_conditions, :93-98
-  if (upwell && first_pos >= nz) {
-    if (a.status && lane == 0 && m_ok) a.status[m] = 1;  // IndexError in the reference
-    return;
-  }
-  const double bsouth = upwell ? s_bb[first_pos] : 0.;
+  const bool upwell = w.ps[1] > 0;  // set_boundary_conditions, :93-98
+  if (upwell && first_pos >= nz) return false;
+  const double bsouth = upwell ? w.bb[first_pos] : 0.;
   {
-    const double v = upwell ? bsouth : s_bs[1];
+    const double v = upwell ? bsouth : w.bs[1];
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) s_bs[0] = v;
+    if (lane == 0) w.bs[0] = v;
     __builtin_amdgcn_wave_barrier();
   }
-
   // tendencies from surface flux / restoring and upwind advection (:250-259)
-  const double dy = a.y[1] - a.y[0];
   for (int j = lane; j < ny; j += 64) {
-    const double bsj = s_bs[j];
-    const double flux = a.surflux[by + j] / a.h +
-                        a.rest_mask[by + j] * a.v_pist / a.h * (a.b_rest[by + j] - bsj);
+    const double bsj = w.bs[j];
+    const double flux =
+        c.surflux[j] / c.h + c.rest_mask[j] * c.v_pist / c.h * (c.b_rest[j] - bsj);
     double adv = 0.;
     if (j >= 1 && j <= ny - 2) {
-      const double ps = s_ps[j];
+      const double ps = w.ps[j];
       if (ps < 0.)
-        adv = -ps * 1e6 * (s_bs[j + 1] - bsj) / a.h / a.L / dy;
+        adv = -ps * 1e6 * (w.bs[j + 1] - bsj) / c.h / c.L / c.dy;
       else if (ps > 0.)
-        adv = -ps * 1e6 * (bsj - s_bs[j - 1]) / a.h / a.L / dy;
+        adv = -ps * 1e6 * (bsj - w.bs[j - 1]) / c.h / c.L / c.dy;
     }
-    s_rhs[j] = bsj + dt * (flux + adv);  // staged: every tendency uses the old bs
+    w.rhs[j] = bsj + dt * (flux + adv);  // staged: every tendency uses the old bs
   }
   __builtin_amdgcn_wave_barrier();
-  for (int j = lane; j < ny; j += 64) s_bs[j] = s_rhs[j];
+  for (int j = lane; j < ny; j += 64) w.bs[j] = w.rhs[j];
   __builtin_amdgcn_wave_barrier();
   if (!upwell) {  // no-flux BC re-set (:264-266)
-    const double v = s_bs[1];
+    const double v = w.bs[1];
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) s_bs[0] = v;
+    if (lane == 0) w.bs[0] = v;
     __builtin_amdgcn_wave_barrier();
   }
-
-  // Crank-Nicolson diffusion (:191-196): U x = V bs, U = tridiag(-s/2, 1+s, -s/2) with
-  // identity boundary rows
-  const double s = a.Ks * dt / (dy * dy);
+  // Crank-Nicolson diffusion (:191-196): U x = V bs
+  const double s = c.s;
   for (int j = lane; j < ny; j += 64) {
     double r;
     if (j == 0 || j == ny - 1)
-      r = s_bs[j];
+      r = w.bs[j];
     else
-      r = (s / 2.) * s_bs[j - 1] + (1 - s) * s_bs[j] + (s / 2.) * s_bs[j + 1];
-    s_rhs[j] = r;
+      r = (s / 2.) * w.bs[j - 1] + (1 - s) * w.bs[j] + (s / 2.) * w.bs[j + 1];
+    w.rhs[j] = r;
   }
   __builtin_amdgcn_wave_barrier();
   {
-    const double ta = -s / 2., tb = 1 + s, tc = -s / 2.;
-    double cp = 0., dp = s_rhs[0];
-    s_cp[0] = cp;
-    s_dp[0] = dp;
+    const double ta = -s / 2.;
+    double dp = w.rhs[0];
+    w.dp[0] = dp;
     for (int i = 1; i < ny - 1; ++i) {
-      const double den = tb - ta * cp;
-      cp = tc / den;
-      dp = (s_rhs[i] - ta * dp) / den;
-      s_cp[i] = cp;
-      s_dp[i] = dp;
+      dp = div_by_recip(w.rhs[i] - ta * dp, w.den[i], w.rden[i]);
+      w.dp[i] = dp;
     }
-    double x = s_rhs[ny - 1];
-    s_bs[ny - 1] = x;
+    double x = w.rhs[ny - 1];
+    w.bs[ny - 1] = x;
     for (int i = ny - 2; i >= 0; --i) {
-      x = s_dp[i] - s_cp[i] * x;
-      s_bs[i] = x;
+      x = w.dp[i] - w.cp[i] * x;
+      w.bs[i] = x;
     }
   }
   __builtin_amdgcn_wave_barrier();
   {
-    const double v = upwell ? bsouth : s_bs[1];  // final BC re-set (:274)
+    const double v = upwell ? bsouth : w.bs[1];  // final BC re-set (:274)
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) s_bs[0] = v;
+    if (lane == 0) w.bs[0] = v;
     __builtin_amdgcn_wave_barrier();
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_so_ml_step(pm_so_ml a, double dt) {
+  extern __shared__ double lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m_raw = blockIdx.x * (blockDim.x >> 6) + wave;
+  const bool m_ok = m_raw < a.n;
+  const int m = m_ok ? m_raw : a.n - 1;
+  const int nz = a.nz, ny = a.ny;
+  MlLds w;
+  w.carve(lds_all + (size_t)wave * MlLds::doubles(nz, ny), nz, ny);
+  const size_t bz = (size_t)m * nz, by = (size_t)m * ny;
+
+  for (int i = lane; i < nz; i += 64) {
+    w.bb[i] = a.b_basin[bz + i];
+    w.pm[i] = a.Psi_b[bz + i];
+  }
+  for (int j = lane; j < ny; j += 64) w.bs[j] = a.bs[by + j];
+  __builtin_amdgcn_wave_barrier();
+
+  int first_pos;
+  MlStatic c;
+  c.surflux = a.surflux + by;
+  c.rest_mask = a.rest_mask + by;
+  c.b_rest = a.b_rest + by;
+  c.h = a.h;
+  c.L = a.L;
+  c.v_pist = a.v_pist;
+  c.dy = a.y[1] - a.y[0];
+  c.s = a.Ks * dt / (c.dy * c.dy);  // :191
+  bool ok = ml_prepare(w, nz, lane, first_pos);
+  if (ok) {
+    ml_tables(w, ny, c.s);
+    ok = ml_step(w, c, nz, ny, lane, first_pos, dt);
+  }
+  if (!ok) {  // IndexError in the reference: leave the state untouched
+    if (a.status && lane == 0 && m_ok) a.status[m] = 1;
+    return;
   }
   bool bad = false;
   for (int j = lane; j < ny; j += 64) {
-    const double v = s_bs[j];
+    const double v = w.bs[j];
     bad |= !isfinite(v);
     if (m_ok) {
       a.bs[by + j] = v;
-      if (a.Psi_s) a.Psi_s[by + j] = s_ps[j];
+      if (a.Psi_s) a.Psi_s[by + j] = w.ps[j];
     }
   }
   if (a.status) {
-    status = (__ballot(bad) != 0ull) ? 2 : 0;
+    const int status = (__ballot(bad) != 0ull) ? 2 : 0;
     if (lane == 0 && m_ok) a.status[m] = status;
   }
 }
 
-// Bottom boundary condition / BBL diffusivity switching of run_JansenNadeau_2018.py:233-254,
-// one thread per member.  Columns are stored basin rows [0, n), north rows [n, 2n);
-// coefficient set 0 = kappa, set 1 = kappaeff.
+// Bottom boundary condition / BBL diffusivity switching of run_JansenNadeau_2018.py:233-254.
+// Columns are stored basin rows [0, n), north rows [n, 2n); coefficient set 0 = kappa,
+// set 1 = kappaeff.  Scalar form shared by the stand-alone kernel and the fused loop.
+struct BcState {
+  double bbot_b, bbot_n;
+  int ksel_b, ksel_n;
+};
+__device__ __forceinline__ void jn2018_bc(BcState &st, double PsiSO1, double Pb1, double Pn1,
+                                          double bb0, double bb1, double bn0, double bn1,
+                                          double bs0) {
+  if (PsiSO1 < 0) {  // bottom water coming in from the south
+    st.bbot_b = bs0;
+    st.ksel_b = 1;
+  }
+  if (Pb1 > 0 && bn0 < bb1 && bn0 < bs0) {  // bottom water coming in from the north
+    st.bbot_b = bn0;
+    st.ksel_b = 1;
+  } else if (PsiSO1 >= 0) {  // no bottom water coming in: no-flux BBC, full kappa
+    st.bbot_b = bb1;
+    st.ksel_b = 0;
+  }
+  if (Pn1 < 0 && bb0 < bn1) {  // bottom water coming in from the basin
+    st.bbot_n = bb0;
+    st.ksel_n = 1;
+  } else {
+    st.bbot_n = bn1;
+    st.ksel_n = 0;
+  }
+}
+
 __global__ void k_jn2018_bc_switch(pm_jn2018_bc a) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= a.n) return;
   const size_t bz = (size_t)m * a.nz;
-  const double PsiSO1 = a.Psi_SO[bz + 1], Pb1 = a.Psi_res_b[bz + 1], Pn1 = a.Psi_res_n[bz + 1];
-  const double bb0 = a.b_basin[bz], bb1 = a.b_basin[bz + 1];
-  const double bn0 = a.b_north[bz], bn1 = a.b_north[bz + 1];
-  const double bs0 = a.bs_SO[(size_t)m * a.ny];
-  if (PsiSO1 < 0) {  // bottom water coming in from the south
-    a.bbot[m] = bs0;
-    a.ksel[m] = 1;
-  }
-  if (Pb1 > 0 && bn0 < bb1 && bn0 < bs0) {  // bottom water coming in from the north
-    a.bbot[m] = bn0;
-    a.ksel[m] = 1;
-  } else if (PsiSO1 >= 0) {  // no bottom water coming in: no-flux BBC, full kappa
-    a.bbot[m] = bb1;
-    a.ksel[m] = 0;
-  }
-  if (Pn1 < 0 && bb0 < bn1) {  // bottom water coming in from the basin
-    a.bbot[a.n + m] = bb0;
-    a.ksel[a.n + m] = 1;
-  } else {
-    a.bbot[a.n + m] = bn1;
-    a.ksel[a.n + m] = 0;
+  BcState st;
+  st.bbot_b = a.bbot[m];
+  st.bbot_n = a.bbot[a.n + m];
+  st.ksel_b = a.ksel[m];
+  st.ksel_n = a.ksel[a.n + m];
+  jn2018_bc(st, a.Psi_SO[bz + 1], a.Psi_res_b[bz + 1], a.Psi_res_n[bz + 1], a.b_basin[bz],
+            a.b_basin[bz + 1], a.b_north[bz], a.b_north[bz + 1], a.bs_SO[(size_t)m * a.ny]);
+  a.bbot[m] = st.bbot_b;
+  a.bbot[a.n + m] = st.bbot_n;
+  a.ksel[m] = st.ksel_b;
+  a.ksel[a.n + m] = st.ksel_n;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused JN2018 time loop: nsteps x [BC switch -> basin.timestep -> north.timestep ->
+// channel.timestep] for one member per wavefront, wA / Psi_SO / Psibz held fixed (they only
+// change at MOC updates).  Both columns live in registers (lane l owns levels [l*P, l*P+P)),
+// the mixed layer in LDS; the scalars the BC switch needs are wave broadcasts -- no launch,
+// no host round trip inside a MOC block.  Same device functions as the stand-alone kernels,
+// so the result is bit-identical to stepping with pm_jn2018_bc_switch + pm_column_steps +
+// pm_so_ml_step.
+template <int P>
+__device__ __forceinline__ void col_load_coef(ColRegs<P> &r, const pm_columns &c, int col,
+                                              int sel, int lg) {
+  const int nz = c.nz;
+  const size_t sbase = ((size_t)sel * c.ncols + col) * nz;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lg * P + p;
+    const int ic = i < nz ? i : nz - 1;
+    r.kap[p] = c.kappa[sbase + ic];
+    r.dAk[p] = c.dAkappa[sbase + ic];
   }
 }
 
+template <int P>
+__global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_jn2018_steps(pm_jn2018 a,
+                                                                          double dt,
+                                                                          int nsteps) {
+  extern __shared__ double lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m_raw = blockIdx.x * (blockDim.x >> 6) + wave;
+  const bool m_ok = m_raw < a.n;
+  const int m = m_ok ? m_raw : a.n - 1;
+  const int n = a.n, nz = a.cols.nz, ny = a.ml.ny;
+  const pm_columns &c = a.cols;
+  MlLds w;
+  w.carve(lds_all + (size_t)wave * MlLds::doubles(nz, ny), nz, ny);
+  const size_t bz = (size_t)m * nz, by = (size_t)m * ny;
+  const int colb = m, coln = n + m;
+
+  BcState st;
+  st.bbot_b = c.bbot[colb];
+  st.bbot_n = c.bbot[coln];
+  st.ksel_b = c.ksel[colb];
+  st.ksel_n = c.ksel[coln];
+  ColRegs<P> rb, rn;
+  col_load_static<P>(rb, c, colb, st.ksel_b, lane);
+  col_load_static<P>(rn, c, coln, st.ksel_n, lane);
+  double wAb[P], wAn[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    const int ic = i < nz ? i : nz - 1;
+    rb.b[p] = c.b[(size_t)colb * nz + ic];
+    rn.b[p] = c.b[(size_t)coln * nz + ic];
+    wAb[p] = a.wA[(size_t)colb * nz + ic];
+    wAn[p] = a.wA[(size_t)coln * nz + ic];
+  }
+  const double bs_b = c.bs[colb], bs_n = c.bs[coln];
+  const double N2_b = c.N2min[colb], N2_n = c.N2min[coln];
+  const double PsiSO1 = a.Psi_SO[bz + 1], Pb1 = a.Psi_res_b[bz + 1], Pn1 = a.Psi_res_n[bz + 1];
+
+  for (int i = lane; i < nz; i += 64) w.pm[i] = a.Psi_SO[bz + i];
+  for (int j = lane; j < ny; j += 64) w.bs[j] = a.ml.bs[by + j];
+  __builtin_amdgcn_wave_barrier();
+  MlStatic mc;
+  mc.surflux = a.ml.surflux + by;
+  mc.rest_mask = a.ml.rest_mask + by;
+  mc.b_rest = a.ml.b_rest + by;
+  mc.h = a.ml.h;
+  mc.L = a.ml.L;
+  mc.v_pist = a.ml.v_pist;
+  mc.dy = a.ml.y[1] - a.ml.y[0];
+  mc.s = a.ml.Ks * dt / (mc.dy * mc.dy);
+  int first_pos;
+  bool ml_ok = ml_prepare(w, nz, lane, first_pos);
+  if (ml_ok) ml_tables(w, ny, mc.s);
+  int status = ml_ok ? 0 : 1;
+
+  // lanes / slots holding levels 0 and 1 of a column
+  constexpr int L1 = 1 / P, S1 = 1 % P;
+  for (int s = 0; s < nsteps; ++s) {
+    // ---- bottom-BC switch (run_JansenNadeau_2018.py:233-254)
+    const double bb0 = __shfl(rb.b[0], 0, 64), bb1 = __shfl(rb.b[S1], L1, 64);
+    const double bn0 = __shfl(rn.b[0], 0, 64), bn1 = __shfl(rn.b[S1], L1, 64);
+    const int kb = st.ksel_b, kn = st.ksel_n;
+    jn2018_bc(st, PsiSO1, Pb1, Pn1, bb0, bb1, bn0, bn1, w.bs[0]);
+    if (st.ksel_b != kb) col_load_coef<P>(rb, c, colb, st.ksel_b, lane);
+    if (st.ksel_n != kn) col_load_coef<P>(rn, c, coln, st.ksel_n, lane);
+    // ---- basin.timestep / north.timestep, do_conv=True (:257-258)
+    col_convect<64, P>(rb.b, rb.z, bs_b, N2_b, lane, lane, nz, c.z);
+    col_vertadvdiff<64, P, true>(rb, wAb, dt, true, bs_b, st.bbot_b, false, 0., lane, nz);
+    col_convect<64, P>(rn.b, rn.z, bs_n, N2_n, lane, lane, nz, c.z);
+    col_vertadvdiff<64, P, true>(rn, wAn, dt, true, bs_n, st.bbot_n, false, 0., lane, nz);
+    // ---- channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi) (:261)
+    if (ml_ok) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = lane * P + p;
+        if (i < nz) w.bb[i] = rb.b[p];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (!ml_step(w, mc, nz, ny, lane, first_pos, dt)) {
+        ml_ok = false;  // IndexError in the reference; the mixed layer stops evolving
+        status = 1;
+      }
+    }
+  }
+
+  bool bad = false;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    if (i < nz) {
+      if (m_ok) {
+        c.b[(size_t)colb * nz + i] = rb.b[p];
+        c.b[(size_t)coln * nz + i] = rn.b[p];
+      }
+      bad |= !isfinite(rb.b[p]) || !isfinite(rn.b[p]);
+    }
+  }
+  for (int j = lane; j < ny; j += 64) {
+    const double v = w.bs[j];
+    bad |= !isfinite(v);
+    if (m_ok) {
+      a.ml.bs[by + j] = v;
+      if (a.ml.Psi_s) a.ml.Psi_s[by + j] = w.ps[j];
+    }
+  }
+  const bool anybad = __ballot(bad) != 0ull;
+  if (lane == 0 && m_ok) {
+    const_cast<double *>(c.bbot)[colb] = st.bbot_b;
+    const_cast<double *>(c.bbot)[coln] = st.bbot_n;
+    const_cast<int32_t *>(c.ksel)[colb] = st.ksel_b;
+    const_cast<int32_t *>(c.ksel)[coln] = st.ksel_n;
+    if (c.nonfinite) {
+      c.nonfinite[colb] = anybad ? 1 : 0;
+      c.nonfinite[coln] = anybad ? 1 : 0;
+    }
+    if (a.ml.status) a.ml.status[m] = status | (anybad ? 2 : 0);
+  }
+}
+
+inline size_t ml_lds_bytes(int nz, int ny) {
+  return (size_t)(2 * nz + 7 * ny) * sizeof(double);
+}
+
 inline int launch_so_ml(const pm_so_ml &a, double dt, hipStream_t st) {
-  const size_t per_wave = (size_t)(2 * a.nz + 5 * a.ny) * sizeof(double);
+  const size_t per_wave = ml_lds_bytes(a.nz, a.ny);
   int wpb = ML_WAVES_PER_BLOCK;
   while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
   const size_t lds = per_wave * wpb;
@@ -230,6 +450,22 @@ inline int launch_so_ml(const pm_so_ml &a, double dt, hipStream_t st) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = (unsigned)((a.n + wpb - 1) / wpb);
   hipLaunchKernelGGL(k_so_ml_step, dim3(grid), dim3(64 * wpb), lds, st, a, dt);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
+template <int P>
+int launch_jn2018_steps(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st) {
+  const size_t per_wave = ml_lds_bytes(a.cols.nz, a.ml.ny);
+  int wpb = ML_WAVES_PER_BLOCK;
+  while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
+  const size_t lds = per_wave * wpb;
+  if (lds > 160 * 1024) return fail(PM_EINVAL, "jn2018 needs %zu B of LDS per member", lds);
+  if (lds > 64 * 1024)
+    PM_HIP(hipFuncSetAttribute((const void *)k_jn2018_steps<P>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const unsigned grid = (unsigned)((a.n + wpb - 1) / wpb);
+  hipLaunchKernelGGL((k_jn2018_steps<P>), dim3(grid), dim3(64 * wpb), lds, st, a, dt, nsteps);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }

@@ -91,35 +91,69 @@ __device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
   return r;
 }
 
+// mask_k * u_k of one cell for TW_JT classes: clip((top - bg)/(top - bot), 0, 1) * u
+// (psi_thermwind.py:183).  Regular cells (finite, non-zero thickness; yk = RN(1/d), else
+// NaN) take the correctly-rounded reciprocal division and a max/min clamp; degenerate cells
+// (zero thickness -> +-inf / NaN, hazard H6) take IEEE division and NumPy's NaN-propagating
+// clip.  The branch is wave-uniform (cell data is broadcast from LDS).
+__device__ __forceinline__ void psib_cell_terms(double t, double d, double yk, double uk,
+                                                const double (&bg)[TW_JT],
+                                                double (&out)[TW_JT]) {
+  if (yk == yk) {
+    double tt[TW_JT], q[TW_JT], rr[TW_JT];
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) tt[j] = t - bg[j];
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) q[j] = tt[j] * yk;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) rr[j] = __builtin_fma(-d, q[j], tt[j]);
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) q[j] = __builtin_fma(rr[j], yk, q[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j)
+      out[j] = __builtin_fmin(__builtin_fmax(q[j], 0.), 1.) * uk;
+  } else {
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) out[j] = np_clip01((t - bg[j]) / d) * uk;
+  }
+}
+
 // One isopycnal class: sum_k clip((top_k - bg)/(top_k - bot_k), 0, 1) * u_k over cells
-// [k0, k0+n) in NumPy's pairwise order, for TW_JT classes at once.
-__device__ __forceinline__ void psib_block_sum(const double *top, const double *bot, const double *u,
-                               int k0, int n, const double (&bg)[TW_JT],
-                               double (&res)[TW_JT]) {
+// [k0, k0+n) in NumPy's pairwise order, for TW_JT classes at once.  Cell arrays in LDS:
+// top, d = top - bot, y = RN(1/d) or NaN, u.
+__device__ __forceinline__ void psib_block_sum(const double *top, const double *dd,
+                                               const double *yy, const double *u, int k0,
+                                               int n, const double (&bg)[TW_JT],
+                                               double (&res)[TW_JT]) {
+  double term[TW_JT];
   if (n < 8) {
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) res[j] = 0.;
     for (int k = k0; k < k0 + n; ++k) {
-      const double t = top[k], d = t - bot[k], uk = u[k];
+      psib_cell_terms(top[k], dd[k], yy[k], u[k], bg, term);
 #pragma unroll
-      for (int j = 0; j < TW_JT; ++j) res[j] += np_clip01((t - bg[j]) / d) * uk;
+      for (int j = 0; j < TW_JT; ++j) res[j] += term[j];
     }
     return;
   }
   double r[8][TW_JT];
 #pragma unroll
   for (int a = 0; a < 8; ++a) {
-    const double t = top[k0 + a], d = t - bot[k0 + a], uk = u[k0 + a];
+    psib_cell_terms(top[k0 + a], dd[k0 + a], yy[k0 + a], u[k0 + a], bg, term);
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) r[a][j] = np_clip01((t - bg[j]) / d) * uk;
+    for (int j = 0; j < TW_JT; ++j) r[a][j] = term[j];
   }
   const int nfull = n - (n % 8);
   for (int k = 8; k < nfull; k += 8) {
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-      const double t = top[k0 + k + a], d = t - bot[k0 + k + a], uk = u[k0 + k + a];
+      const int kk = k0 + k + a;
+      psib_cell_terms(top[kk], dd[kk], yy[kk], u[kk], bg, term);
 #pragma unroll
-      for (int j = 0; j < TW_JT; ++j) r[a][j] += np_clip01((t - bg[j]) / d) * uk;
+      for (int j = 0; j < TW_JT; ++j) r[a][j] += term[j];
     }
   }
 #pragma unroll
@@ -127,40 +161,40 @@ __device__ __forceinline__ void psib_block_sum(const double *top, const double *
     res[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) +
              ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
   for (int k = nfull; k < n; ++k) {
-    const double t = top[k0 + k], d = t - bot[k0 + k], uk = u[k0 + k];
+    psib_cell_terms(top[k0 + k], dd[k0 + k], yy[k0 + k], u[k0 + k], bg, term);
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) res[j] += np_clip01((t - bg[j]) / d) * uk;
+    for (int j = 0; j < TW_JT; ++j) res[j] += term[j];
   }
 }
 
 // out-of-line copy for the recursive (nz > 129) path: 16 inlined copies per kernel cost
 // minutes of compile time and every register
-__device__ __noinline__ void psib_block_sum_call(const double *top, const double *bot,
-                                                 const double *u, int k0, int n,
-                                                 const double (&bg)[TW_JT],
+__device__ __noinline__ void psib_block_sum_call(const double *top, const double *dd,
+                                                 const double *yy, const double *u, int k0,
+                                                 int n, const double (&bg)[TW_JT],
                                                  double (&res)[TW_JT]) {
-  psib_block_sum(top, bot, u, k0, n, bg, res);
+  psib_block_sum(top, dd, yy, u, k0, n, bg, res);
 }
 
 // np.add.reduce pairwise recursion (blocks of <= 128, left half rounded down to a
 // multiple of 8).  D bounds the recursion depth: D=4 covers n <= 128*16.
 template <int D>
-__device__ __forceinline__ void psib_pairwise(const double *top, const double *bot,
-                                              const double *u, int k0, int n,
-                                              const double (&bg)[TW_JT],
+__device__ __forceinline__ void psib_pairwise(const double *top, const double *dd,
+                                              const double *yy, const double *u, int k0,
+                                              int n, const double (&bg)[TW_JT],
                                               double (&res)[TW_JT]) {
   if constexpr (D == 0) {
-    psib_block_sum_call(top, bot, u, k0, n, bg, res);
+    psib_block_sum_call(top, dd, yy, u, k0, n, bg, res);
   } else {
     if (n <= 128) {
-      psib_block_sum_call(top, bot, u, k0, n, bg, res);
+      psib_block_sum_call(top, dd, yy, u, k0, n, bg, res);
       return;
     }
     int n2 = n / 2;
     n2 -= n2 % 8;
     double l[TW_JT], r[TW_JT];
-    psib_pairwise<D - 1>(top, bot, u, k0, n2, bg, l);
-    psib_pairwise<D - 1>(top, bot, u, k0 + n2, n - n2, bg, r);
+    psib_pairwise<D - 1>(top, dd, yy, u, k0, n2, bg, l);
+    psib_pairwise<D - 1>(top, dd, yy, u, k0 + n2, n - n2, bg, r);
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) res[j] = l[j] + r[j];
   }
@@ -202,11 +236,12 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
   const bool m_ok = m_raw < a.n;
   const int m = m_ok ? m_raw : a.n - 1;
   const int nz = a.nz, nb = a.nb;
-  const int per_wave = 3 * nz + nb;
+  const int per_wave = 4 * nz + nb;
   double *s_a = lds_all + (size_t)wave * per_wave;  // [nz]  increments / top
-  double *s_b = s_a + nz;                           // [nz]  bot
+  double *s_b = s_a + nz;                           // [nz]  d = top - bot
   double *s_c = s_b + nz;                           // [nz]  u
-  double *s_psib = s_c + nz;                        // [nb]
+  double *s_y = s_c + nz;                           // [nz]  RN(1/d), NaN for degenerate cells
+  double *s_psib = s_y + nz;                        // [nb]
   const size_t base = (size_t)m * nz;
 
   double z[P], zu[P], b1[P], b2[P], b1u[P], b2u[P], Psi[P];
@@ -304,6 +339,7 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
   Linspace lin;
   lin.init(mn, mx, nb);
 
+  const bool range_ok = __builtin_fabs(mn) < 1e100 && __builtin_fabs(mx) < 1e100;
   const double Psi_up0 = from_next_lane(Psi[0]);
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -312,9 +348,14 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
       const double Pu = (p < P - 1) ? Psi[p + 1 < P ? p + 1 : p] : Psi_up0;
       const double u = -(Pu - Psi[p]);  // :175
       const bool north = u < 0;         // :179-181
-      s_a[k] = north ? b2u[p] : b1u[p];  // top
-      s_b[k] = north ? b2[p] : b1[p];    // bot
+      const double top = north ? b2u[p] : b1u[p];
+      const double bot = north ? b2[p] : b1[p];
+      const double d = top - bot, ad = __builtin_fabs(d);
+      const bool regular = range_ok && ad >= 1e-290 && ad <= 1e290 && __builtin_fabs(top) < 1e100;
+      s_a[k] = top;
+      s_b[k] = d;
       s_c[k] = u;
+      s_y[k] = regular ? 1.0 / d : __builtin_nan("");
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -327,9 +368,9 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
       bg[j] = lin.at(i < nb ? i : nb - 1);
     }
     if constexpr (BIG)
-      psib_pairwise<4>(s_a, s_b, s_c, 0, nc, bg, res);
+      psib_pairwise<4>(s_a, s_b, s_y, s_c, 0, nc, bg, res);
     else
-      psib_block_sum(s_a, s_b, s_c, 0, nc, bg, res);  // nc <= 128: one pairwise block
+      psib_block_sum(s_a, s_b, s_y, s_c, 0, nc, bg, res);  // nc <= 128: one pairwise block
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) {
       const int i = i0 + j * 64 + lane;
@@ -363,7 +404,7 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
 
 template <int P, bool BIG>
 int launch_thermwind_impl(const pm_thermwind &a, int ops, hipStream_t st) {
-  const size_t per_wave = (size_t)(3 * a.nz + a.nb) * sizeof(double);
+  const size_t per_wave = (size_t)(4 * a.nz + a.nb) * sizeof(double);
   int wpb = TW_WAVES_PER_BLOCK;
   while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
   const size_t lds = per_wave * wpb;

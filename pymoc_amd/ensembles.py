@@ -161,7 +161,7 @@ class JN2018Ensemble(object):
   MOC_up_iters steps (before the step) the three diagnostics are refreshed.  With
   `use_graph` a whole MOC block is captured once into a hipGraph and replayed."""
 
-  def __init__(self, cfg, stream=None, lanes_per_col=0, use_graph=False):
+  def __init__(self, cfg, stream=None, lanes_per_col=0, use_graph=False, fused=None):
     import ctypes as C
     from ._lib import pm_jn2018_bc
     z, y = cfg['z'], cfg['y']
@@ -202,6 +202,8 @@ class JN2018Ensemble(object):
     self.ii = 0
     self._graph = None
     self._use_graph = use_graph
+    # fused: one launch per MOC block for the whole [BC switch, 2 columns, mixed layer] loop
+    self._fused = (nz <= 256) if fused is None else bool(fused)
 
   def _update(self):
     b_basin, b_north = self.cols.b.ptr, self.cols.b.ptr + self._off
@@ -221,9 +223,34 @@ class JN2018Ensemble(object):
     for _ in range(self.M):
       self._step()
 
+  def _fused_steps(self, nsteps):
+    from ._lib import check, lib, pm_jn2018, pm_so_ml
+    from .device import _sh
+    d = pm_jn2018()
+    d.n = self.n
+    d.cols = self.cols.descriptor()
+    d.wA, d.Psi_SO = self.wA.ptr, self.so.Psi.ptr
+    d.Psi_res_b, d.Psi_res_n = self.tw.psibz1.ptr, self.tw.psibz2.ptr
+    ml, t = pm_so_ml(), self.ml
+    ml.n, ml.nz, ml.ny, ml.reserved = t.n, t.nz, t.ny, 0
+    ml.y, ml.bs, ml.Psi_s = t.y.ptr, t.bs.ptr, t.Psi_s.ptr
+    ml.b_basin, ml.Psi_b = None, None
+    ml.surflux, ml.rest_mask, ml.b_rest = t.surflux.ptr, t.rest_mask.ptr, t.b_rest.ptr
+    ml.Ks, ml.h, ml.L, ml.v_pist = t.Ks, t.h, t.L, t.v_pist
+    ml.status = t.status.ptr
+    d.ml = ml
+    check(lib.pm_jn2018_steps(self._C.byref(d), self.dt, int(nsteps), _sh(self.stream)))
+
   def run(self, nsteps):
     from .device import Graph
     remaining = int(nsteps)
+    while remaining > 0 and self._fused:
+      if self.ii % self.M == 0:
+        self._update()
+      n = min(self.M - self.ii % self.M, remaining)
+      self._fused_steps(n)
+      self.ii += n
+      remaining -= n
     while remaining > 0:
       if self._use_graph and self.ii % self.M == 0 and remaining >= self.M:
         if self._graph is None:

@@ -90,20 +90,23 @@ def test_so_ml_wrapper_api(gpu):
   assert str(e.value) == 'y needs to be numpy array providing (regular) grid'
 
 
-@pytest.mark.parametrize("name,nz,dtd,steps,use_graph", [
-    ("jn2018_nz81", 81, 30., (1, 12, 13, 14, 240, 1200), False),
-    ("jn2018_nz200", 200, 10., (1, 36, 37, 38, 360, 1200), True),
+@pytest.mark.parametrize("name,nz,dtd,steps,use_graph,fused", [
+    ("jn2018_nz81", 81, 30., (1, 12, 13, 14, 240, 1200), False, False),
+    ("jn2018_nz200", 200, 10., (1, 36, 37, 38, 360, 1200), True, False),
+    ("jn2018_nz81", 81, 30., (1, 12, 13, 14, 240, 1200), False, True),
+    ("jn2018_nz200", 200, 10., (1, 36, 37, 38, 360, 1200), False, True),
 ])
-def test_jn2018_trajectory_golden(gpu, name, nz, dtd, steps, use_graph):
+def test_jn2018_trajectory_golden(gpu, name, nz, dtd, steps, use_graph, fused):
   """run_JansenNadeau_2018 physics against the reference's snapshots (1e-10: ys by direct
-  inversion instead of brentq) -- eager launches and hipGraph replay of whole MOC blocks."""
+  inversion instead of brentq) -- eager launches, hipGraph replay of whole MOC blocks, and
+  the fused one-launch-per-block kernel."""
   g = load_golden(name)
   m = configs.jn2018_member(nz=nz, dt_days=dtd)
   cfg = dict(m)
   for k in ("b_basin0", "b_north0", "bs_SO0", "surflux", "b_rest"):
     cfg[k] = m[k][None]
   cfg["rest_mask"] = m["rest_mask"][None]
-  ens = gpu.JN2018Ensemble(cfg, use_graph=use_graph)
+  ens = gpu.JN2018Ensemble(cfg, use_graph=use_graph, fused=fused)
   done = 0
   for s in steps:
     ens.run(s - done)
@@ -113,11 +116,28 @@ def test_jn2018_trajectory_golden(gpu, name, nz, dtd, steps, use_graph):
       assert relerr(st[k][0], g["s%05d_%s" % (s, k)]) <= 1e-10, (s, k)
 
 
-def test_config5_sweep_members_vs_reference(gpu):
+def test_jn2018_fused_equals_stepwise_bitwise(gpu):
+  """The fused per-block kernel against bc_switch + column_steps + so_ml_step launches."""
+  c = configs.config5(N=256)
+  c["rest_mask"] = np.repeat(c["rest_mask"][None], 256, axis=0)
+  a = gpu.JN2018Ensemble(c, fused=True)
+  b = gpu.JN2018Ensemble(c, fused=False)
+  for n in (1, 35, 36, 37, 200):
+    a.run(n)
+    b.run(n)
+    sa, sb = a.state(), b.state()
+    for k in sa:
+      assert np.array_equal(sa[k], sb[k], equal_nan=True), (n, k)
+  assert np.array_equal(a.cols.bbot.download(), b.cols.bbot.download(), equal_nan=True)
+  assert np.array_equal(a.cols.ksel.download(), b.cols.ksel.download())
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_config5_sweep_members_vs_reference(gpu, fused):
   g = load_golden("sweep")
   c = configs.config5(N=4096)
   c["rest_mask"] = np.repeat(c["rest_mask"][None], 4096, axis=0)
-  ens = gpu.JN2018Ensemble(c, use_graph=True)
+  ens = gpu.JN2018Ensemble(c, use_graph=not fused, fused=fused)
   n, nl = int(g["c5_nsteps"]), int(g["c5_long_nsteps"])
   ens.run(n)
   st = ens.state()
