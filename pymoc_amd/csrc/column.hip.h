@@ -71,13 +71,15 @@ __device__ __forceinline__ void col_convect(double (&b)[P], const double (&z)[P]
 
 // Column.vertadvdiff (column.py:210-249), one explicit step.  FAST: the three divisions by
 // static denominators go through div_by_recip (correctly rounded, so still bit-identical).
-template <int G, int P, bool FAST>
+// BC = false: the caller has already imposed the (constant) boundary values, which no
+// interior update ever touches -- valid when bzbot is None and the surface value is bs.
+template <int G, int P, bool FAST, bool BC = true>
 __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA)[P],
                                                 double dt, bool do_conv, double bs,
                                                 double bbot, bool use_bzbot,
                                                 double bzbot, int lg, int nz) {
   // surface boundary condition (column.py:230-231)
-  if (!do_conv) {
+  if (BC && !do_conv) {
 #pragma unroll
     for (int p = 0; p < P; ++p)
       if (lg * P + p == nz - 1) r.b[p] = bs;
@@ -88,7 +90,7 @@ __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA
 #pragma unroll
   for (int p = 0; p < P; ++p) bup[p] = (p < P - 1) ? r.b[p + 1 < P ? p + 1 : p] : nb0;
   // bottom boundary condition (column.py:232-233); level 0 = lane 0, slot 0
-  if (lg == 0) r.b[0] = use_bzbot ? (bup[0] - bzbot * r.dz[0]) : bbot;
+  if (BC && lg == 0) r.b[0] = use_bzbot ? (bup[0] - bzbot * r.dz[0]) : bbot;
 
   // Every stage below is written across the P slots so that the in-order wave always has
   // P independent dependency chains in flight (one wave per SIMD is latency-bound).
@@ -112,8 +114,14 @@ __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA
 #pragma unroll
       for (int p = 0; p < P; ++p) q[p] = num[p] / r.dz[p];
     }
+    if constexpr (FAST) {
+      // rdz is 0 above the top level, so q is already 0 there (num*0, +0 corrections)
 #pragma unroll
-    for (int p = 0; p < P; ++p) bz[p] = (lg * P + p < nz - 1) ? q[p] : 0.0;
+      for (int p = 0; p < P; ++p) bz[p] = q[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < P; ++p) bz[p] = (lg * P + p < nz - 1) ? q[p] : 0.0;
+    }
   }
   const double pbz = from_prev_lane(bz[P - 1]);
   double bz_dn[P], dbz[P], flx[P], bzz[P], adv[P];
@@ -199,13 +207,15 @@ __device__ __forceinline__ void col_load_static(ColRegs<P> &r, const pm_columns 
     r.kap[p] = c.kappa[sbase + ic];
     r.dAk[p] = c.dAkappa[sbase + ic];
     r.area[p] = c.area[base + ic];
-    r.rdz[p] = 1.0 / r.dz[p];
+    r.rdz[p] = (i < nz - 1) ? 1.0 / r.dz[p] : 0.0;  // 0: bz above the top level is 0
     r.rdzc[p] = 1.0 / r.dzc[p];
     r.rarea[p] = 1.0 / r.area[p];
   }
 }
 
-template <int G, int P, bool FAST>
+// PLAIN: ops == PM_OP_TIMESTEP without horadv inputs -- the time loop then carries no
+// loop-invariant branches (they cost a lone wave ~15% of a step).
+template <int G, int P, bool FAST, bool PLAIN>
 __global__ __launch_bounds__(256) void k_column_steps(
     pm_columns c, const double *__restrict__ wA_g, const double *__restrict__ vdx_g,
     const double *__restrict__ bin_g, double dt, int nsteps, int ops) {
@@ -239,12 +249,33 @@ __global__ __launch_bounds__(256) void k_column_steps(
   const double bzbot = use_bzbot ? c.bzbot[col] : 0.0;
   const double N2min = c.N2min[col];
 
-  for (int s = 0; s < nsteps; ++s) {
-    if ((ops & PM_OP_CONVECT) && do_conv)
-      col_convect<G, P>(r.b, r.z, bs, N2min, lg, lane, nz, c.z);
-    if (ops & PM_OP_VERTADVDIFF)
-      col_vertadvdiff<G, P, FAST>(r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lg, nz);
-    if ((ops & PM_OP_HORADV) && vdx_g) col_horadv<P>(r, vdx, bin, dt, lg, nz);
+  if constexpr (PLAIN) {
+    if (do_conv) {
+      for (int s = 0; s < nsteps; ++s) {
+        col_convect<G, P>(r.b, r.z, bs, N2min, lg, lane, nz, c.z);
+        col_vertadvdiff<G, P, FAST>(r, wA, dt, true, bs, bbot, use_bzbot, bzbot, lg, nz);
+      }
+    } else if (use_bzbot) {
+      for (int s = 0; s < nsteps; ++s)
+        col_vertadvdiff<G, P, FAST>(r, wA, dt, false, bs, bbot, true, bzbot, lg, nz);
+    } else {
+      // constant boundary values: impose them once, then run the BC-free step
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (lg * P + p == nz - 1) r.b[p] = bs;
+        if (lg * P + p == 0) r.b[p] = bbot;
+      }
+      for (int s = 0; s < nsteps; ++s)
+        col_vertadvdiff<G, P, FAST, false>(r, wA, dt, false, bs, bbot, false, 0., lg, nz);
+    }
+  } else {
+    for (int s = 0; s < nsteps; ++s) {
+      if ((ops & PM_OP_CONVECT) && do_conv)
+        col_convect<G, P>(r.b, r.z, bs, N2min, lg, lane, nz, c.z);
+      if (ops & PM_OP_VERTADVDIFF)
+        col_vertadvdiff<G, P, FAST>(r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lg, nz);
+      if ((ops & PM_OP_HORADV) && vdx_g) col_horadv<P>(r, vdx, bin, dt, lg, nz);
+    }
   }
 
   bool bad = false;
@@ -286,12 +317,15 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
   const int cols_per_block = 256 / G;
   const unsigned grid = (unsigned)((c.ncols + cols_per_block - 1) / cols_per_block);
   // the reciprocal path pays 3 true divisions per level up front: worth it from 3 steps on
-  if (nsteps >= 3)
-    hipLaunchKernelGGL((k_column_steps<G, P, true>), dim3(grid), dim3(256), 0, st, c, wA, vdx,
-                       bin, dt, nsteps, ops);
+  if (nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx)
+    hipLaunchKernelGGL((k_column_steps<G, P, true, true>), dim3(grid), dim3(256), 0, st, c, wA,
+                       vdx, bin, dt, nsteps, ops);
+  else if (nsteps >= 3)
+    hipLaunchKernelGGL((k_column_steps<G, P, true, false>), dim3(grid), dim3(256), 0, st, c, wA,
+                       vdx, bin, dt, nsteps, ops);
   else
-    hipLaunchKernelGGL((k_column_steps<G, P, false>), dim3(grid), dim3(256), 0, st, c, wA, vdx,
-                       bin, dt, nsteps, ops);
+    hipLaunchKernelGGL((k_column_steps<G, P, false, false>), dim3(grid), dim3(256), 0, st, c,
+                       wA, vdx, bin, dt, nsteps, ops);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
