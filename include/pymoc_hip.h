@@ -255,6 +255,16 @@ typedef struct pm_jn2018 {
 
 int pm_jn2018_steps(const pm_jn2018 *jn, double dt, int32_t nsteps, pm_stream_t stream);
 
+/* Column forcing of the two-basin driver, examples/twobasin_NadeauJansen.py:103-105:
+ *   wA_Atl = (Psi_iso_Atl + Psi_zonal_Atl - SO_Atl.Psi)*1e6
+ *   wAN    = -Psi_iso_N*1e6
+ *   wA_Pac = (-Psi_zonal_Pac - SO_Pac.Psi)*1e6          all arrays [n][nz]            */
+int pm_twobasin_forcing(int32_t n, int32_t nz, const double *Psi_iso_Atl,
+                        const double *Psi_zonal_Atl, const double *SO_Atl,
+                        const double *Psi_iso_N, const double *Psi_zonal_Pac,
+                        const double *SO_Pac, double *wA_Atl, double *wAN, double *wA_Pac,
+                        pm_stream_t stream);
+
 /* ------------------------------------------------------------------ RCCL
  * One process per GPU.  The ensemble is sharded by member, stepping needs no
  * communication; the only exchange is the gather of per-member output at diagnostic

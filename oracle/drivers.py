@@ -110,3 +110,40 @@ def run_jn2018(m, nsteps, snaps, dense_inverse=False):
     _snap(out, ii + 1, snaps, b_basin=bb, b_north=bn, bs_SO=bsSO, Psi=Psi, Psi_SO=PsiSO,
           Psi_iso_b=pib, Psi_iso_n=pin, Psi_s=Psi_s)
   return out
+
+
+def run_twobasin(m, nsteps, snaps):
+  """examples/twobasin_NadeauJansen.py:99-122: three columns, AMOC + zonal thermal-wind
+  overturnings, one SO overturning per sector.  m: `configs.twobasin_member` dict."""
+  z, y = m['z'], m['y']
+  kap = m['kappa']
+  A = {k: m['A_' + k] + 0 * z for k in ('Atl', 'north', 'Pac')}
+  bA, bN, bP = m['b_Atl0'].copy(), m['b_north0'].copy(), m['b_Pac0'].copy()
+  nb, dt, M = m['nb'], m['dt'], m['MOC_up_iters']
+  so = dict(f=m['f_SO'], KGM=m['K'])
+  Psi_A = thermwind_solve(z, bA, m['b2_init'], m['f_AMOC'])
+  _, _, iso_A, iso_N = thermwind_psibz(bA, m['b2_init'], Psi_A, nb)
+  Psi_Z = thermwind_solve(z, bA, bP, m['f_ZOC'])
+  _, _, zon_A, zon_P = thermwind_psibz(bA, bP, Psi_Z, nb)
+  SO_A = psi_so_solve(z, y, bA, m['bs_SO'], m['tau'], L=m['L_Atl'], **so)[0]
+  SO_P = psi_so_solve(z, y, bP, m['bs_SO'], m['tau'], L=m['L_Pac'], **so)[0]
+  out = {}
+  snaps = set(snaps)
+  kw = dict(bbot=m['bbot'], N2min=m['N2min'])
+  for ii in range(nsteps):
+    wA_Atl = (iso_A + zon_A - SO_A) * 1e6
+    wAN = -iso_N * 1e6
+    wA_Pac = (-zon_P - SO_P) * 1e6
+    bA = column_timestep(z, kap, A['Atl'], bA, wA_Atl, dt, bs=m['bs'], **kw)
+    bN = column_timestep(z, kap, A['north'], bN, wAN, dt, do_conv=True, bs=m['bs_north'], **kw)
+    bP = column_timestep(z, kap, A['Pac'], bP, wA_Pac, dt, bs=m['bs'], **kw)
+    if ii % M == 0:
+      Psi_A = thermwind_solve(z, bA, bN, m['f_AMOC'])
+      _, _, iso_A, iso_N = thermwind_psibz(bA, bN, Psi_A, nb)
+      Psi_Z = thermwind_solve(z, bA, bP, m['f_ZOC'])
+      _, _, zon_A, zon_P = thermwind_psibz(bA, bP, Psi_Z, nb)
+      SO_A = psi_so_solve(z, y, bA, m['bs_SO'], m['tau'], L=m['L_Atl'], **so)[0]
+      SO_P = psi_so_solve(z, y, bP, m['bs_SO'], m['tau'], L=m['L_Pac'], **so)[0]
+    _snap(out, ii + 1, snaps, b_Atl=bA, b_north=bN, b_Pac=bP, Psi_AMOC=Psi_A, Psi_ZOC=Psi_Z,
+          Psi_SO_Atl=SO_A, Psi_SO_Pac=SO_P)
+  return out

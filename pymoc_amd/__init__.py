@@ -16,4 +16,5 @@ from . import utils
 from .modules import Column, Psi_Thermwind, Psi_SO, SO_ML
 from . import configs
 from . import sharding
-from .ensembles import ColumnThermwindEnsemble, TwoColEnsemble, JN2018Ensemble
+from .ensembles import (ColumnThermwindEnsemble, TwoColEnsemble, JN2018Ensemble,
+                        TwoBasinEnsemble)

@@ -136,6 +136,7 @@ SIGNATURES = {
     "pm_so_ml_step": (C.c_int, [C.POINTER(pm_so_ml), C.c_double, C.c_void_p]),
     "pm_jn2018_bc_switch": (C.c_int, [C.POINTER(pm_jn2018_bc), C.c_void_p]),
     "pm_jn2018_steps": (C.c_int, [C.POINTER(pm_jn2018), C.c_double, C.c_int32, C.c_void_p]),
+    "pm_twobasin_forcing": (C.c_int, [C.c_int32, C.c_int32] + [c_dp] * 9 + [C.c_void_p]),
     "pm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pm_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "pm_comm_destroy": (C.c_int, [C.c_void_p]),

@@ -206,3 +206,45 @@ def config5(N=4096, nz=200, ny=51, dt_days=10., seed=20243, members=None):
     out[key] = np.stack([m[key] for m in mem]) if mem else np.zeros((0,))
   out.update(nsteps=3600, members=idx, scalars=dict(db=db[sl], B=B[sl]))
   return out
+
+
+def twobasin_kappaeff(z):
+  """Effective diffusivity of examples/twobasin_NadeauJansen.py:36-38."""
+  return 1.0 * (1e-4 * (1.1 - np.tanh(np.maximum(z + 2000., 0) / 1000. +
+                                      np.minimum(z + 2000., 0) / 1300.)) *
+                (1. - np.maximum(-4000. - z + 600., 0.) / 600.)**2)
+
+
+def twobasin_member(nz=80, ny=51, tau=0.16, K=1800., A_Atl=7e13, A_north=5.5e12, A_Pac=1.7e14):
+  """One `examples/twobasin_NadeauJansen.py` member (physics of :21-97): Atlantic, northern
+  sinking region and Pacific columns, AMOC and zonal thermal-wind overturnings, one SO
+  overturning per basin sector.  Array initial profiles (SURVEY hazard H7)."""
+  bs, bs_north, bAABW = 0.02, 0.00036, -0.0011
+  bbot = min(bAABW, bs_north)
+  y = np.asarray(np.linspace(0, 3.e6, ny))
+  offset = 0.0345 * (1 - np.cos(np.pi * (5.55e5 - 1.e5) / 8e6))
+  bs_SO = (0.0345 * (1 - np.cos(np.pi * (y - 1.e5) / 8e6)) * (y > 5.55e5) +
+           (bAABW - offset) / 5.55e5 * np.maximum(0, 5.55e5 - y) + offset * (y < 5.55e5))
+  Lx = 1.3e+07
+  z = np.asarray(np.linspace(-4000, 0, nz))
+  b_Atl = bs * np.exp(z / 300.) + z / z[0] * bbot
+  return dict(z=z, y=y, kappa=twobasin_kappaeff(z), A_Atl=A_Atl, A_north=A_north,
+              A_Pac=A_Pac, bs=bs, bs_north=bs_north, bbot=bbot, N2min=2e-7, tau=tau, K=K,
+              L_Atl=6. / 21. * Lx, L_Pac=15. / 21. * Lx, f_AMOC=1.2e-4, f_ZOC=1e-4,
+              f_SO=1.2e-4, bs_SO=bs_SO, b_Atl0=b_Atl, b_north0=b_Atl.copy(),
+              b_Pac0=b_Atl.copy(), b2_init=0.01 * b_Atl, dt=DAY * 30., MOC_up_iters=24, nb=500)
+
+
+def config_twobasin(N=2048, nz=80, ny=51, seed=20244, members=None):
+  """N two-basin members; sweep tau, K, A_Pac."""
+  rng = np.random.default_rng(seed)
+  tau = rng.uniform(0.1, 0.2, N)
+  K = rng.uniform(1200., 2400., N)
+  A_Pac = _logu(rng, 1.2e14, 2.2e14, N)
+  sl = _slice(members, N)
+  idx = np.arange(N)[sl]
+  n = idx.size
+  out = twobasin_member(nz=nz, ny=ny)
+  out.update(tau=tau[sl], K=K[sl], A_Pac=A_Pac[sl], A_Atl=np.full(n, out['A_Atl']),
+             A_north=np.full(n, out['A_north']), nsteps=2400, members=idx)
+  return out

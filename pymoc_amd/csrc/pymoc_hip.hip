@@ -87,6 +87,21 @@ __global__ void k_selftest_fastdiv(unsigned long long seed, int per_thread, int 
   if (bad) atomicAdd(mismatch, bad);
 }
 
+__global__ void k_twobasin_forcing(size_t count, const double *__restrict__ iso_A,
+                                   const double *__restrict__ zon_A,
+                                   const double *__restrict__ so_A,
+                                   const double *__restrict__ iso_N,
+                                   const double *__restrict__ zon_P,
+                                   const double *__restrict__ so_P, double *__restrict__ wA_A,
+                                   double *__restrict__ wA_N, double *__restrict__ wA_P) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count;
+       i += (size_t)gridDim.x * blockDim.x) {
+    wA_A[i] = (iso_A[i] + zon_A[i] - so_A[i]) * 1e6;  // twobasin_NadeauJansen.py:103
+    wA_N[i] = (-iso_N[i]) * 1e6;                       // :104
+    wA_P[i] = (-zon_P[i] - so_P[i]) * 1e6;             // :105
+  }
+}
+
 }  // namespace pm
 
 using namespace pm;
@@ -342,6 +357,25 @@ int pm_jn2018_steps(const pm_jn2018 *jn, double dt, int32_t nsteps, pm_stream_t 
     case 3: return launch_jn2018_steps<3>(a, dt, nsteps, st);
     default: return launch_jn2018_steps<4>(a, dt, nsteps, st);
   }
+}
+
+int pm_twobasin_forcing(int32_t n, int32_t nz, const double *Psi_iso_Atl,
+                        const double *Psi_zonal_Atl, const double *SO_Atl,
+                        const double *Psi_iso_N, const double *Psi_zonal_Pac,
+                        const double *SO_Pac, double *wA_Atl, double *wAN, double *wA_Pac,
+                        pm_stream_t stream) {
+  PM_REQUIRE(n >= 0 && nz >= 1, "bad shape n=%d nz=%d", n, nz);
+  PM_REQUIRE(Psi_iso_Atl && Psi_zonal_Atl && SO_Atl && Psi_iso_N && Psi_zonal_Pac && SO_Pac &&
+                 wA_Atl && wAN && wA_Pac,
+             "NULL pointer");
+  const size_t count = (size_t)n * nz;
+  if (count == 0) return PM_OK;
+  const unsigned grid = (unsigned)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_twobasin_forcing, dim3(grid), dim3(256), 0, resolve_stream(stream),
+                     count, Psi_iso_Atl, Psi_zonal_Atl, SO_Atl, Psi_iso_N, Psi_zonal_Pac,
+                     SO_Pac, wA_Atl, wAN, wA_Pac);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
 }
 
 // ---------------------------------------------------------------------- RCCL

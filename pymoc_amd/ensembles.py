@@ -4,6 +4,7 @@ whole parameter-sweep ensemble with all state resident in HBM.
 The reference has no driver class: the loops live in examples/*.py.  The
 classes here reproduce those loops' order of operations and cadence exactly:
   JN2018Ensemble           examples/run_JansenNadeau_2018.py:201-261 (config 5)
+  TwoBasinEnsemble         examples/twobasin_NadeauJansen.py:99-122
   ColumnThermwindEnsemble  examples/example_timestepping.py:73-80   (BASELINE config 1)
   TwoColEnsemble           examples/example_twocol.py:85-96         (config 3)
                            examples/example_twocol_plusSO.py:99-115 (config 4, with_so)
@@ -277,3 +278,79 @@ class JN2018Ensemble(object):
   def nonfinite_members(self):
     nf = self.cols.get_nonfinite()
     return np.nonzero(nf[:self.n] | nf[self.n:])[0]
+
+
+class TwoBasinEnsemble(object):
+  """twobasin_NadeauJansen.py: Atlantic, northern-sinking and Pacific columns; AMOC
+  (Atl vs north) and zonal (Atl vs Pac) thermal-wind overturnings mapped to isopycnal space;
+  one Southern-Ocean overturning per basin sector.  Columns are stored Atl rows [0,n),
+  north rows [n,2n), Pac rows [2n,3n)."""
+
+  def __init__(self, cfg, stream=None, lanes_per_col=0):
+    z, y = cfg['z'], cfg['y']
+    nz, ny = z.size, y.size
+    n = np.size(cfg['tau']) if np.ndim(cfg['tau']) else 1
+    self.n, self.nz = n, nz
+    self.dt, self.M, self.nb = float(cfg['dt']), int(cfg['MOC_up_iters']), int(cfg['nb'])
+    self.lanes, self.stream = lanes_per_col, stream
+    kap = _rows(cfg['kappa'], n, nz)
+    rows = lambda v: _rows(v, n, nz)  # noqa: E731
+    self.cols = ColumnBatch(
+        z, np.concatenate([kap, kap, kap]),
+        np.concatenate([rows(cfg['A_Atl']), rows(cfg['A_north']), rows(cfg['A_Pac'])]),
+        np.concatenate([rows(cfg['b_Atl0']), rows(cfg['b_north0']), rows(cfg['b_Pac0'])]),
+        bs=np.concatenate([_vec(cfg['bs'], n), _vec(cfg['bs_north'], n), _vec(cfg['bs'], n)]),
+        bbot=np.full(3 * n, float(cfg['bbot'])), N2min=float(cfg['N2min']),
+        do_conv=np.concatenate([np.zeros(n, bool), np.ones(n, bool), np.zeros(n, bool)]),
+        stream=stream)
+    zd = self.cols.z
+    self.amoc = ThermwindBatch(z, n, f=cfg['f_AMOC'], nb=self.nb, stream=stream, z_dev=zd)
+    self.zoc = ThermwindBatch(z, n, f=cfg['f_ZOC'], nb=self.nb, stream=stream, z_dev=zd)
+    so = dict(tau=cfg['tau'], KGM=cfg['K'], f=cfg['f_SO'], stream=stream, z_dev=zd)
+    self.so_atl = PsiSOBatch(z, y, n, L=cfg['L_Atl'], **so)
+    self.so_pac = PsiSOBatch(z, y, n, L=cfg['L_Pac'], **so)
+    self.bs_SO = DeviceArray.from_host(_rows(cfg['bs_SO'], n, ny) if np.ndim(cfg['bs_SO']) == 1
+                                       else cfg['bs_SO'])
+    self.wA = DeviceArray.zeros((3 * n, nz))
+    self._off = n * nz * 8
+    self.ii = 0
+    # initial diagnostics (:58-79): AMOC against b2 = 0.01*b_Atl, the rest on the initial columns
+    b2 = DeviceArray.from_host(rows(cfg['b2_init']))
+    self._update(b_north=b2.ptr)
+
+  def _update(self, b_north=None):
+    from ._lib import check, lib
+    from .device import _sh
+    bA = self.cols.b.ptr
+    bN = self.cols.b.ptr + self._off if b_north is None else b_north
+    bP = self.cols.b.ptr + 2 * self._off
+    self.amoc.update(bA, bN, ops=_TW_ALL)
+    self.zoc.update(bA, bP, ops=_TW_ALL)
+    self.so_atl.update(bA, self.bs_SO)
+    self.so_pac.update(bP, self.bs_SO)
+    w = self.wA.ptr
+    check(lib.pm_twobasin_forcing(self.n, self.nz, self.amoc.psibz1.ptr, self.zoc.psibz1.ptr,
+                                  self.so_atl.Psi.ptr, self.amoc.psibz2.ptr,
+                                  self.zoc.psibz2.ptr, self.so_pac.Psi.ptr, w, w + self._off,
+                                  w + 2 * self._off, _sh(self.stream)))
+
+  def run(self, nsteps):
+    remaining = int(nsteps)
+    while remaining > 0:
+      nxt = self.ii if self.ii % self.M == 0 else (self.ii // self.M + 1) * self.M
+      n = min(nxt - self.ii + 1, remaining)
+      self.cols.steps(self.wA, self.dt, n, lanes_per_col=self.lanes)
+      self.ii += n
+      remaining -= n
+      if (self.ii - 1) % self.M == 0:
+        self._update()
+
+  def state(self):
+    b, n = self.cols.get_b(), self.n
+    return dict(b_Atl=b[:n], b_north=b[n:2 * n], b_Pac=b[2 * n:], Psi_AMOC=self.amoc.Psi.download(),
+                Psi_ZOC=self.zoc.Psi.download(), Psi_SO_Atl=self.so_atl.Psi.download(),
+                Psi_SO_Pac=self.so_pac.Psi.download())
+
+  def nonfinite_members(self):
+    nf, n = self.cols.get_nonfinite(), self.n
+    return np.nonzero(nf[:n] | nf[n:2 * n] | nf[2 * n:])[0]

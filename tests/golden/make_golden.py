@@ -21,6 +21,7 @@ Sets:
   G7 so_ml, jn2018     SO_ML.timestep I/O; run_JansenNadeau_2018 physics at
                        nz=81/dt=30d and nz=200/dt=10d, steps {1,12,13,...}
   G8 sweep             members of the config-2/3/4/5 ensembles run through the reference
+  G9 twobasin          twobasin_NadeauJansen physics (3 columns, 2 thermal winds, 2 SO sectors)
 """
 import os
 import sys
@@ -432,11 +433,77 @@ def g8_sweep():
   save("sweep", **out)
 
 
+# ------------------------------------------------------------------- G9 two-basin
+def ref_twobasin(m, nsteps, snaps):
+  """examples/twobasin_NadeauJansen.py physics, array profiles."""
+  z, y = m['z'], m['y']
+  kap = m['kappa']
+  AMOC = Psi_Thermwind(z=z, b1=m['b_Atl0'].copy(), b2=m['b2_init'].copy(), f=m['f_AMOC'])
+  AMOC.solve()
+  [Psi_iso_Atl, Psi_iso_N] = AMOC.Psibz()
+  ZOC = Psi_Thermwind(z=z, b1=m['b_Atl0'].copy(), b2=m['b_Pac0'].copy(), f=m['f_ZOC'])
+  ZOC.solve()
+  [Psi_zonal_Atl, Psi_zonal_Pac] = ZOC.Psibz()
+  SO_Atl = Psi_SO(z=z, y=y, b=m['b_Atl0'].copy(), bs=m['bs_SO'].copy(), tau=float(m['tau']),
+                  L=m['L_Atl'], KGM=float(m['K']))
+  SO_Atl.solve()
+  SO_Pac = Psi_SO(z=z, y=y, b=m['b_Pac0'].copy(), bs=m['bs_SO'].copy(), tau=float(m['tau']),
+                  L=m['L_Pac'], KGM=float(m['K']))
+  SO_Pac.solve()
+  mk = lambda b, bs, A, : Column(z=z, kappa=kap.copy(), b=b.copy(), bs=bs, bbot=m['bbot'],  # noqa
+                                 Area=float(A), N2min=m['N2min'])
+  Atl = mk(m['b_Atl0'], m['bs'], m['A_Atl'])
+  north = mk(m['b_north0'], m['bs_north'], m['A_north'])
+  Pac = mk(m['b_Pac0'], m['bs'], m['A_Pac'])
+  out = {}
+  for ii in range(nsteps):
+    wA_Atl = (Psi_iso_Atl + Psi_zonal_Atl - SO_Atl.Psi) * 1e6
+    wAN = -Psi_iso_N * 1e6
+    wA_Pac = (-Psi_zonal_Pac - SO_Pac.Psi) * 1e6
+    Atl.timestep(wA=wA_Atl, dt=m['dt'])
+    north.timestep(wA=wAN, dt=m['dt'], do_conv=True)
+    Pac.timestep(wA=wA_Pac, dt=m['dt'])
+    if ii % m['MOC_up_iters'] == 0:
+      AMOC.update(b1=Atl.b, b2=north.b)
+      AMOC.solve()
+      [Psi_iso_Atl, Psi_iso_N] = AMOC.Psibz()
+      ZOC.update(b1=Atl.b, b2=Pac.b)
+      ZOC.solve()
+      [Psi_zonal_Atl, Psi_zonal_Pac] = ZOC.Psibz()
+      SO_Atl.update(b=Atl.b)
+      SO_Atl.solve()
+      SO_Pac.update(b=Pac.b)
+      SO_Pac.solve()
+    if ii + 1 in snaps:
+      out[ii + 1] = dict(b_Atl=Atl.b.copy(), b_north=north.b.copy(), b_Pac=Pac.b.copy(),
+                         Psi_AMOC=AMOC.Psi.copy(), Psi_ZOC=ZOC.Psi.copy(),
+                         Psi_SO_Atl=SO_Atl.Psi.copy(), Psi_SO_Pac=SO_Pac.Psi.copy())
+  return out
+
+
+def g9_twobasin():
+  m = configs.twobasin_member(nz=80)
+  out = pack("", ref_twobasin(m, 1200, {1, 24, 25, 26, 1200}))
+  c = configs.config_twobasin(N=2048)
+  pick = np.arange(0, 2048, 256)
+  keys = ('b_Atl', 'b_north', 'b_Pac', 'Psi_AMOC', 'Psi_ZOC', 'Psi_SO_Atl')
+  acc = {k: [] for k in keys}
+  for i in pick:
+    mm = member_of(c, i, ('tau', 'K', 'A_Pac', 'A_Atl', 'A_north'))
+    s = ref_twobasin(mm, 121, {121})[121]
+    for k in keys:
+      acc[k].append(s[k])
+  out.update(sweep_members=pick, sweep_nsteps=np.array(121))
+  for k in keys:
+    out["sweep_" + k] = np.array(acc[k])
+  save("twobasin", **out)
+
+
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
   table = dict(g1=[g1_column_steps], g2=[g2_config1], g3=[g3_thermwind], g4=[g4_twocol],
                g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
-               g8=[g8_sweep])
+               g8=[g8_sweep], g9=[g9_twobasin])
   for w in which:
     for fn in table[w]:
       fn()

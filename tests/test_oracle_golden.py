@@ -277,3 +277,17 @@ def test_sweep_config5_members():
       if i in long_members:
         jl = long_members.index(i)
         assert relerr(s[nl][k], g["c5_long_" + k][jl]) <= 1e-10, (i, k)
+
+
+def test_twobasin_trajectory_golden():
+  """twobasin_NadeauJansen physics, 1200 steps + 8 sweep members."""
+  g = load_golden("twobasin")
+  out = drivers.run_twobasin(configs.twobasin_member(nz=80), 1200, {1, 24, 25, 26, 1200})
+  _check_snaps(out, g, ("b_Atl", "b_north", "b_Pac", "Psi_AMOC", "Psi_ZOC", "Psi_SO_Atl",
+                        "Psi_SO_Pac"), TOL_TRAJ)
+  c = configs.config_twobasin(N=2048)
+  n = int(g["sweep_nsteps"])
+  for j, i in enumerate(g["sweep_members"]):
+    s = drivers.run_twobasin(_member(c, i, ("tau", "K", "A_Pac", "A_Atl", "A_north")), n, {n})[n]
+    for k in ("b_Atl", "b_north", "b_Pac", "Psi_AMOC", "Psi_ZOC", "Psi_SO_Atl"):
+      assert relerr(s[k], g["sweep_" + k][j]) <= TOL_TRAJ, (i, k)
