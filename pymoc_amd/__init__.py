@@ -18,3 +18,4 @@ from . import configs
 from . import sharding
 from .ensembles import (ColumnThermwindEnsemble, TwoColEnsemble, JN2018Ensemble,
                         TwoBasinEnsemble)
+from . import diagnostics

@@ -205,6 +205,7 @@ class JN2018Ensemble(object):
     self._use_graph = use_graph
     # fused: one launch per MOC block for the whole [BC switch, 2 columns, mixed layer] loop
     self._fused = (nz <= 256) if fused is None else bool(fused)
+    self.recorder = None  # optional diagnostics.JN2018Diagnostics
 
   def _update(self):
     b_basin, b_north = self.cols.b.ptr, self.cols.b.ptr + self._off
@@ -248,12 +249,15 @@ class JN2018Ensemble(object):
     while remaining > 0 and self._fused:
       if self.ii % self.M == 0:
         self._update()
+        if self.recorder is not None:
+          self.recorder.maybe_record(self.ii)
       n = min(self.M - self.ii % self.M, remaining)
       self._fused_steps(n)
       self.ii += n
       remaining -= n
     while remaining > 0:
-      if self._use_graph and self.ii % self.M == 0 and remaining >= self.M:
+      if (self._use_graph and self.recorder is None and self.ii % self.M == 0 and
+          remaining >= self.M):
         if self._graph is None:
           with Graph.capture(self.stream) as cap:
             self._block()
@@ -264,6 +268,8 @@ class JN2018Ensemble(object):
         continue
       if self.ii % self.M == 0:
         self._update()
+        if self.recorder is not None:
+          self.recorder.maybe_record(self.ii)
       self._step()
       self.ii += 1
       remaining -= 1

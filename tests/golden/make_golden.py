@@ -22,6 +22,8 @@ Sets:
                        nz=81/dt=30d and nz=200/dt=10d, steps {1,12,13,...}
   G8 sweep             members of the config-2/3/4/5 ensembles run through the reference
   G9 twobasin          twobasin_NadeauJansen physics (3 columns, 2 thermal winds, 2 SO sectors)
+  G10 jn2018_files     the diagnostics / pickup .npz payloads of run_JansenNadeau_2018.py and a
+                       restart from the pickup
 """
 import os
 import sys
@@ -433,6 +435,83 @@ def g8_sweep():
   save("sweep", **out)
 
 
+# ------------------------------------------------- G10 diagnostics + pickup wire format
+def g10_jn2018_files():
+  """What `run_JansenNadeau_2018.py --diagfile d.npz --pickup_save_file p.npz` writes
+  (:192-226, :266-272) for total_iters=480, Diag_iters=120 at nz=81: the positional arrays
+  of both files, plus the state 240 steps after restarting from that pickup."""
+  m = configs.jn2018_member(nz=81, dt_days=30.)
+  total, Diag = 480, 120
+  z, y, nb = m['z'], m['y'], m['nb']
+  nd = total // Diag
+  sv = dict(AMOC=np.zeros((len(z), nd)), AMOC_b=np.zeros((nb, nd)), bgrid=np.zeros((nb, nd)),
+            b_basin=np.zeros((len(z), nd)), b_north=np.zeros((len(z), nd)),
+            bs_SO=np.zeros((len(y), nd)), Psi_SO=np.zeros((len(z), nd)))
+
+  def run(b_basin, b_north, bs_SO, nsteps, record):
+    kappa, kappaeff = configs.jn2018_kappa, configs.jn2018_kappaeff
+    AMOC = Psi_Thermwind(z=z, b1=b_basin, b2=b_north, f=m['f'])
+    AMOC.solve()
+    PsiSO = Psi_SO(z=z, y=y, b=b_basin, bs=bs_SO, tau=float(m['tau']), f=m['f'], L=m['L'],
+                   KGM=float(m['KGM']))
+    PsiSO.solve()
+    bs_SO[-1] = m['bs']
+    basin = Column(z=z, kappa=kappaeff, Area=m['A_basin'], b=b_basin, bs=float(m['bs']),
+                   bbot=b_basin[0])
+    north = Column(z=z, kappa=kappaeff, Area=m['A_north'], b=b_north,
+                   bs=float(m['bs_north']), bbot=b_north[0])
+    channel = SO_ML(y=y, h=m['h'], L=m['L'], Ks=m['Ks'], surflux=m['surflux'],
+                    rest_mask=m['rest_mask'], b_rest=m['b_rest'], v_pist=m['v_pist'],
+                    bs=bs_SO)
+    for ii in range(nsteps):
+      if ii % m['MOC_up_iters'] == 0:
+        AMOC.update(b1=basin.b, b2=north.b)
+        AMOC.solve()
+        [Psi_res_b, Psi_res_n] = AMOC.Psibz(nb=nb)
+        PsiSO.update(b=basin.b, bs=channel.bs)
+        PsiSO.solve()
+        if record and ii % Diag == 0:
+          k = ii // Diag
+          sv['AMOC'][:, k] = AMOC.Psi
+          sv['AMOC_b'][:, k] = AMOC.Psib(nb=nb)
+          sv['bgrid'][:, k] = AMOC.bgrid
+          sv['b_basin'][:, k] = basin.b
+          sv['b_north'][:, k] = north.b
+          sv['bs_SO'][:, k] = channel.bs
+          sv['Psi_SO'][:, k] = PsiSO.Psi
+      wAb = (Psi_res_b - PsiSO.Psi) * 1e6
+      wAN = -Psi_res_n * 1e6
+      if PsiSO.Psi[1] < 0:
+        basin.bbot = channel.bs[0]
+        basin.kappa = kappaeff
+      if Psi_res_b[1] > 0 and north.b[0] < basin.b[1] and north.b[0] < channel.bs[0]:
+        basin.bbot = north.b[0]
+        basin.kappa = kappaeff
+      elif PsiSO.Psi[1] >= 0:
+        basin.bbot = basin.b[1]
+        basin.kappa = kappa
+      if Psi_res_n[1] < 0 and basin.b[0] < north.b[1]:
+        north.bbot = basin.b[0]
+        north.kappa = kappaeff
+      else:
+        north.bbot = north.b[1]
+        north.kappa = kappa
+      basin.timestep(wA=wAb, dt=m['dt'], do_conv=True)
+      north.timestep(wA=wAN, dt=m['dt'], do_conv=True)
+      channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi, dt=m['dt'])
+    return basin.b.copy(), north.b.copy(), channel.bs.copy()
+
+  p0, p1, p2 = run(m['b_basin0'].copy(), m['b_north0'].copy(), m['bs_SO_init'].copy(), total,
+                   True)
+  # restart exactly like the script's --pickup path (:135-138)
+  r0, r1, r2 = run(1.0 * p0, 1.0 * p1, 1.0 * p2, 240, False)
+  save("jn2018_files", diag_0=sv['AMOC'], diag_1=sv['AMOC_b'], diag_2=sv['b_basin'],
+       diag_3=sv['b_north'], diag_4=sv['bs_SO'], diag_5=z, diag_6=sv['bgrid'], diag_7=y,
+       diag_8=sv['Psi_SO'], diag_9=np.array(m['tau']), diag_10=np.array(m['KGM']),
+       pickup_0=p0, pickup_1=p1, pickup_2=p2, restart_0=r0, restart_1=r1, restart_2=r2,
+       total_iters=np.array(total), Diag_iters=np.array(Diag))
+
+
 # ------------------------------------------------------------------- G9 two-basin
 def ref_twobasin(m, nsteps, snaps):
   """examples/twobasin_NadeauJansen.py physics, array profiles."""
@@ -500,10 +579,10 @@ def g9_twobasin():
 
 
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
   table = dict(g1=[g1_column_steps], g2=[g2_config1], g3=[g3_thermwind], g4=[g4_twocol],
                g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
-               g8=[g8_sweep], g9=[g9_twobasin])
+               g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files])
   for w in which:
     for fn in table[w]:
       fn()

@@ -1,0 +1,59 @@
+"""diagnostics and pickup files in the reference's wire format."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+from pymoc_amd import configs, diagnostics
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg():
+  m = configs.jn2018_member(nz=81, dt_days=30.)
+  cfg = dict(m)
+  for k in ("b_basin0", "b_north0", "bs_SO0", "surflux", "b_rest", "rest_mask"):
+    cfg[k] = m[k][None]
+  return m, cfg
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_diagfile_and_pickup_match_the_reference_script(gpu, tmp_path, fused):
+  g = load_golden("jn2018_files")
+  total, Diag = int(g["total_iters"]), int(g["Diag_iters"])
+  m, cfg = _cfg()
+  ens = gpu.JN2018Ensemble(cfg, fused=fused)
+  ens.recorder = diagnostics.JN2018Diagnostics(ens, Diag, total)
+  ens.run(total)
+  dfile, pfile = str(tmp_path / "diags.npz"), str(tmp_path / "pickup.npz")
+  ens.recorder.save_member(dfile, 0, m["tau"], m["KGM"])
+  diagnostics.save_pickup(ens, pfile, member=0)
+  d = np.load(dfile)
+  assert sorted(d.files) == ["arr_%d" % i for i in range(11)] or len(d.files) == 11
+  for i in range(11):
+    ref = g["diag_%d" % i]
+    got = d["arr_%d" % i]
+    assert got.shape == ref.shape, i
+    assert relerr(got, ref) <= 1e-10 or np.abs(ref).max() == 0, i
+  p = np.load(pfile)
+  for i in range(3):
+    assert relerr(p["arr_%d" % i], g["pickup_%d" % i]) <= 1e-10, i
+  # restart from the pickup exactly like `--pickup` and run 240 more steps
+  ens2 = gpu.JN2018Ensemble(diagnostics.load_pickup(cfg, pfile), fused=fused)
+  ens2.run(240)
+  st = ens2.state()
+  for i, k in enumerate(("b_basin", "b_north", "bs_SO")):
+    assert relerr(st[k][0], g["restart_%d" % i]) <= 1e-10, k
+
+
+def test_ensemble_pickup_roundtrip(gpu, tmp_path):
+  c = configs.config5(N=64, nz=81, dt_days=30.)
+  c["rest_mask"] = np.repeat(c["rest_mask"][None], 64, axis=0)
+  a = gpu.JN2018Ensemble(c)
+  a.run(36)
+  f = str(tmp_path / "p.npz")
+  diagnostics.save_pickup(a, f)
+  p = np.load(f)
+  st = a.state()
+  assert np.array_equal(p["arr_0"], st["b_basin"]) and np.array_equal(p["arr_2"], st["bs_SO"])
+  b = gpu.JN2018Ensemble(diagnostics.load_pickup(c, f))
+  assert np.array_equal(b.state()["b_north"], st["b_north"])
