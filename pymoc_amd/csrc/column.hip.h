@@ -30,8 +30,9 @@ struct ColRegs {
 };
 
 // Column.convect (column.py:251-271).  `zg` is the shared grid in global memory.
+// Returns true when some level convected (rare), false when only b[-1] = bs was imposed.
 template <int G, int P>
-__device__ __forceinline__ void col_convect(double (&b)[P], const double (&z)[P],
+__device__ __forceinline__ bool col_convect(double (&b)[P], const double (&z)[P],
                                             double bs, double N2min, int lg, int lane,
                                             int nz, const double *__restrict__ zg) {
   const unsigned long long gm = group_mask<G>(lane);
@@ -43,30 +44,45 @@ __device__ __forceinline__ void col_convect(double (&b)[P], const double (&z)[P]
     ind[p] = (i < nz) && (b[p] > bs);  // column.py:264
     any_l |= ind[p];
   }
-  const unsigned long long anym = __ballot(any_l) & gm;
-  if (anym != 0ull) {
+  const unsigned long long anym = __builtin_amdgcn_ballot_w64(any_l) & gm;
+  if (__builtin_expect(anym != 0ull, 0)) {
     // zconv = max(z[~ind]) (column.py:267): z ascends, so it is z at the highest
     // non-convecting level; bottom of the ocean if every level convects.
     int jmax = 0;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = lg * P + p;
-      const unsigned long long m = __ballot((i < nz) && !ind[p]) & gm;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64((i < nz) && !ind[p]) & gm;
       if (m != 0ull) {
         const int hl = 63 - __clzll((long long)m);
         const int j = (hl % G) * P + p;
         jmax = j > jmax ? j : jmax;
       }
     }
-    const double zconv = zg[jmax];
+    double zconv;
+    if constexpr (G == 64) {
+      // the wave owns the whole column: fetch z[jmax] from the owning lane's registers
+      // (two v_readlane) instead of a scalar memory load in the middle of the time loop
+      const int jl = __builtin_amdgcn_readfirstlane(jmax / P);
+      const int jp = __builtin_amdgcn_readfirstlane(jmax % P);
+      double zsel = z[0];
+#pragma unroll
+      for (int p = 1; p < P; ++p) zsel = (jp == p) ? z[p] : zsel;
+      const int lo = __builtin_amdgcn_readlane(__double2loint(zsel), jl);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(zsel), jl);
+      zconv = __hiloint2double(hi, lo);
+    } else {
+      zconv = zg[jmax];
+    }
 #pragma unroll
     for (int p = 0; p < P; ++p)
       if (ind[p]) b[p] = bs + N2min * (z[p] - zconv);  // column.py:268
-  } else {
-#pragma unroll
-    for (int p = 0; p < P; ++p)
-      if (lg * P + p == nz - 1) b[p] = bs;  // column.py:271
+    return true;
   }
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+    if (lg * P + p == nz - 1) b[p] = bs;  // column.py:271
+  return false;
 }
 
 // Column.vertadvdiff (column.py:210-249), one explicit step.  FAST: the three divisions by
@@ -77,12 +93,14 @@ template <int G, int P, bool FAST, bool BC = true>
 __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA)[P],
                                                 double dt, bool do_conv, double bs,
                                                 double bbot, bool use_bzbot,
-                                                double bzbot, int lg, int nz) {
+                                                double bzbot, int lg, int nz,
+                                                int lvl0 = 0) {
+  // level of slot p of this lane: lvl0 + lg*P + p
   // surface boundary condition (column.py:230-231)
   if (BC && !do_conv) {
 #pragma unroll
     for (int p = 0; p < P; ++p)
-      if (lg * P + p == nz - 1) r.b[p] = bs;
+      if (lvl0 + lg * P + p == nz - 1) r.b[p] = bs;
   }
   // b at the level above each owned level
   const double nb0 = from_next_lane(r.b[0]);
@@ -90,7 +108,7 @@ __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA
 #pragma unroll
   for (int p = 0; p < P; ++p) bup[p] = (p < P - 1) ? r.b[p + 1 < P ? p + 1 : p] : nb0;
   // bottom boundary condition (column.py:232-233); level 0 = lane 0, slot 0
-  if (BC && lg == 0) r.b[0] = use_bzbot ? (bup[0] - bzbot * r.dz[0]) : bbot;
+  if (BC && lvl0 + lg * P == 0) r.b[0] = use_bzbot ? (bup[0] - bzbot * r.dz[0]) : bbot;
 
   // Every stage below is written across the P slots so that the in-order wave always has
   // P independent dependency chains in flight (one wave per SIMD is latency-bound).
@@ -120,7 +138,7 @@ __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA
       for (int p = 0; p < P; ++p) bz[p] = q[p];
     } else {
 #pragma unroll
-      for (int p = 0; p < P; ++p) bz[p] = (lg * P + p < nz - 1) ? q[p] : 0.0;
+      for (int p = 0; p < P; ++p) bz[p] = (lvl0 + lg * P + p < nz - 1) ? q[p] : 0.0;
     }
   }
   const double pbz = from_prev_lane(bz[P - 1]);
@@ -162,7 +180,7 @@ __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA
   }
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    const int i = lg * P + p;
+    const int i = lvl0 + lg * P + p;
     const bool interior = (i >= 1) && (i <= nz - 2);
     const double db_dt = adv[p] + r.kap[p] * bzz[p];  // column.py:245-248
     // column.py:249.  Boundary / padding slots advance with dt = 0 (b + 0*x == b for the
@@ -190,13 +208,13 @@ __device__ __forceinline__ void col_horadv(ColRegs<P> &r, const double (&vdx)[P]
 // static part of a column (grid metrics + coefficient set `sel`) into registers
 template <int P>
 __device__ __forceinline__ void col_load_static(ColRegs<P> &r, const pm_columns &c,
-                                                int col, int sel, int lg) {
+                                                int col, int sel, int lg, int lvl0 = 0) {
   const int nz = c.nz;
   const size_t base = (size_t)col * nz;
   const size_t sbase = ((size_t)sel * c.ncols + col) * nz;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    const int i = lg * P + p;
+    const int i = lvl0 + lg * P + p;
     const int ic = i < nz ? i : nz - 1;
     const int iu = ic + 1 < nz ? ic + 1 : nz - 1;
     const int id = ic > 0 ? ic - 1 : 0;
@@ -250,10 +268,20 @@ __global__ __launch_bounds__(256) void k_column_steps(
   const double N2min = c.N2min[col];
 
   if constexpr (PLAIN) {
-    if (do_conv) {
+    if (do_conv && use_bzbot) {
       for (int s = 0; s < nsteps; ++s) {
         col_convect<G, P>(r.b, r.z, bs, N2min, lg, lane, nz, c.z);
-        col_vertadvdiff<G, P, FAST>(r, wA, dt, true, bs, bbot, use_bzbot, bzbot, lg, nz);
+        col_vertadvdiff<G, P, FAST>(r, wA, dt, true, bs, bbot, true, bzbot, lg, nz);
+      }
+    } else if (do_conv) {
+      // b[0] = bbot is constant unless a convection event rewrites level 0: impose it once
+      // and again after such an event (the reference re-imposes it every step, column.py:232)
+      for (int s = 0; s < nsteps; ++s) {
+        const bool hit = col_convect<G, P>(r.b, r.z, bs, N2min, lg, lane, nz, c.z);
+        if (hit || s == 0) {
+          if (lg == 0) r.b[0] = bbot;
+        }
+        col_vertadvdiff<G, P, FAST, false>(r, wA, dt, true, bs, bbot, false, 0., lg, nz);
       }
     } else if (use_bzbot) {
       for (int s = 0; s < nsteps; ++s)

@@ -125,3 +125,4 @@ def test_config2_full_size_properties(gpu):
   assert np.array_equal(b_one[:, 0], c["bbot"])
   noconv = ~c["do_conv"]
   assert np.array_equal(b_one[noconv, -1], c["bs"][noconv])
+
