@@ -18,15 +18,19 @@
 namespace pm {
 
 template <int P>
-struct ColRegs {
-  double b[P];     // state
+struct ColGrid {     // shared by every column of a batch (and by the columns of one member)
   double z[P];     // level depth
   double dz[P];    // z[i+1]-z[i]           (interface above level i)
   double dzc[P];   // 0.5*(dz[i]+dz[i-1])   (column.py:238)
+  double rdz[P], rdzc[P];  // RN(1/dz) (0 above the top level), RN(1/dzc)
+};
+template <int P>
+struct ColRegs {
+  double b[P];     // state
   double kap[P];   // kappa(z_i)
   double area[P];  // Area(z_i)
   double dAk[P];   // d(Area*kappa)/dz at z_i (np.gradient, host precomputed)
-  double rdz[P], rdzc[P], rarea[P];  // RN(1/dz), RN(1/dzc), RN(1/area) (FAST path only)
+  double rarea[P]; // RN(1/area)
 };
 
 // Column.convect (column.py:251-271).  `zg` is the shared grid in global memory.
@@ -90,7 +94,8 @@ __device__ __forceinline__ bool col_convect(double (&b)[P], const double (&z)[P]
 // BC = false: the caller has already imposed the (constant) boundary values, which no
 // interior update ever touches -- valid when bzbot is None and the surface value is bs.
 template <int G, int P, bool FAST, bool BC = true>
-__device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA)[P],
+__device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> &r,
+                                                const double (&wA)[P],
                                                 double dt, bool do_conv, double bs,
                                                 double bbot, bool use_bzbot,
                                                 double bzbot, int lg, int nz,
@@ -108,7 +113,7 @@ __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA
 #pragma unroll
   for (int p = 0; p < P; ++p) bup[p] = (p < P - 1) ? r.b[p + 1 < P ? p + 1 : p] : nb0;
   // bottom boundary condition (column.py:232-233); level 0 = lane 0, slot 0
-  if (BC && lvl0 + lg * P == 0) r.b[0] = use_bzbot ? (bup[0] - bzbot * r.dz[0]) : bbot;
+  if (BC && lvl0 + lg * P == 0) r.b[0] = use_bzbot ? (bup[0] - bzbot * g.dz[0]) : bbot;
 
   // Every stage below is written across the P slots so that the in-order wave always has
   // P independent dependency chains in flight (one wave per SIMD is latency-bound).
@@ -119,18 +124,18 @@ __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA
     for (int p = 0; p < P; ++p) num[p] = bup[p] - r.b[p];
     if constexpr (FAST) {
 #pragma unroll
-      for (int p = 0; p < P; ++p) q[p] = num[p] * r.rdz[p];
+      for (int p = 0; p < P; ++p) q[p] = num[p] * g.rdz[p];
 #pragma unroll
-      for (int p = 0; p < P; ++p) rr[p] = __builtin_fma(-r.dz[p], q[p], num[p]);
+      for (int p = 0; p < P; ++p) rr[p] = __builtin_fma(-g.dz[p], q[p], num[p]);
 #pragma unroll
-      for (int p = 0; p < P; ++p) q[p] = __builtin_fma(rr[p], r.rdz[p], q[p]);
+      for (int p = 0; p < P; ++p) q[p] = __builtin_fma(rr[p], g.rdz[p], q[p]);
 #pragma unroll
-      for (int p = 0; p < P; ++p) rr[p] = __builtin_fma(-r.dz[p], q[p], num[p]);
+      for (int p = 0; p < P; ++p) rr[p] = __builtin_fma(-g.dz[p], q[p], num[p]);
 #pragma unroll
-      for (int p = 0; p < P; ++p) q[p] = __builtin_fma(rr[p], r.rdz[p], q[p]);
+      for (int p = 0; p < P; ++p) q[p] = __builtin_fma(rr[p], g.rdz[p], q[p]);
     } else {
 #pragma unroll
-      for (int p = 0; p < P; ++p) q[p] = num[p] / r.dz[p];
+      for (int p = 0; p < P; ++p) q[p] = num[p] / g.dz[p];
     }
     if constexpr (FAST) {
       // rdz is 0 above the top level, so q is already 0 there (num*0, +0 corrections)
@@ -155,26 +160,26 @@ __device__ __forceinline__ void col_vertadvdiff(ColRegs<P> &r, const double (&wA
     double r1[P], r2[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      bzz[p] = dbz[p] * r.rdzc[p];
+      bzz[p] = dbz[p] * g.rdzc[p];
       adv[p] = flx[p] * r.rarea[p];
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        r1[p] = __builtin_fma(-r.dzc[p], bzz[p], dbz[p]);
+        r1[p] = __builtin_fma(-g.dzc[p], bzz[p], dbz[p]);
         r2[p] = __builtin_fma(-r.area[p], adv[p], flx[p]);
       }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        bzz[p] = __builtin_fma(r1[p], r.rdzc[p], bzz[p]);
+        bzz[p] = __builtin_fma(r1[p], g.rdzc[p], bzz[p]);
         adv[p] = __builtin_fma(r2[p], r.rarea[p], adv[p]);
       }
     }
   } else {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      bzz[p] = dbz[p] / r.dzc[p];
+      bzz[p] = dbz[p] / g.dzc[p];
       adv[p] = flx[p] / r.area[p];
     }
   }
@@ -205,7 +210,27 @@ __device__ __forceinline__ void col_horadv(ColRegs<P> &r, const double (&vdx)[P]
   }
 }
 
-// static part of a column (grid metrics + coefficient set `sel`) into registers
+// grid metrics of the batch into registers
+template <int P>
+__device__ __forceinline__ void col_load_grid(ColGrid<P> &g, const pm_columns &c, int lg,
+                                              int lvl0 = 0) {
+  const int nz = c.nz;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lvl0 + lg * P + p;
+    const int ic = i < nz ? i : nz - 1;
+    const int iu = ic + 1 < nz ? ic + 1 : nz - 1;
+    const int id = ic > 0 ? ic - 1 : 0;
+    const double zc = c.z[ic];
+    g.z[p] = zc;
+    g.dz[p] = c.z[iu] - zc;
+    g.dzc[p] = 0.5 * (g.dz[p] + (zc - c.z[id]));
+    g.rdz[p] = (i < nz - 1) ? 1.0 / g.dz[p] : 0.0;  // 0: bz above the top level is 0
+    g.rdzc[p] = 1.0 / g.dzc[p];
+  }
+}
+
+// static coefficients of one column (coefficient set `sel`) into registers
 template <int P>
 __device__ __forceinline__ void col_load_static(ColRegs<P> &r, const pm_columns &c,
                                                 int col, int sel, int lg, int lvl0 = 0) {
@@ -216,17 +241,9 @@ __device__ __forceinline__ void col_load_static(ColRegs<P> &r, const pm_columns 
   for (int p = 0; p < P; ++p) {
     const int i = lvl0 + lg * P + p;
     const int ic = i < nz ? i : nz - 1;
-    const int iu = ic + 1 < nz ? ic + 1 : nz - 1;
-    const int id = ic > 0 ? ic - 1 : 0;
-    const double zc = c.z[ic];
-    r.z[p] = zc;
-    r.dz[p] = c.z[iu] - zc;
-    r.dzc[p] = 0.5 * (r.dz[p] + (zc - c.z[id]));
     r.kap[p] = c.kappa[sbase + ic];
     r.dAk[p] = c.dAkappa[sbase + ic];
     r.area[p] = c.area[base + ic];
-    r.rdz[p] = (i < nz - 1) ? 1.0 / r.dz[p] : 0.0;  // 0: bz above the top level is 0
-    r.rdzc[p] = 1.0 / r.dzc[p];
     r.rarea[p] = 1.0 / r.area[p];
   }
 }
@@ -245,8 +262,10 @@ __global__ __launch_bounds__(256) void k_column_steps(
   const int nz = c.nz;
   const size_t base = (size_t)col * nz;
 
+  ColGrid<P> g;
   ColRegs<P> r;
   const int sel = c.ksel ? c.ksel[col] : 0;
+  col_load_grid<P>(g, c, lg);
   col_load_static<P>(r, c, col, sel, lg);
 
   double wA[P], vdx[P], bin[P];
@@ -270,22 +289,22 @@ __global__ __launch_bounds__(256) void k_column_steps(
   if constexpr (PLAIN) {
     if (do_conv && use_bzbot) {
       for (int s = 0; s < nsteps; ++s) {
-        col_convect<G, P>(r.b, r.z, bs, N2min, lg, lane, nz, c.z);
-        col_vertadvdiff<G, P, FAST>(r, wA, dt, true, bs, bbot, true, bzbot, lg, nz);
+        col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
+        col_vertadvdiff<G, P, FAST>(g, r, wA, dt, true, bs, bbot, true, bzbot, lg, nz);
       }
     } else if (do_conv) {
       // b[0] = bbot is constant unless a convection event rewrites level 0: impose it once
       // and again after such an event (the reference re-imposes it every step, column.py:232)
       for (int s = 0; s < nsteps; ++s) {
-        const bool hit = col_convect<G, P>(r.b, r.z, bs, N2min, lg, lane, nz, c.z);
+        const bool hit = col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
         if (hit || s == 0) {
           if (lg == 0) r.b[0] = bbot;
         }
-        col_vertadvdiff<G, P, FAST, false>(r, wA, dt, true, bs, bbot, false, 0., lg, nz);
+        col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
       }
     } else if (use_bzbot) {
       for (int s = 0; s < nsteps; ++s)
-        col_vertadvdiff<G, P, FAST>(r, wA, dt, false, bs, bbot, true, bzbot, lg, nz);
+        col_vertadvdiff<G, P, FAST>(g, r, wA, dt, false, bs, bbot, true, bzbot, lg, nz);
     } else {
       // constant boundary values: impose them once, then run the BC-free step
 #pragma unroll
@@ -294,14 +313,14 @@ __global__ __launch_bounds__(256) void k_column_steps(
         if (lg * P + p == 0) r.b[p] = bbot;
       }
       for (int s = 0; s < nsteps; ++s)
-        col_vertadvdiff<G, P, FAST, false>(r, wA, dt, false, bs, bbot, false, 0., lg, nz);
+        col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
     }
   } else {
     for (int s = 0; s < nsteps; ++s) {
       if ((ops & PM_OP_CONVECT) && do_conv)
-        col_convect<G, P>(r.b, r.z, bs, N2min, lg, lane, nz, c.z);
+        col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
       if (ops & PM_OP_VERTADVDIFF)
-        col_vertadvdiff<G, P, FAST>(r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lg, nz);
+        col_vertadvdiff<G, P, FAST>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lg, nz);
       if ((ops & PM_OP_HORADV) && vdx_g) col_horadv<P>(r, vdx, bin, dt, lg, nz);
     }
   }

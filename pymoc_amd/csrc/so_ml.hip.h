@@ -46,7 +46,10 @@ struct MlLds {
   double *cp;    // [ny] Thomas c'   (constant coefficients: tabulated once per launch)
   double *den;   // [ny] Thomas denominators
   double *rden;  // [ny] RN(1/den)
-  __device__ static int doubles(int nz, int ny) { return 2 * nz + 7 * ny; }
+  double *f1;    // [ny] surflux/h                 (loop-invariant part of the flux, :250)
+  double *f2;    // [ny] rest_mask*v_pist/h
+  double *br;    // [ny] b_rest
+  __device__ static int doubles(int nz, int ny) { return 2 * nz + 10 * ny; }
   __device__ void carve(double *base, int nz, int ny) {
     bb = base;
     pm = bb + nz;
@@ -57,6 +60,9 @@ struct MlLds {
     cp = dp + ny;
     den = cp + ny;
     rden = den + ny;
+    f1 = rden + ny;
+    f2 = f1 + ny;
+    br = f2 + ny;
   }
 };
 
@@ -71,6 +77,26 @@ __device__ __forceinline__ bool ml_prepare(const MlLds &w, int nz, int lane, int
   for (int i = lane; i < ind; i += 64) w.pm[i] = fillv;
   __builtin_amdgcn_wave_barrier();
   return true;
+}
+
+struct MlStatic {
+  const double *surflux, *rest_mask, *b_rest;  // this member's rows in global memory
+  double h, L, v_pist, dy, s;
+  double rh, rL, rdy;  // RN(1/h), RN(1/L), RN(1/dy) for the correctly rounded divisions
+};
+
+// loop-invariant parts of the surface-flux tendency (:250-252), same operations as the
+// reference: surflux/h and rest_mask*v_pist/h
+__device__ __forceinline__ void ml_flux_tables(const MlLds &w, MlStatic &c, int ny, int lane) {
+  for (int j = lane; j < ny; j += 64) {
+    w.f1[j] = c.surflux[j] / c.h;
+    w.f2[j] = c.rest_mask[j] * c.v_pist / c.h;
+    w.br[j] = c.b_rest[j];
+  }
+  c.rh = 1.0 / c.h;
+  c.rL = 1.0 / c.L;
+  c.rdy = 1.0 / c.dy;
+  __builtin_amdgcn_wave_barrier();
 }
 
 // Thomas factors of U = tridiag(-s/2, 1+s, -s/2) with identity boundary rows (:155-165)
@@ -90,10 +116,6 @@ __device__ __forceinline__ void ml_tables(const MlLds &w, int ny, double s) {
 
 // One SO_ML.advdiff step on the member staged in `w` (bs, bb, pm valid; tables valid).
 // Returns false where the reference raises IndexError (state untouched).
-struct MlStatic {
-  const double *surflux, *rest_mask, *b_rest;  // this member's rows in global memory
-  double h, L, v_pist, dy, s;
-};
 __device__ __forceinline__ bool ml_step(const MlLds &w, const MlStatic &c, int nz, int ny,
                                         int lane, int first_pos, double dt) {
   // Psi_s = np.interp(bs, b_basin, Psi_mod) (:232)
@@ -136,15 +158,19 @@ __device__ __forceinline__ bool ml_step(const MlLds &w, const MlStatic &c, int n
   // tendencies from surface flux / restoring and upwind advection (:250-259)
   for (int j = lane; j < ny; j += 64) {
     const double bsj = w.bs[j];
-    const double flux =
-        c.surflux[j] / c.h + c.rest_mask[j] * c.v_pist / c.h * (c.b_rest[j] - bsj);
+    const double flux = w.f1[j] + w.f2[j] * (w.br[j] - bsj);
     double adv = 0.;
     if (j >= 1 && j <= ny - 2) {
       const double ps = w.ps[j];
+      // -Psi_s*1e6*(db)/h/L/dy (:128-133): the three divisions are correctly rounded
+      // through the precomputed reciprocals, so the value equals the plain quotient chain
+      double num = 0.;
       if (ps < 0.)
-        adv = -ps * 1e6 * (w.bs[j + 1] - bsj) / c.h / c.L / c.dy;
+        num = -ps * 1e6 * (w.bs[j + 1] - bsj);
       else if (ps > 0.)
-        adv = -ps * 1e6 * (bsj - w.bs[j - 1]) / c.h / c.L / c.dy;
+        num = -ps * 1e6 * (bsj - w.bs[j - 1]);
+      if (ps != 0. && ps == ps)
+        adv = div_by_recip(div_by_recip(div_by_recip(num, c.h, c.rh), c.L, c.rL), c.dy, c.rdy);
     }
     w.rhs[j] = bsj + dt * (flux + adv);  // staged: every tendency uses the old bs
   }
@@ -168,7 +194,30 @@ __device__ __forceinline__ bool ml_step(const MlLds &w, const MlStatic &c, int n
     w.rhs[j] = r;
   }
   __builtin_amdgcn_wave_barrier();
-  {
+  if (ny <= 64) {
+    // Thomas sweep, every lane redundantly; lane i keeps row i's result in a register so the
+    // loops contain no LDS stores and their (broadcast) loads pipeline ahead of the chain
+    const double ta = -s / 2.;
+    double dp = w.rhs[0];
+    double mine = dp;  // lane 0: dp_0
+#pragma unroll 4
+    for (int i = 1; i < ny - 1; ++i) {
+      dp = div_by_recip(w.rhs[i] - ta * dp, w.den[i], w.rden[i]);
+      mine = (lane == i) ? dp : mine;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < ny - 1) w.dp[lane] = mine;
+    __builtin_amdgcn_wave_barrier();
+    double x = w.rhs[ny - 1];
+    mine = x;  // lane ny-1
+#pragma unroll 4
+    for (int i = ny - 2; i >= 0; --i) {
+      x = w.dp[i] - w.cp[i] * x;
+      mine = (lane == i) ? x : mine;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < ny) w.bs[lane] = mine;
+  } else {
     const double ta = -s / 2.;
     double dp = w.rhs[0];
     w.dp[0] = dp;
@@ -224,6 +273,7 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_so_ml_step(pm_so_ml
   c.s = a.Ks * dt / (c.dy * c.dy);  // :191
   bool ok = ml_prepare(w, nz, lane, first_pos);
   if (ok) {
+    ml_flux_tables(w, c, ny, lane);
     ml_tables(w, ny, c.s);
     ok = ml_step(w, c, nz, ny, lane, first_pos, dt);
   }
@@ -316,7 +366,7 @@ __device__ __forceinline__ void col_load_coef(ColRegs<P> &r, const pm_columns &c
 }
 
 template <int P>
-__global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_jn2018_steps(pm_jn2018 a,
+__global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_jn2018 a,
                                                                           double dt,
                                                                           int nsteps) {
   extern __shared__ double lds_all[];
@@ -337,7 +387,9 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_jn2018_steps(pm_jn2
   st.bbot_n = c.bbot[coln];
   st.ksel_b = c.ksel[colb];
   st.ksel_n = c.ksel[coln];
+  ColGrid<P> g;
   ColRegs<P> rb, rn;
+  col_load_grid<P>(g, c, lane);
   col_load_static<P>(rb, c, colb, st.ksel_b, lane);
   col_load_static<P>(rn, c, coln, st.ksel_n, lane);
   double wAb[P], wAn[P];
@@ -368,7 +420,10 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_jn2018_steps(pm_jn2
   mc.s = a.ml.Ks * dt / (mc.dy * mc.dy);
   int first_pos;
   bool ml_ok = ml_prepare(w, nz, lane, first_pos);
-  if (ml_ok) ml_tables(w, ny, mc.s);
+  if (ml_ok) {
+    ml_flux_tables(w, mc, ny, lane);
+    ml_tables(w, ny, mc.s);
+  }
   int status = ml_ok ? 0 : 1;
 
   // lanes / slots holding levels 0 and 1 of a column
@@ -382,10 +437,10 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_jn2018_steps(pm_jn2
     if (st.ksel_b != kb) col_load_coef<P>(rb, c, colb, st.ksel_b, lane);
     if (st.ksel_n != kn) col_load_coef<P>(rn, c, coln, st.ksel_n, lane);
     // ---- basin.timestep / north.timestep, do_conv=True (:257-258)
-    col_convect<64, P>(rb.b, rb.z, bs_b, N2_b, lane, lane, nz, c.z);
-    col_vertadvdiff<64, P, true>(rb, wAb, dt, true, bs_b, st.bbot_b, false, 0., lane, nz);
-    col_convect<64, P>(rn.b, rn.z, bs_n, N2_n, lane, lane, nz, c.z);
-    col_vertadvdiff<64, P, true>(rn, wAn, dt, true, bs_n, st.bbot_n, false, 0., lane, nz);
+    col_convect<64, P>(rb.b, g.z, bs_b, N2_b, lane, lane, nz, c.z);
+    col_vertadvdiff<64, P, true>(g, rb, wAb, dt, true, bs_b, st.bbot_b, false, 0., lane, nz);
+    col_convect<64, P>(rn.b, g.z, bs_n, N2_n, lane, lane, nz, c.z);
+    col_vertadvdiff<64, P, true>(g, rn, wAn, dt, true, bs_n, st.bbot_n, false, 0., lane, nz);
     // ---- channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi) (:261)
     if (ml_ok) {
 #pragma unroll
@@ -436,7 +491,7 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_jn2018_steps(pm_jn2
 }
 
 inline size_t ml_lds_bytes(int nz, int ny) {
-  return (size_t)(2 * nz + 7 * ny) * sizeof(double);
+  return (size_t)(2 * nz + 10 * ny) * sizeof(double);
 }
 
 inline int launch_so_ml(const pm_so_ml &a, double dt, hipStream_t st) {

@@ -226,7 +226,7 @@ __device__ __forceinline__ double serial_prefix_inplace(double *s, int n) {
   return acc;
 }
 
-template <int P, bool BIG>
+template <int P, int BIG>
 __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermwind a,
                                                                        int ops) {
   extern __shared__ double lds_all[];
@@ -367,10 +367,20 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
       const int i = i0 + j * 64 + lane;
       bg[j] = lin.at(i < nb ? i : nb - 1);
     }
-    if constexpr (BIG)
+    if constexpr (BIG == 2) {
       psib_pairwise<4>(s_a, s_b, s_y, s_c, 0, nc, bg, res);
-    else
+    } else if constexpr (BIG == 1) {
+      // 128 < nc <= 256: NumPy's recursion is exactly two blocks, both inlined
+      int n2 = nc / 2;
+      n2 -= n2 % 8;
+      double r2[TW_JT];
+      psib_block_sum(s_a, s_b, s_y, s_c, 0, n2, bg, res);
+      psib_block_sum(s_a, s_b, s_y, s_c, n2, nc - n2, bg, r2);
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) res[j] = res[j] + r2[j];
+    } else {
       psib_block_sum(s_a, s_b, s_y, s_c, 0, nc, bg, res);  // nc <= 128: one pairwise block
+    }
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) {
       const int i = i0 + j * 64 + lane;
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
   }
 }
 
-template <int P, bool BIG>
+template <int P, int BIG>
 int launch_thermwind_impl(const pm_thermwind &a, int ops, hipStream_t st) {
   const size_t per_wave = (size_t)(4 * a.nz + a.nb) * sizeof(double);
   int wpb = TW_WAVES_PER_BLOCK;
@@ -421,9 +431,12 @@ int launch_thermwind_impl(const pm_thermwind &a, int ops, hipStream_t st) {
 template <int P>
 int launch_thermwind(const pm_thermwind &a, int ops, hipStream_t st) {
   if constexpr (P <= 3) {
-    if (a.nz - 1 <= 128) return launch_thermwind_impl<P, false>(a, ops, st);
+    if (a.nz - 1 <= 128) return launch_thermwind_impl<P, 0>(a, ops, st);
   }
-  return launch_thermwind_impl<P, true>(a, ops, st);
+  if constexpr (P >= 2 && P <= 5) {
+    if (a.nz - 1 > 128 && a.nz - 1 <= 256) return launch_thermwind_impl<P, 1>(a, ops, st);
+  }
+  return launch_thermwind_impl<P, 2>(a, ops, st);
 }
 
 inline int dispatch_thermwind(const pm_thermwind &a, int ops, hipStream_t st) {
