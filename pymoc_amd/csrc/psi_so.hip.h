@@ -68,13 +68,16 @@ struct SoElem {  // condensed 2x2 element of an interval: rows for its left/righ
 // S = u'_0 + u'_1 and D = u'_1 - u'_0 as affine functions of (u_0, u_1).
 __device__ __forceinline__ SoElem so_sub_element(double h, double q0, double q1, double qm,
                                                  double r0, double r1, double rm) {
-  const double al = 1. + h * h * qm / 12.;
-  const double sA = -(2. / h) * (1. + h * h * q0 / 12.);
-  const double sB = (2. / h) * (1. + h * h * q1 / 12.);
-  const double sC = -(h / 6.) * (r1 - r0);
-  const double dA = (h / 6.) * (q0 + 2. * qm) / al;
-  const double dB = (h / 6.) * (q1 + 2. * qm) / al;
-  const double dC = -(h / 6.) * (r0 + r1 + 4. * rm) / al;
+  // divisions by the constants 12 and 6 and the repeated 1/h, 1/al are multiplications by
+  // reciprocals here (<= 1 ulp each; this solve is compared at 1e-9 / 1e-5, not bitwise)
+  const double h2_12 = h * h * (1. / 12.), h_6 = h * (1. / 6.), two_h = 2. / h;
+  const double ral = 1. / (1. + h2_12 * qm);
+  const double sA = -two_h * (1. + h2_12 * q0);
+  const double sB = two_h * (1. + h2_12 * q1);
+  const double sC = -h_6 * (r1 - r0);
+  const double dA = h_6 * (q0 + 2. * qm) * ral;
+  const double dB = h_6 * (q1 + 2. * qm) * ral;
+  const double dC = -h_6 * (r0 + r1 + 4. * rm) * ral;
   SoElem e;
   e.a11 = sA - dA;
   e.a12 = sB - dB;
@@ -87,8 +90,8 @@ __device__ __forceinline__ SoElem so_sub_element(double h, double q0, double q1,
 
 // eliminate the node shared by E (left) and e (right)
 __device__ __forceinline__ SoElem so_merge(const SoElem &E, const SoElem &e) {
-  const double D = E.a22 + e.a11;
-  const double w1 = E.a12 / D, w2 = e.a21 / D;
+  const double rD = 1. / (E.a22 + e.a11);
+  const double w1 = E.a12 * rD, w2 = e.a21 * rD;
   const double cc = E.c2 + e.c1;
   SoElem o;
   o.a11 = E.a11 - w1 * E.a21;
@@ -292,6 +295,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
     }
     __builtin_amdgcn_wave_barrier();
     const int R = a.bvp_refine > 0 ? a.bvp_refine : 8;
+    const double rc2 = 1. / c2, rR = 1. / (double)R;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int k = lane * P + p;  // interval [z_k, z_k+1]
@@ -300,20 +304,20 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
         const double N0 = s_N2[k], N1 = s_N2[k + 1], T0 = s_T[k], T1 = s_T[k + 1];
         const double sN = (N1 - N0) / hz, sT = (T1 - T0) / hz;
         SoElem E;
-        double xl = zk, ql = N0 / c2, rl = ql * T0;
+        double xl = zk, ql = N0 * rc2, rl = ql * T0;
         for (int j = 0; j < R; ++j) {
           double xr, qr, rr;
           if (j == R - 1) {
             xr = a.z[k + 1];
-            qr = N1 / c2;
+            qr = N1 * rc2;
             rr = qr * T1;
           } else {
-            xr = zk + hz * ((double)(j + 1) / R);
-            qr = (sN * (xr - zk) + N0) / c2;
+            xr = zk + hz * ((double)(j + 1) * rR);
+            qr = (sN * (xr - zk) + N0) * rc2;
             rr = qr * (sT * (xr - zk) + T0);
           }
           const double h = xr - xl, xm = xl + 0.5 * h;
-          const double qm = (sN * (xm - zk) + N0) / c2;
+          const double qm = (sN * (xm - zk) + N0) * rc2;
           const double rm = qm * (sT * (xm - zk) + T0);
           const SoElem e = so_sub_element(h, ql, qr, qm, rl, rr, rm);
           E = (j == 0) ? e : so_merge(E, e);
@@ -341,33 +345,76 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
       ua = -(__shfl(ek_sv[0], 0, 64) * 1e6);
       ub = -(__shfl(v_last, last_lane, 64) * 1e6);
     }
-    // Thomas sweep over the nz condensed nodes, every lane redundantly via LDS
-    {
-      double cp = 0., dp = ua;  // row 0: u_0 = ua
-      s_cp[0] = cp;
-      s_dp[0] = dp;
-      for (int i = 1; i < nz - 1; ++i) {
-        const double lo = e21[i - 1], di = e22[i - 1] + e11[i], up = e12[i];
-        const double rh = ec2[i - 1] + ec1[i];
-        const double den = di - lo * cp;
-        cp = up / den;
-        dp = (rh - lo * dp) / den;
-        s_cp[i] = cp;
-        s_dp[i] = dp;
-      }
-      double u = ub;
-      s_u[nz - 1] = u;
-      for (int i = nz - 2; i >= 1; --i) {
-        u = s_dp[i] - s_cp[i] * u;
-        s_u[i] = u;
-      }
-      s_u[0] = ua;
-    }
-    __builtin_amdgcn_wave_barrier();
+    // Assemble the nz-point tridiagonal rows from the condensed elements (parallel), then a
+    // Thomas sweep that every lane runs redundantly.  The sweep has no LDS stores (lane i
+    // keeps row i's factors in registers), so its broadcast loads pipeline ahead of the
+    // dependency chain, and one reciprocal per row serves both quotients.
+    double r_lo[P], r_di[P], r_up[P], r_rh[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = lane * P + p;
-      temp[p] = s_u[i < nz ? i : nz - 1];
+      const bool row = i >= 1 && i <= nz - 2;
+      const int ii = row ? i : 1;
+      r_lo[p] = e21[ii - 1];
+      r_di[p] = e22[ii - 1] + e11[ii];
+      r_up[p] = e12[ii];
+      r_rh[p] = ec2[ii - 1] + ec1[ii];
+    }
+    __builtin_amdgcn_wave_barrier();
+    double *t_lo = e11, *t_di = e12, *t_up = ec1, *t_rh = e21;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      if (i >= 1 && i <= nz - 2) {
+        t_lo[i] = r_lo[p];
+        t_di[i] = r_di[p];
+        t_up[i] = r_up[p];
+        t_rh[i] = r_rh[p];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      double cp = 0., dp = ua;  // row 0: u_0 = ua
+      double my_cp[P], my_dp[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        my_cp[p] = 0.;
+        my_dp[p] = ua;
+      }
+#pragma unroll 2
+      for (int i = 1; i < nz - 1; ++i) {
+        const double lo = t_lo[i];
+        const double inv = 1.0 / (t_di[i] - lo * cp);
+        cp = t_up[i] * inv;
+        dp = (t_rh[i] - lo * dp) * inv;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          my_cp[p] = (lane * P + p == i) ? cp : my_cp[p];
+          my_dp[p] = (lane * P + p == i) ? dp : my_dp[p];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = lane * P + p;
+        if (i < nz - 1) {
+          s_cp[i] = my_cp[p];
+          s_dp[i] = my_dp[p];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      double u = ub;
+      double my_u[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) my_u[p] = (lane * P + p == 0) ? ua : ub;
+#pragma unroll 2
+      for (int i = nz - 2; i >= 1; --i) {
+        u = s_dp[i] - s_cp[i] * u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) my_u[p] = (lane * P + p == i) ? u : my_u[p];
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) temp[p] = my_u[p];
     }
   }
   // limit Psi_GM to -Psi_Ek on isopycnals that do not outcrop (:329-330)
