@@ -86,6 +86,8 @@ def main():
   ap.add_argument("--lanes", type=int, default=0, help="lanes per column (0 = auto)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-single-step", action="store_true")
+  ap.add_argument("--force-rccl", action="store_true",
+                  help="use the RCCL communicator even with one rank (plumbing check)")
   args = ap.parse_args()
 
   import pymoc_amd
@@ -98,7 +100,8 @@ def main():
                      "(one process per GPU)" % (args.gpus, world))
   pymoc_amd._lib.require_device(local_rank)
   stream = Stream()
-  comm = sharding.make_communicator(stream=stream)
+  comm = (sharding.RcclCommunicator(stream=stream) if args.force_rccl
+          else sharding.make_communicator(stream=stream))
 
   C, nz, F, K, W = args.columns, args.nz, args.steps_per_launch, args.steps, args.warmup
   lo, hi = rank * C, (rank + 1) * C
@@ -107,7 +110,8 @@ def main():
                                 bs=cfg["bs"], bbot=cfg["bbot"], N2min=cfg["N2min"],
                                 do_conv=cfg["do_conv"], stream=stream)
   wA = DeviceArray.from_host(cfg["wA"], stream=stream)
-  gathered = DeviceArray((world, C, nz)) if world > 1 else None
+  use_gather = world > 1 or args.force_rccl
+  gathered = DeviceArray((world, C, nz)) if use_gather else None
   dt = cfg["dt"]
 
   run_steps(batch, wA, dt, W, F, args.lanes)
@@ -120,7 +124,7 @@ def main():
   ev0.record(stream)
   launches = run_steps(batch, wA, dt, K, F, args.lanes)
   ev1.record(stream)
-  if world > 1:  # diagnostic output: RCCL all-gather of the final buoyancy
+  if use_gather:  # diagnostic output: RCCL all-gather of the final buoyancy
     comm.allgather_device(batch.b, gathered, stream)
   stream.sync()
   comm.barrier(stream)

@@ -256,6 +256,7 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
   PM_REQUIRE(c.ncols >= 0 && c.nz >= 2 && c.nz <= 1024,
              "bad batch shape ncols=%d nz=%d (need nz in [2,1024])", c.ncols, c.nz);
   PM_REQUIRE(c.nsel >= 1 && c.nsel <= 2, "nsel must be 1 or 2 (got %d)", c.nsel);
+  if (c.ncols == 0) return PM_OK;  // empty batch: nothing to do, pointers may be NULL
   PM_REQUIRE(c.z && c.b && c.kappa && c.area && c.dAkappa && c.bs && c.bbot && c.N2min,
              "pm_columns has a NULL required pointer");
   PM_REQUIRE(nsteps >= 0, "nsteps < 0");
@@ -287,6 +288,7 @@ int pm_thermwind_update(const pm_thermwind *tw, int32_t ops, pm_stream_t stream)
   PM_REQUIRE((ops & ~15) == 0 && ops != 0, "bad ops 0x%x", ops);
   PM_REQUIRE(!(ops & PM_TW_PSIBZ) || (ops & PM_TW_PSIB), "PM_TW_PSIBZ needs PM_TW_PSIB");
   PM_REQUIRE(!(ops & PM_TW_PSIB) || a.nb >= 1, "nb must be >= 1");
+  if (a.n == 0) return PM_OK;
   PM_REQUIRE(a.z && a.b1 && a.b2 && a.Psi, "pm_thermwind has a NULL required pointer");
   PM_REQUIRE(!(ops & PM_TW_SOLVE) || a.f, "f is NULL");
   if (a.n == 0) return PM_OK;
@@ -300,6 +302,7 @@ int pm_psi_so_update(const pm_psi_so *so, int32_t ops, pm_stream_t stream) {
   PM_REQUIRE(a.n >= 0 && a.nz >= 2 && a.nz <= 512 && a.ny >= 2 && a.ny <= 2048,
              "bad shape n=%d nz=%d ny=%d", a.n, a.nz, a.ny);
   PM_REQUIRE(ops >= 1 && ops <= 3, "bad ops %d", ops);
+  if (a.n == 0) return PM_OK;
   PM_REQUIRE(a.z && a.y && a.b && a.bs && a.tau && a.KGM && a.Psi_Ek,
              "pm_psi_so has a NULL required pointer");
   PM_REQUIRE(!(ops & PM_SO_OP_GM) || (a.Psi && a.Psi_GM), "Psi / Psi_GM is NULL");
@@ -314,6 +317,7 @@ int pm_so_ml_step(const pm_so_ml *ml, double dt, pm_stream_t stream) {
   const pm_so_ml &a = *ml;
   PM_REQUIRE(a.n >= 0 && a.nz >= 2 && a.ny >= 3 && a.nz <= 4096 && a.ny <= 2048,
              "bad shape n=%d nz=%d ny=%d", a.n, a.nz, a.ny);
+  if (a.n == 0) return PM_OK;
   PM_REQUIRE(a.y && a.bs && a.b_basin && a.Psi_b && a.surflux && a.rest_mask && a.b_rest,
              "pm_so_ml has a NULL required pointer");
   if (a.n == 0) return PM_OK;

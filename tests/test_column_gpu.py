@@ -80,6 +80,27 @@ def test_empty_batch_and_zero_steps(gpu):
   assert np.array_equal(batch.get_b(), b0)
 
 
+def test_empty_ensembles_are_no_ops(gpu):
+  """n = 0 members: every entry point returns OK without touching memory."""
+  import ctypes as C
+  from pymoc_amd import _lib
+  cols = _lib.pm_columns()
+  cols.ncols, cols.nz, cols.nsel = 0, 10, 1
+  _lib.check(_lib.lib.pm_column_steps(C.byref(cols), None, None, None, 1.0, 5, 7, 0, None))
+  tw = _lib.pm_thermwind()
+  tw.n, tw.nz, tw.nb = 0, 10, 5
+  _lib.check(_lib.lib.pm_thermwind_update(C.byref(tw), 7, None))
+  so = _lib.pm_psi_so()
+  so.n, so.nz, so.ny = 0, 10, 5
+  _lib.check(_lib.lib.pm_psi_so_update(C.byref(so), 3, None))
+  ml = _lib.pm_so_ml()
+  ml.n, ml.nz, ml.ny = 0, 10, 5
+  _lib.check(_lib.lib.pm_so_ml_step(C.byref(ml), 1.0, None))
+  with pytest.raises(_lib.PmError):  # but bad shapes are still rejected
+    cols.nz = 1
+    _lib.check(_lib.lib.pm_column_steps(C.byref(cols), None, None, None, 1.0, 5, 7, 0, None))
+
+
 def test_nonfinite_members_are_flagged_not_raised(gpu):
   z = np.linspace(-100., 0., 10)
   b = np.zeros((4, 10)) + 0.01
