@@ -12,7 +12,6 @@ wrapper pays two small PCIe copies per call.
 import numpy as np
 
 from .. import _lib
-from ..columns import ColumnBatch
 from ..utils import make_func, make_array
 
 
@@ -40,7 +39,7 @@ class Column(object):
     self.N2min = N2min
     self.b = make_array(b, self.z, 'b')
     self.bz = np.gradient(self.b, z)
-    self._batch = None
+    self._arena = None
     self._kap_cached = None
     self._area_cached = None
 
@@ -56,29 +55,62 @@ class Column(object):
         'Column.solve_equi (SciPy solve_bvp equilibrium solver, column.py:187-208) is '
         'outside the timestep() path this engine replaces')
 
-  # ---- device plumbing
-  def _sync_to_device(self, do_conv):
-    z = self.z
-    kap = np.asarray(self.kappa(z), dtype=np.float64) + 0 * z
-    area = np.asarray(self.Area(z), dtype=np.float64) + 0 * z
-    if self._batch is None:
-      self._batch = ColumnBatch(z, kap, area, np.asarray(self.b, dtype=np.float64),
-                                report_nonfinite=False)
-      self._kap_cached, self._area_cached = kap.copy(), area.copy()
-    else:
-      if not (np.array_equal(kap, self._kap_cached) and
-              np.array_equal(area, self._area_cached)):
-        self._batch.set_static(kap, area)
-        self._kap_cached, self._area_cached = kap.copy(), area.copy()
-      self._batch.set_b(self.b)
-    self._batch.set_params(bs=float(self.bs), bbot=float(self.bbot),
-                           bzbot=None if self.bzbot is None else float(self.bzbot),
-                           N2min=float(self.N2min), do_conv=bool(do_conv))
+  # ---- device plumbing: one arena, one H2D and one D2H per call
+  # arena (float64 slots): [b | wA | vdx_in | b_in | bs bbot bzbot N2min | flags(int32)]
+  def _alloc(self):
+    import ctypes as C
+    from ..device import DeviceArray
+    nz = self.z.size
+    self._nz = nz
+    self._host = np.zeros(4 * nz + 5)
+    self._arena = DeviceArray((4 * nz + 5,))
+    self._zd = DeviceArray.from_host(np.ascontiguousarray(self.z, dtype=np.float64))
+    self._kap = DeviceArray((nz,))
+    self._area = DeviceArray((nz,))
+    self._dAk = DeviceArray((nz,))
+    p, d = self._arena.ptr, _lib.pm_columns()
+    d.ncols, d.nz, d.nsel, d.reserved = 1, nz, 1, 0
+    d.z, d.b = self._zd.ptr, p
+    d.kappa, d.area, d.dAkappa = self._kap.ptr, self._area.ptr, self._dAk.ptr
+    sc = p + 4 * nz * 8
+    d.bs, d.bbot, d.bzbot, d.N2min, d.flags = sc, sc + 8, sc + 16, sc + 24, sc + 32
+    d.ksel, d.nonfinite = None, None
+    self._desc = d
+    self._wA_ptr, self._vdx_ptr, self._bin_ptr = p + nz * 8, p + 2 * nz * 8, p + 3 * nz * 8
+    self._C = C
 
   def _run(self, ops, do_conv, wA=None, dt=1., vdx_in=None, b_in=None):
-    self._sync_to_device(do_conv)
-    self._batch.steps(wA, dt, 1, ops, vdx_in, b_in)
-    self.b[...] = self._batch.get_b()[0]
+    if getattr(self, "_arena", None) is None or self._nz != self.z.size:
+      self._alloc()
+      self._kap_cached = None
+    z, nz, h = self.z, self._nz, self._host
+    kap = np.asarray(self.kappa(z), dtype=np.float64) + 0 * z
+    area = np.asarray(self.Area(z), dtype=np.float64) + 0 * z
+    if (self._kap_cached is None or not np.array_equal(kap, self._kap_cached) or
+        not np.array_equal(area, self._area_cached)):
+      # static coefficients changed (first call, or the user re-assigned kappa / Area)
+      self._kap.upload(kap)
+      self._area.upload(area)
+      self._dAk.upload(np.gradient(area * kap, z))  # dAkappa_dz, column.py:96-122
+      self._kap_cached, self._area_cached = kap.copy(), area.copy()
+    h[0:nz] = self.b
+    h[nz:2 * nz] = 0. if wA is None else wA
+    if vdx_in is not None:
+      h[2 * nz:3 * nz] = vdx_in
+      h[3 * nz:4 * nz] = b_in
+    h[4 * nz:4 * nz + 4] = (self.bs, self.bbot, 0. if self.bzbot is None else self.bzbot,
+                            self.N2min)
+    flags = (_lib.PM_COL_DO_CONV if do_conv else 0) | (
+        _lib.PM_COL_BZBOT if self.bzbot is not None else 0)
+    h[4 * nz + 4:].view(np.int32)[0] = flags
+    self._arena.upload(h)
+    _lib.check(_lib.lib.pm_column_steps(
+        self._C.byref(self._desc), self._wA_ptr,
+        self._vdx_ptr if vdx_in is not None else None,
+        self._bin_ptr if vdx_in is not None else None, float(dt), 1, int(ops), 0, None))
+    out = np.empty(nz)
+    _lib.check(_lib.lib.pm_memcpy_d2h(out.ctypes.data, self._arena.ptr, nz * 8, None))
+    self.b[...] = out
 
   # ---- the time-stepping API (column.py:210-348)
   def vertadvdiff(self, wA, dt, do_conv=False):

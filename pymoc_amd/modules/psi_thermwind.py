@@ -10,7 +10,6 @@ import numpy as np
 
 from .. import _lib
 from ..device import DeviceArray
-from ..thermwind import ThermwindBatch
 from ..utils import make_func, make_array
 
 
@@ -34,37 +33,60 @@ class Psi_Thermwind(object):
     self.sol_init = np.zeros((2, nz)) if sol_init is None else sol_init
     self._batch = None
     self._nb = 0
+    self._nz = 0
 
-  def _device(self, nb):
+  # ---- device plumbing: one arena, one H2D and one D2H per call
+  # arena (float64 slots): in  [b1 | b2 | Psi_in | f]   out [Psi | psibz1 | psibz2 | bgrid | psib]
+  def _run(self, ops, nb, need_psi):
+    import ctypes as C
+    from .. import _lib
     nz = np.size(self.z)
-    if self._batch is None or self._nb < nb:
-      self._nb = max(int(nb), 1)
-      self._batch = ThermwindBatch(self.z, 1, f=float(self.f), nb=self._nb)
-      self._b1 = DeviceArray((1, nz))
-      self._b2 = DeviceArray((1, nz))
-    self._batch.f.upload(np.array([float(self.f)]))
-    self._b1.upload(np.asarray(make_array(self.b1, self.z, 'b1'), dtype=np.float64) + 0 * self.z)
-    self._b2.upload(np.asarray(make_array(self.b2, self.z, 'b2'), dtype=np.float64) + 0 * self.z)
-    return self._batch
+    if self._batch is None or self._nb < nb or self._nz != nz:
+      self._nb, self._nz = max(int(nb), 1), nz
+      self._zd = DeviceArray.from_host(np.ascontiguousarray(self.z, dtype=np.float64))
+      self._nin = 3 * nz + 1
+      self._arena = DeviceArray((self._nin + 3 * nz + 2 * self._nb,))
+      self._host = np.zeros(self._nin)
+      self._batch = True
+    h, p = self._host, self._arena.ptr
+    h[0:nz] = np.asarray(make_array(self.b1, self.z, 'b1'), dtype=np.float64) + 0 * self.z
+    h[nz:2 * nz] = np.asarray(make_array(self.b2, self.z, 'b2'), dtype=np.float64) + 0 * self.z
+    if need_psi:
+      h[2 * nz:3 * nz] = self.Psi
+    h[3 * nz] = self.f
+    _lib.check(_lib.lib.pm_memcpy_h2d(p, h.ctypes.data, h.nbytes, None))
+    o = p + self._nin * 8
+    d = _lib.pm_thermwind()
+    d.n, d.nz, d.nb, d.reserved = 1, nz, int(nb), 0
+    d.z, d.b1, d.b2, d.f = self._zd.ptr, p, p + nz * 8, p + 3 * nz * 8
+    # without PM_TW_SOLVE the kernel reads Psi: point it at the uploaded copy
+    d.Psi = o if (ops & _lib.PM_TW_SOLVE) else p + 2 * nz * 8
+    d.psibz1, d.psibz2 = o + nz * 8, o + 2 * nz * 8
+    d.bgrid, d.psib = o + 3 * nz * 8, o + (3 * nz + self._nb) * 8
+    d.Psi_SO, d.wA1, d.wA2 = None, None, None
+    _lib.check(_lib.lib.pm_thermwind_update(C.byref(d), int(ops), None))
+    out = np.empty(3 * nz + 2 * self._nb)
+    _lib.check(_lib.lib.pm_memcpy_d2h(out.ctypes.data, o, out.nbytes, None))
+    return out
 
   def solve(self):
-    t = self._device(self._nb or 1)
-    t.update(self._b1, self._b2, ops=_lib.PM_TW_SOLVE, nb=1)
-    self.Psi = t.Psi.download()[0]
+    from .. import _lib
+    out = self._run(_lib.PM_TW_SOLVE, 1, False)
+    self.Psi = out[:np.size(self.z)].copy()
 
   def Psib(self, nb=500):
-    t = self._device(nb)
-    t.Psi.upload(np.asarray(self.Psi, dtype=np.float64)[None, :])
-    t.update(self._b1, self._b2, ops=_lib.PM_TW_PSIB, nb=nb)
-    self.bgrid = t.bgrid.download()[0, :nb].copy()
-    return t.psib.download()[0, :nb].copy()
+    from .. import _lib
+    nz = np.size(self.z)
+    out = self._run(_lib.PM_TW_PSIB, nb, True)
+    self.bgrid = out[3 * nz:3 * nz + nb].copy()
+    return out[3 * nz + self._nb:3 * nz + self._nb + nb].copy()
 
   def Psibz(self, nb=500):
-    t = self._device(nb)
-    t.Psi.upload(np.asarray(self.Psi, dtype=np.float64)[None, :])
-    t.update(self._b1, self._b2, ops=_lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ, nb=nb)
-    self.bgrid = t.bgrid.download()[0, :nb].copy()
-    return [t.psibz1.download()[0], t.psibz2.download()[0]]
+    from .. import _lib
+    nz = np.size(self.z)
+    out = self._run(_lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ, nb, True)
+    self.bgrid = out[3 * nz:3 * nz + nb].copy()
+    return [out[nz:2 * nz].copy(), out[2 * nz:3 * nz].copy()]
 
   def update(self, b1=None, b2=None):
     if b1 is not None:
