@@ -33,50 +33,80 @@ struct ColRegs {
   double rarea[P]; // RN(1/area)
 };
 
+// Convecting-level pattern of the previous step and its zconv: persistent convection keeps
+// the same levels convecting for many steps, so the find-last-bit / readlane chain that
+// locates zconv is skipped while the pattern is unchanged (G = 64 only).
+template <int P>
+struct ConvCache {
+  unsigned long long mask[P];
+  double zconv;
+  bool valid = false;
+};
+
 // Column.convect (column.py:251-271).  `zg` is the shared grid in global memory.
 // Returns true when some level convected (rare), false when only b[-1] = bs was imposed.
 template <int G, int P>
 __device__ __forceinline__ bool col_convect(double (&b)[P], const double (&z)[P],
                                             double bs, double N2min, int lg, int lane,
-                                            int nz, const double *__restrict__ zg) {
+                                            int nz, const double *__restrict__ zg,
+                                            ConvCache<P> *cache = nullptr) {
   const unsigned long long gm = group_mask<G>(lane);
   bool ind[P];
-  bool any_l = false;
+  unsigned long long im[P];  // per-slot ballot of the convecting levels (column.py:264)
+  unsigned long long anym = 0ull;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int i = lg * P + p;
-    ind[p] = (i < nz) && (b[p] > bs);  // column.py:264
-    any_l |= ind[p];
+    ind[p] = (i < nz) && (b[p] > bs);
+    im[p] = __builtin_amdgcn_ballot_w64(ind[p]);
+    anym |= im[p] & gm;
   }
-  const unsigned long long anym = __builtin_amdgcn_ballot_w64(any_l) & gm;
   if (__builtin_expect(anym != 0ull, 0)) {
-    // zconv = max(z[~ind]) (column.py:267): z ascends, so it is z at the highest
-    // non-convecting level; bottom of the ocean if every level convects.
-    int jmax = 0;
+    double zconv;
+    bool hit = false;
+    if constexpr (G == 64) {
+      if (cache != nullptr && cache->valid) {
+        hit = true;
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int i = lg * P + p;
-      const unsigned long long m = __builtin_amdgcn_ballot_w64((i < nz) && !ind[p]) & gm;
-      if (m != 0ull) {
-        const int hl = 63 - __clzll((long long)m);
-        const int j = (hl % G) * P + p;
-        jmax = j > jmax ? j : jmax;
+        for (int p = 0; p < P; ++p) hit = hit && (cache->mask[p] == im[p]);
       }
     }
-    double zconv;
-    if constexpr (G == 64) {
-      // the wave owns the whole column: fetch z[jmax] from the owning lane's registers
-      // (two v_readlane) instead of a scalar memory load in the middle of the time loop
-      const int jl = __builtin_amdgcn_readfirstlane(jmax / P);
-      const int jp = __builtin_amdgcn_readfirstlane(jmax % P);
-      double zsel = z[0];
-#pragma unroll
-      for (int p = 1; p < P; ++p) zsel = (jp == p) ? z[p] : zsel;
-      const int lo = __builtin_amdgcn_readlane(__double2loint(zsel), jl);
-      const int hi = __builtin_amdgcn_readlane(__double2hiint(zsel), jl);
-      zconv = __hiloint2double(hi, lo);
+    if (hit) {
+      zconv = cache->zconv;
     } else {
-      zconv = zg[jmax];
+      // zconv = max(z[~ind]) (column.py:267): z ascends, so it is z at the highest
+      // non-convecting level; bottom of the ocean if every level convects.
+      int jmax = 0;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = lg * P + p;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64((i < nz) && !ind[p]) & gm;
+        if (m != 0ull) {
+          const int hl = 63 - __clzll((long long)m);
+          const int j = (hl % G) * P + p;
+          jmax = j > jmax ? j : jmax;
+        }
+      }
+      if constexpr (G == 64) {
+        // the wave owns the whole column: fetch z[jmax] from the owning lane's registers
+        // (two v_readlane) instead of a scalar memory load in the middle of the time loop
+        const int jl = __builtin_amdgcn_readfirstlane(jmax / P);
+        const int jp = __builtin_amdgcn_readfirstlane(jmax % P);
+        double zsel = z[0];
+#pragma unroll
+        for (int p = 1; p < P; ++p) zsel = (jp == p) ? z[p] : zsel;
+        const int lo = __builtin_amdgcn_readlane(__double2loint(zsel), jl);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(zsel), jl);
+        zconv = __hiloint2double(hi, lo);
+        if (cache != nullptr) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) cache->mask[p] = im[p];
+          cache->zconv = zconv;
+          cache->valid = true;
+        }
+      } else {
+        zconv = zg[jmax];
+      }
     }
 #pragma unroll
     for (int p = 0; p < P; ++p)
@@ -87,6 +117,57 @@ __device__ __forceinline__ bool col_convect(double (&b)[P], const double (&z)[P]
   for (int p = 0; p < P; ++p)
     if (lg * P + p == nz - 1) b[p] = bs;  // column.py:271
   return false;
+}
+
+// Column.convect for a wave-owned column (G = 64) inside a time loop, branch-free in the
+// steady state: the convecting-level pattern (one ballot per slot, scalar registers) is
+// compared with the previous step's; only when it CHANGES does the wave take the branch that
+// re-derives zconv.  The adjustment itself is applied with selects every step.
+template <int P>
+__device__ __forceinline__ void col_convect_cached(double (&b)[P], const double (&z)[P],
+                                                   double bs, double N2min, int lane, int nz,
+                                                   ConvCache<P> &cc) {
+  bool ind[P];
+  unsigned long long im[P], anym = 0ull;
+  bool same = cc.valid;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    ind[p] = (lane * P + p < nz) && (b[p] > bs);  // column.py:264
+    im[p] = __builtin_amdgcn_ballot_w64(ind[p]);
+    anym |= im[p];
+    same = same && (im[p] == cc.mask[p]);
+  }
+  if (__builtin_expect(!same, 0)) {
+    // zconv = max(z[~ind]) (column.py:267): z at the highest non-convecting level, bottom of
+    // the ocean if every level convects
+    int jmax = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64((lane * P + p < nz) && !ind[p]);
+      if (m != 0ull) {
+        const int j = (63 - __clzll((long long)m)) * P + p;
+        jmax = j > jmax ? j : jmax;
+      }
+    }
+    const int jl = __builtin_amdgcn_readfirstlane(jmax / P);
+    const int jp = __builtin_amdgcn_readfirstlane(jmax % P);
+    double zsel = z[0];
+#pragma unroll
+    for (int p = 1; p < P; ++p) zsel = (jp == p) ? z[p] : zsel;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(zsel), jl);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(zsel), jl);
+    cc.zconv = __hiloint2double(hi, lo);
+#pragma unroll
+    for (int p = 0; p < P; ++p) cc.mask[p] = im[p];
+    cc.valid = true;
+  }
+  const bool none = anym == 0ull;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const double adj = bs + N2min * (z[p] - cc.zconv);  // column.py:268
+    b[p] = ind[p] ? adj : b[p];
+    if (lane * P + p == nz - 1) b[p] = none ? bs : b[p];  // column.py:271
+  }
 }
 
 // Column.vertadvdiff (column.py:210-249), one explicit step.  FAST: the three divisions by
@@ -295,11 +376,17 @@ __global__ __launch_bounds__(256) void k_column_steps(
     } else if (do_conv) {
       // b[0] = bbot is constant unless a convection event rewrites level 0: impose it once
       // and again after such an event (the reference re-imposes it every step, column.py:232)
+      ConvCache<P> cc;
+#pragma unroll
+      for (int p = 0; p < P; ++p) cc.mask[p] = 0ull;
+      cc.zconv = 0.;
       for (int s = 0; s < nsteps; ++s) {
-        const bool hit = col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
-        if (hit || s == 0) {
-          if (lg == 0) r.b[0] = bbot;
+        if constexpr (G == 64) {
+          col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);
+        } else {
+          col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
         }
+        if (lg == 0) r.b[0] = bbot;  // column.py:232 (a convection event may rewrite level 0)
         col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
       }
     } else if (use_bzbot) {

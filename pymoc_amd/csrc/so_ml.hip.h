@@ -426,6 +426,10 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
   }
   int status = ml_ok ? 0 : 1;
 
+  ConvCache<P> ccb, ccn;
+#pragma unroll
+  for (int p = 0; p < P; ++p) ccb.mask[p] = ccn.mask[p] = 0ull;
+  ccb.zconv = ccn.zconv = 0.;
   // lanes / slots holding levels 0 and 1 of a column
   constexpr int L1 = 1 / P, S1 = 1 % P;
   for (int s = 0; s < nsteps; ++s) {
@@ -437,9 +441,9 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
     if (st.ksel_b != kb) col_load_coef<P>(rb, c, colb, st.ksel_b, lane);
     if (st.ksel_n != kn) col_load_coef<P>(rn, c, coln, st.ksel_n, lane);
     // ---- basin.timestep / north.timestep, do_conv=True (:257-258)
-    col_convect<64, P>(rb.b, g.z, bs_b, N2_b, lane, lane, nz, c.z);
+    col_convect_cached<P>(rb.b, g.z, bs_b, N2_b, lane, nz, ccb);
     col_vertadvdiff<64, P, true>(g, rb, wAb, dt, true, bs_b, st.bbot_b, false, 0., lane, nz);
-    col_convect<64, P>(rn.b, g.z, bs_n, N2_n, lane, lane, nz, c.z);
+    col_convect_cached<P>(rn.b, g.z, bs_n, N2_n, lane, nz, ccn);
     col_vertadvdiff<64, P, true>(g, rn, wAn, dt, true, bs_n, st.bbot_n, false, 0., lane, nz);
     // ---- channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi) (:261)
     if (ml_ok) {
