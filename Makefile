@@ -1,9 +1,7 @@
 # Build the gfx950 engine (libpymoc_hip.so) and the CPU oracle (test infrastructure).
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Wno-unused-value
 CSRC  = pymoc_amd/csrc
-HIPSRC = $(CSRC)/pymoc_hip.hip
 HIPHDR = $(wildcard $(CSRC)/*.h) include/pymoc_hip.h
 
 all: lib oracle

@@ -86,12 +86,7 @@ __device__ __forceinline__ unsigned long long group_mask(int lane) {
   }
 }
 
-// value of `x` held by lane `src` (absolute lane in wave)
-__device__ __forceinline__ double lane_bcast(double x, int src) {
-  return __shfl(x, src, WAVE);
-}
-
-// min / max / sum over the G lanes of a group (butterfly; every lane gets the result)
+// min / max over the G lanes of a group (butterfly; every lane gets the result)
 template <int G>
 __device__ __forceinline__ double group_min(double x) {
 #pragma unroll
@@ -111,15 +106,23 @@ __device__ __forceinline__ double group_max(double x) {
   return x;
 }
 
-// inclusive prefix sum over the G lanes of a group (Hillis-Steele on ds_bpermute)
-template <int G>
-__device__ __forceinline__ double group_scan_incl(double x, int lg) {
-#pragma unroll
-  for (int o = 1; o < G; o <<= 1) {
-    double y = __shfl_up(x, o, G);
-    if (lg >= o) x += y;
+// value of np.linspace(start, stop, num)[i]  (numpy/_core/function_base.py)
+struct Linspace {
+  double start, stop, delta, step;
+  int num;
+  __device__ __forceinline__ void init(double a, double b, int n) {
+    start = a;
+    stop = b;
+    num = n;
+    delta = b - a;
+    step = (n > 1) ? delta / (double)(n - 1) : 0.;
   }
-  return x;
-}
+  __device__ __forceinline__ double at(int i) const {
+    if (i == num - 1 && num > 1) return stop;
+    if (num == 1) return start;
+    if (step == 0.) return ((double)i / (double)(num - 1)) * delta + start;
+    return (double)i * step + start;
+  }
+};
 
 }  // namespace pm

@@ -31,25 +31,6 @@ __device__ __forceinline__ double np_clip01(double v) {
   return v > 1. ? 1. : v;
 }
 
-// value of np.linspace(start, stop, num)[i]  (numpy/_core/function_base.py)
-struct Linspace {
-  double start, stop, delta, step;
-  int num;
-  __device__ __forceinline__ void init(double a, double b, int n) {
-    start = a;
-    stop = b;
-    num = n;
-    delta = b - a;
-    step = (n > 1) ? delta / (double)(n - 1) : 0.;
-  }
-  __device__ __forceinline__ double at(int i) const {
-    if (i == num - 1 && num > 1) return stop;
-    if (num == 1) return start;
-    if (step == 0.) return ((double)i / (double)(num - 1)) * delta + start;
-    return (double)i * step + start;
-  }
-};
-
 // np.interp(x, bgrid, psib) for one query, bgrid = lin (ascending, uniform), psib in LDS
 __device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
                                                  const double *psib, int nb) {
