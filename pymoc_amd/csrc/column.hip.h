@@ -380,14 +380,47 @@ __global__ __launch_bounds__(256) void k_column_steps(
 #pragma unroll
       for (int p = 0; p < P; ++p) cc.mask[p] = 0ull;
       cc.zconv = 0.;
-      for (int s = 0; s < nsteps; ++s) {
-        if constexpr (G == 64) {
-          col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);
-        } else {
-          col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
-        }
-        if (lg == 0) r.b[0] = bbot;  // column.py:232 (a convection event may rewrite level 0)
+      if constexpr (G == 64) {
+        // Speculative step: adjust with the PREVIOUS step's pattern facts (zconv, "nothing
+        // convects"), so the arithmetic of the step never waits for the scalar unit; the
+        // ballots of this step's pattern are compared with the cached ones after the step
+        // has been issued, and only a changed pattern (rare) redoes the step from b_old.
+        col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);  // step 0: establishes cc
+        if (lg == 0) r.b[0] = bbot;
         col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
+        for (int s = 1; s < nsteps; ++s) {
+          double b_old[P];
+          unsigned long long im[P];
+          bool none_all = true, same = true;
+#pragma unroll
+          for (int p = 0; p < P; ++p) none_all = none_all && (cc.mask[p] == 0ull);
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            b_old[p] = r.b[p];
+            const bool ind = (lane * P + p < nz) && (r.b[p] > bs);  // column.py:264
+            im[p] = __builtin_amdgcn_ballot_w64(ind);
+            const double adj = bs + N2min * (g.z[p] - cc.zconv);     // column.py:268
+            r.b[p] = ind ? adj : r.b[p];
+            if (lane * P + p == nz - 1) r.b[p] = none_all ? bs : r.b[p];  // column.py:271
+          }
+          if (lg == 0) r.b[0] = bbot;  // column.py:232
+          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
+#pragma unroll
+          for (int p = 0; p < P; ++p) same = same && (im[p] == cc.mask[p]);
+          if (__builtin_expect(!same, 0)) {  // pattern changed: redo this step exactly
+#pragma unroll
+            for (int p = 0; p < P; ++p) r.b[p] = b_old[p];
+            col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);
+            if (lg == 0) r.b[0] = bbot;
+            col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
+          }
+        }
+      } else {
+        for (int s = 0; s < nsteps; ++s) {
+          col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
+          if (lg == 0) r.b[0] = bbot;  // column.py:232 (a convection event may rewrite level 0)
+          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
+        }
       }
     } else if (use_bzbot) {
       for (int s = 0; s < nsteps; ++s)
