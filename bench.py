@@ -161,6 +161,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "traffic_unit": "bytes per launch (FETCH_SIZE+WRITE_SIZE, calibrated; profiles/)",
             "kernel": "k_column_steps<%d,%d>" % (lanes, -(-nz // lanes)),
             "kernel_ms_per_launch": launch_s * 1e3, "launches": launches,
             "algorithmic_bytes_per_launch": alg_bytes,

@@ -15,16 +15,16 @@ from ..utils import make_array
 class SO_ML(object):
   def __init__(
       self,
-      y=None,    # grid (input)
-      Ks=0.,    # hor. diffusivity (input)
-      h=50.,    # ML depth (input)
-      L=4e6,    # zonal width (input)
-      surflux=0.,    # prescribed surface buoyancy flux (in m^2/s^3; input)
-      rest_mask=0.,    # mask for surface restoring (1 where restoring is applied 0 elsewhere)
-      b_rest=0.,    # surface buoyancy towards which we are restoring
-      v_pist=1.5 / 86400.,    # piston velocity for restoring in SL (input)
-      bs=0.0,    # surface buoyancy (input, output)
-      Psi_s=None    # overturning in the ML (output)
+      y=None,
+      Ks=0.,
+      h=50.,
+      L=4e6,
+      surflux=0.,
+      rest_mask=0.,
+      b_rest=0.,
+      v_pist=1.5 / 86400.,
+      bs=0.0,
+      Psi_s=None
   ):
     if isinstance(y, np.ndarray):
       self.y = y

@@ -18,14 +18,14 @@ from ..utils import make_func, make_array
 class Column(object):
   def __init__(
       self,
-      z=None,    # grid (input)
-      kappa=None,    # diffusivity profile (input)
-      bs=0.025,    # surface buoyancy bound. cond (input)
-      bbot=0.0,    # bottom buoyancy boundary condition (input)
-      bzbot=None,    # bottom strat. as alternative boundary condition (input)
-      b=0.0,    # buoyancy profile (input, output)
-      Area=None,    # horizontal area (can be function of depth)
-      N2min=1e-7    # minimum strat. for conv adjustment
+      z=None,
+      kappa=None,
+      bs=0.025,
+      bbot=0.0,
+      bzbot=None,
+      b=0.0,
+      Area=None,
+      N2min=1e-7
   ):
     if isinstance(z, np.ndarray) and len(z) > 0:
       self.z = z

@@ -19,22 +19,22 @@ from ..utils import make_func, make_array
 class Psi_SO(object):
   def __init__(
       self,
-      z=None,    # vertical grid (array, in)
-      y=None,    # horizontal grid (array, in)
-      b=None,    # buoyancy profile at northern end of ACC (function, array or float, in)
-      bs=None,    # surface buoyancy (function, array or float, in)
-      tau=None,    # surface wind stress (function, array or float, in)
-      f=1.2e-4,    # Coriolis parameter (in)
-      rho=1030,    # density of sea water (in)
-      L=1e7,    # zonal length of the ACC (in)
-      KGM=1e3,    # GM coefficient (in)
-      c=None,    # phase speed for F2010 BVP smoother of GM streamfunction
-      bvp_with_Ek=False,    # if true, apply boundary condition Psi_GM=-Psi_EK in the smoother
-      Hsill=None,    # height (in m above ocean floor) of the "sill", where Psi_Ek is tapered
-      HEk=None,    # depth of surface Ekman layer
-      Htapertop=None,    # quadratic tapering of the GM streamfunction at the surface
-      Htaperbot=None,    # quadratic tapering of the GM streamfunction at the bottom
-      smax=0.01,    # maximum slope for clipping of GM streamfunction
+      z=None,
+      y=None,
+      b=None,
+      bs=None,
+      tau=None,
+      f=1.2e-4,
+      rho=1030,
+      L=1e7,
+      KGM=1e3,
+      c=None,
+      bvp_with_Ek=False,
+      Hsill=None,
+      HEk=None,
+      Htapertop=None,
+      Htaperbot=None,
+      smax=0.01,
   ):
     if isinstance(z, np.ndarray):
       self.z = z

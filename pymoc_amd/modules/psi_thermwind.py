@@ -16,11 +16,11 @@ from ..utils import make_func, make_array
 class Psi_Thermwind(object):
   def __init__(
       self,
-      f=1.2e-4,    # Coriolis parameter (input)
-      z=None,    # grid (input)
-      sol_init=None,    # initial conditions for the reference's ODE solver (unused here)
-      b1=None,    # buoyancy in the basin (input, output)
-      b2=0.,    # buoyancy in the deep water formation region (input, output)
+      f=1.2e-4,
+      z=None,
+      sol_init=None,
+      b1=None,
+      b2=0.,
   ):
     self.f = f
     if isinstance(z, np.ndarray):
