@@ -33,6 +33,29 @@ struct ColRegs {
   double rarea[P]; // RN(1/area)
 };
 
+// P consecutive levels of one column row (`row` points at level 0 of the column) starting at
+// level lvl0 + lg*P.  For P == 2, even nz and a 16-byte aligned row the lane issues ONE 16-byte
+// load (a wave then reads 1 KiB contiguously) instead of two 8-byte loads with stride 16;
+// padding lanes re-read the last pair.  Otherwise: per-level loads clamped to the last level.
+template <int P>
+__device__ __forceinline__ void load_levels(double (&out)[P], const double *__restrict__ row,
+                                            int lg, int nz, int lvl0 = 0) {
+  if constexpr (P == 2) {
+    if (lvl0 == 0 && (nz & 1) == 0 && (((unsigned long long)row) & 15ull) == 0ull) {
+      const int i0 = lg * 2 < nz - 2 ? lg * 2 : nz - 2;
+      const double2 v = *reinterpret_cast<const double2 *>(row + i0);
+      out[0] = v.x;
+      out[1] = v.y;
+      return;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lvl0 + lg * P + p;
+    out[p] = row[i < nz ? i : nz - 1];
+  }
+}
+
 // Convecting-level pattern of the previous step and its zconv: persistent convection keeps
 // the same levels convecting for many steps, so the find-last-bit / readlane chain that
 // locates zconv is skipped while the pattern is unchanged (G = 64 only).
@@ -292,7 +315,7 @@ __device__ __forceinline__ void col_horadv(ColRegs<P> &r, const double (&vdx)[P]
 }
 
 // grid metrics of the batch into registers
-template <int P>
+template <int P, bool FAST = true>
 __device__ __forceinline__ void col_load_grid(ColGrid<P> &g, const pm_columns &c, int lg,
                                               int lvl0 = 0) {
   const int nz = c.nz;
@@ -306,27 +329,27 @@ __device__ __forceinline__ void col_load_grid(ColGrid<P> &g, const pm_columns &c
     g.z[p] = zc;
     g.dz[p] = c.z[iu] - zc;
     g.dzc[p] = 0.5 * (g.dz[p] + (zc - c.z[id]));
-    g.rdz[p] = (i < nz - 1) ? 1.0 / g.dz[p] : 0.0;  // 0: bz above the top level is 0
-    g.rdzc[p] = 1.0 / g.dzc[p];
+    if constexpr (FAST) {  // reciprocals only where div_by_recip will use them
+      g.rdz[p] = (i < nz - 1) ? 1.0 / g.dz[p] : 0.0;  // 0: bz above the top level is 0
+      g.rdzc[p] = 1.0 / g.dzc[p];
+    } else {
+      g.rdz[p] = g.rdzc[p] = 0.0;
+    }
   }
 }
 
 // static coefficients of one column (coefficient set `sel`) into registers
-template <int P>
+template <int P, bool FAST = true>
 __device__ __forceinline__ void col_load_static(ColRegs<P> &r, const pm_columns &c,
                                                 int col, int sel, int lg, int lvl0 = 0) {
   const int nz = c.nz;
   const size_t base = (size_t)col * nz;
   const size_t sbase = ((size_t)sel * c.ncols + col) * nz;
+  load_levels<P>(r.kap, c.kappa + sbase, lg, nz, lvl0);
+  load_levels<P>(r.dAk, c.dAkappa + sbase, lg, nz, lvl0);
+  load_levels<P>(r.area, c.area + base, lg, nz, lvl0);
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const int i = lvl0 + lg * P + p;
-    const int ic = i < nz ? i : nz - 1;
-    r.kap[p] = c.kappa[sbase + ic];
-    r.dAk[p] = c.dAkappa[sbase + ic];
-    r.area[p] = c.area[base + ic];
-    r.rarea[p] = 1.0 / r.area[p];
-  }
+  for (int p = 0; p < P; ++p) r.rarea[p] = FAST ? 1.0 / r.area[p] : 0.0;
 }
 
 // PLAIN: ops == PM_OP_TIMESTEP without horadv inputs -- the time loop then carries no
@@ -346,19 +369,16 @@ __global__ __launch_bounds__(256) void k_column_steps(
   ColGrid<P> g;
   ColRegs<P> r;
   const int sel = c.ksel ? c.ksel[col] : 0;
-  col_load_grid<P>(g, c, lg);
-  col_load_static<P>(r, c, col, sel, lg);
+  col_load_grid<P, FAST>(g, c, lg);
+  col_load_static<P, FAST>(r, c, col, sel, lg);
 
   double wA[P], vdx[P], bin[P];
+  load_levels<P>(r.b, c.b + base, lg, nz);
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const int i = lg * P + p;
-    const int ic = i < nz ? i : nz - 1;
-    r.b[p] = c.b[base + ic];
-    wA[p] = wA_g ? wA_g[base + ic] : 0.0;
-    vdx[p] = vdx_g ? vdx_g[base + ic] : 0.0;
-    bin[p] = bin_g ? bin_g[base + ic] : 0.0;
-  }
+  for (int p = 0; p < P; ++p) wA[p] = vdx[p] = bin[p] = 0.0;
+  if (wA_g) load_levels<P>(wA, wA_g + base, lg, nz);
+  if (vdx_g) load_levels<P>(vdx, vdx_g + base, lg, nz);
+  if (bin_g) load_levels<P>(bin, bin_g + base, lg, nz);
   const int flags = c.flags ? c.flags[col] : 0;
   const bool do_conv = (flags & PM_COL_DO_CONV) != 0;
   const bool use_bzbot = (flags & PM_COL_BZBOT) != 0 && c.bzbot != nullptr;
@@ -446,12 +466,24 @@ __global__ __launch_bounds__(256) void k_column_steps(
   }
 
   bool bad = false;
+  bool stored = false;
+  if constexpr (P == 2) {
+    if ((nz & 1) == 0 && (((unsigned long long)(c.b + base)) & 15ull) == 0ull) {
+      if (lg * 2 < nz) {  // even nz: both levels of the pair are valid
+        if (col_ok) *reinterpret_cast<double2 *>(c.b + base + lg * 2) = make_double2(r.b[0], r.b[1]);
+        bad = !isfinite(r.b[0]) || !isfinite(r.b[1]);
+      }
+      stored = true;
+    }
+  }
+  if (!stored) {
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const int i = lg * P + p;
-    if (i < nz) {
-      if (col_ok) c.b[base + i] = r.b[p];
-      bad |= !isfinite(r.b[p]);
+    for (int p = 0; p < P; ++p) {
+      const int i = lg * P + p;
+      if (i < nz) {
+        if (col_ok) c.b[base + i] = r.b[p];
+        bad |= !isfinite(r.b[p]);
+      }
     }
   }
   if (c.nonfinite) {
