@@ -9,7 +9,14 @@ z = m["z"]
 basin = pymoc_amd.Column(z=z, kappa=m["kappa"].copy(), Area=m["A_basin"], b=m["b_basin0"].copy(), bs=m["bs"], bbot=m["bbot"])
 AMOC = pymoc_amd.Psi_Thermwind(z=z, b1=m["b_basin0"].copy(), b2=m["b_north0"].copy())
 wA = 1e6 * np.sin(z / 1000.)
-for name, fn in (("Column.timestep", lambda: basin.timestep(wA=wA, dt=m["dt"])),
+j = configs.jn2018_member(nz=81)
+ch = pymoc_amd.SO_ML(y=j["y"], h=j["h"], L=j["L"], Ks=j["Ks"], surflux=j["surflux"], rest_mask=j["rest_mask"],
+                     b_rest=j["b_rest"], v_pist=j["v_pist"], bs=j["bs_SO0"].copy())
+SO = pymoc_amd.Psi_SO(z=j["z"], y=j["y"], b=j["b_basin0"].copy(), bs=j["bs_SO0"].copy(), tau=0.12, L=j["L"], KGM=800.)
+SO.solve()
+for name, fn in (("SO_ML.timestep", lambda: ch.timestep(b_basin=j["b_basin0"], Psi_b=SO.Psi, dt=j["dt"])),
+                 ("Psi_SO.solve", lambda: SO.solve()),
+                 ("Column.timestep", lambda: basin.timestep(wA=wA, dt=m["dt"])),
                  ("Psi_Thermwind.solve", lambda: AMOC.solve()),
                  ("Psi_Thermwind.Psibz", lambda: AMOC.Psibz())):
   fn(); fn()

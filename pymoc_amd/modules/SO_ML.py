@@ -8,7 +8,6 @@ Thomas sweep instead of the reference's dense np.linalg.inv (difference ~1e-16).
 import numpy as np
 
 from ..device import DeviceArray
-from ..so_ml import SOMLBatch
 from ..utils import make_array
 
 
@@ -40,28 +39,46 @@ class SO_ML(object):
     self.Psi_s = Psi_s
     self.bs = make_array(bs, self.y, 'bs')
     self._batch = None
+    self._shape = None
 
+  # one arena: in [bs | surflux | rest_mask | b_rest | b_basin | Psi_b]  out [bs | Psi_s | status]
   def advdiff(self, b_basin, Psi_b, dt):
-    nz = np.size(b_basin)
-    if self._batch is None or self._batch.nz != nz:
-      self._batch = SOMLBatch(self.y, nz, np.asarray(self.bs, dtype=np.float64))
-      self._bb = DeviceArray((1, nz))
-      self._pb = DeviceArray((1, nz))
-    t = self._batch
-    t.Ks, t.h, t.L, t.v_pist = float(self.Ks), float(self.h), float(self.L), float(self.v_pist)
-    y0 = 0 * self.y
-    t.bs.upload(np.asarray(self.bs, dtype=np.float64)[None, :] + y0)
-    t.surflux.upload(np.asarray(self.surflux, dtype=np.float64)[None, :] + y0)
-    t.rest_mask.upload(np.asarray(self.rest_mask, dtype=np.float64)[None, :] + y0)
-    t.b_rest.upload(np.asarray(self.b_rest, dtype=np.float64)[None, :] + y0)
-    self._bb.upload(np.asarray(b_basin, dtype=np.float64)[None, :])
-    self._pb.upload(np.asarray(Psi_b, dtype=np.float64)[None, :])
-    t.step(self._bb, self._pb, dt)
-    if t.status.download()[0] == 1:
+    import ctypes as C
+    from .. import _lib
+    ny, nz = np.size(self.y), np.size(b_basin)
+    if self._batch is None or self._shape != (ny, nz):
+      self._shape = (ny, nz)
+      self._yd = DeviceArray.from_host(np.ascontiguousarray(self.y, dtype=np.float64))
+      self._nin = 4 * ny + 2 * nz
+      self._arena = DeviceArray((self._nin + ny + 1,))
+      self._host = np.zeros(self._nin)
+      self._batch = True
+    h, p, y0 = self._host, self._arena.ptr, 0 * self.y
+    h[0:ny] = np.asarray(self.bs, dtype=np.float64) + y0
+    h[ny:2 * ny] = np.asarray(self.surflux, dtype=np.float64) + y0
+    h[2 * ny:3 * ny] = np.asarray(self.rest_mask, dtype=np.float64) + y0
+    h[3 * ny:4 * ny] = np.asarray(self.b_rest, dtype=np.float64) + y0
+    h[4 * ny:4 * ny + nz] = b_basin
+    h[4 * ny + nz:] = Psi_b
+    _lib.check(_lib.lib.pm_memcpy_h2d(p, h.ctypes.data, h.nbytes, None))
+    d = _lib.pm_so_ml()
+    d.n, d.nz, d.ny, d.reserved = 1, nz, ny, 0
+    d.y, d.bs = self._yd.ptr, p
+    d.surflux, d.rest_mask, d.b_rest = p + ny * 8, p + 2 * ny * 8, p + 3 * ny * 8
+    d.b_basin, d.Psi_b = p + 4 * ny * 8, p + (4 * ny + nz) * 8
+    o = p + self._nin * 8
+    d.Psi_s, d.status = o, o + ny * 8
+    d.Ks, d.h, d.L, d.v_pist = float(self.Ks), float(self.h), float(self.L), float(self.v_pist)
+    _lib.check(_lib.lib.pm_memset(d.status, 0, 8, None))
+    _lib.check(_lib.lib.pm_so_ml_step(C.byref(d), float(dt), None))
+    # bs sits at the head of the arena, Psi_s and the status word behind the inputs
+    out = np.empty(self._nin + ny + 1)
+    _lib.check(_lib.lib.pm_memcpy_d2h(out.ctypes.data, p, out.nbytes, None))
+    if out[self._nin + ny:].view(np.int32)[0] == 1:
       # np.nonzero(Psi_mod)[0][0] / np.argwhere(Psi_b > 0)[0][0] on an empty result
       raise IndexError('index 0 is out of bounds for axis 0 with size 0')
-    self.Psi_s = t.Psi_s.download()[0]
-    self.bs = t.bs.download()[0]
+    self.Psi_s = out[self._nin:self._nin + ny].copy()
+    self.bs = out[0:ny].copy()
 
   def timestep(self, b_basin=None, Psi_b=None, dt=1.):
     if not isinstance(b_basin, np.ndarray):
