@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""bench_coupled.py -- throughput of the coupled drivers (BASELINE configs 3, 4, 5) on one
-GPU.  Secondary to bench.py (which measures the headline metric on config 2); prints one
+"""bench_coupled.py -- throughput of the coupled drivers (BASELINE configs 3, 4, 5; 6 = the
+two-basin topology of SURVEY 8f row N1) on one GPU.  Secondary to bench.py (which measures the headline metric on config 2); prints one
 JSON line per config with column-timesteps/s and coupled steps/s.
 
   python bench_coupled.py [--configs 3 4 5] [--members N] [--steps K]
@@ -18,7 +18,7 @@ if ROOT not in sys.path:
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument("--configs", type=int, nargs="*", default=[3, 4, 5])
+  ap.add_argument("--configs", type=int, nargs="*", default=[3, 4, 5, 6])
   ap.add_argument("--members", type=int, default=0, help="0 = the per-GPU size of SURVEY 8d")
   ap.add_argument("--steps", type=int, default=0)
   ap.add_argument("--no-graph", action="store_true")
@@ -38,6 +38,11 @@ def main():
       cfg = dict(configs.config4(N=n), bvp_refine=8)
       ens = pymoc_amd.TwoColEnsemble(cfg)
       steps, warm, ncol = args.steps or 2400, 241, 2
+    elif c == 6:  # two-basin topology, 3 columns per member
+      n = args.members or 2048
+      cfg = configs.config_twobasin(N=n)
+      ens = pymoc_amd.TwoBasinEnsemble(cfg)
+      steps, warm, ncol = args.steps or 2400, 241, 3
     else:
       n = args.members or 4096
       cfg = configs.config5(N=n)
