@@ -190,8 +190,9 @@ typedef struct pm_psi_so {
   double *Ek_raw;       /* [n][nz] out, m^3/s: calc_Ekman() return value (may be NULL)*/
   double *GM_raw;       /* [n][nz] out, m^3/s: calc_GM() return value (may be NULL)  */
   double *ys;           /* [n][nz] out: outcrop latitude of b[i] (may be NULL)        */
-  int32_t *status;      /* [n] out: bit0 bs not monotone north of its minimum (root
-                           ambiguous), bit1 non-finite Psi, bit2 NaN in bs (may be NULL) */
+  int32_t *status;      /* [n] out: bit0 bs not monotone north of its minimum (several
+                           roots: ys then follows brentq's own iteration, like the
+                           reference), bit1 non-finite Psi, bit2 NaN in bs (may be NULL) */
 } pm_psi_so;
 
 int pm_psi_so_update(const pm_psi_so *so, int32_t ops, pm_stream_t stream);
@@ -264,6 +265,46 @@ int pm_twobasin_forcing(int32_t n, int32_t nz, const double *Psi_iso_Atl,
                         const double *Psi_iso_N, const double *Psi_zonal_Pac,
                         const double *SO_Pac, double *wA_Atl, double *wAN, double *wA_Pac,
                         pm_stream_t stream);
+
+/* ---------------------------------------------------- equilibrium column
+ * Column.solve_equi (src/pymoc/modules/column.py:187-208 with ode :161-164 and bc :124-159):
+ * the steady advective-diffusive profile, which the reference obtains from
+ * scipy.integrate.solve_bvp.  pm_column_equi_pass is ONE mesh pass of that solver for n
+ * members, each on its own mesh: the exact solution of the 4th-order collocation system
+ * (the ODE is linear), the rms residual estimate of every interval and the number of nodes
+ * solve_bvp would insert.  The caller refines the flagged meshes and calls again until nadd
+ * is 0 (pymoc_amd/equilibrium.py does, following solve_bvp's loop).
+ * Point sets of a mesh x[m]: 0 = the m nodes; 1 = the m-1 interval middles x[i] + h/2;
+ * 2 / 3 = the Lobatto points middle +- (h/2) sqrt(3/7).                                  */
+typedef struct pm_column_equi {
+  int32_t n, nz, mmax, reserved;
+  const int32_t *m;       /* [n] mesh nodes of each member, 2 <= m <= mmax <= 1024        */
+  const int32_t *active;  /* [n] 0 = skip this member (may be NULL: all active)           */
+  const double *x;        /* [n][mmax] ascending mesh, contains every level of z          */
+  const double *Ak;       /* [4][n][mmax] Column.Akappa at the four point sets            */
+  const double *dAk;      /* [4][n][mmax] Column.dAkappa_dz at the four point sets        */
+  const double *wA;       /* [4][n][mmax] wA at the four point sets, or NULL to use wA_z  */
+  const double *wA_z;     /* [n][nz] wA on the column grid (np.interp'ed on the device)   */
+  const double *z;        /* [nz] column grid (needed with wA_z)                          */
+  const double *bs;       /* [n] */
+  const double *bbot;     /* [n] */
+  const double *bzbot;    /* [n] or NULL */
+  const int32_t *flags;   /* [n] PM_COL_BZBOT: b'(-H) = bzbot replaces b(-H) = bbot (or NULL) */
+  const int32_t *zidx;    /* [n][nz] position of column level k in the member's mesh      */
+  double tol;             /* solve_bvp's tol (the reference uses the default 1e-3)        */
+  double *y;              /* [n][2][mmax] out: b and db/dz on the mesh (may be NULL)      */
+  double *rms;            /* [n][mmax] out: rms residual of every interval (may be NULL)  */
+  int32_t *nadd;          /* [n] out: nodes solve_bvp would insert; 0 = converged (or NULL) */
+  double *b;              /* [n][nz] out: Column.b on the column grid (may be NULL)       */
+  double *bz;             /* [n][nz] out: Column.bz (may be NULL)                         */
+} pm_column_equi;
+
+int pm_column_equi_pass(const pm_column_equi *eq, pm_stream_t stream);
+
+/* out[i] = alpha*x[i] + beta*y[i] (two products, one sum, in that order): the relaxation
+ * b1 <- 0.8*b1 + 0.2*basin.b of examples/example_iteration.py:67.                         */
+int pm_axpby(size_t count, double alpha, const double *x, double beta, const double *y,
+             double *out, pm_stream_t stream);
 
 /* ------------------------------------------------------------------ RCCL
  * One process per GPU.  The ensemble is sharded by member, stepping needs no

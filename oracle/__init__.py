@@ -235,3 +235,45 @@ def so_ml_advdiff(y, surflux, rest_mask, b_rest, bs, b_basin, Psi_b, dt, Ks=0., 
   if rc != 0:
     raise IndexError("index 0 is out of bounds for axis 0 with size 0")
   return bs, Psi_s
+
+
+# ------------------------------------------------------------------ Column.solve_equi
+def column_equi_pass(x, c_n, c_m, c_1, c_2, bs, bbot, bzbot=None):
+  """One solve_bvp mesh pass (exact collocation solution + rms residuals) on mesh x."""
+  x, c_n, c_m, c_1, c_2 = _a(x), _a(c_n), _a(c_m), _a(c_1), _a(c_2)
+  y = np.empty((2, x.size))
+  rms = np.empty(x.size - 1)
+  lib().orc_column_equi_pass(_p(x), C.c_int(x.size), _p(c_n), _p(c_m), _p(c_1), _p(c_2),
+                             C.c_double(bs), C.c_double(bbot), C.c_int(bzbot is not None),
+                             C.c_double(0. if bzbot is None else bzbot), _p(y), _p(rms))
+  return y, rms
+
+
+def column_solve_equi(z, coef, bs, bbot, bzbot=None, tol=1e-3, max_nodes=1000):
+  """Column.solve_equi (column.py:187-208) = scipy.integrate.solve_bvp's mesh loop
+  (scipy 1.15.3 _bvp.py:solve_bvp) around `column_equi_pass`.  `coef(x)` returns
+  c(x) = (wA(x) - dAkappa_dz(x)) / Akappa(x) for one array of points, evaluated the way the
+  reference's `ode` does (column.py:161-164).  Returns (b, bz, mesh, status)."""
+  x = _a(z).copy()
+  status, it = 0, 0
+  while True:
+    h = np.diff(x)
+    xm = x[:-1] + 0.5 * h
+    s = 0.5 * h * (3 / 7)**0.5
+    y, rms = column_equi_pass(x, coef(x), coef(xm), coef(xm + s), coef(xm - s), bs, bbot,
+                              bzbot)
+    it += 1
+    ins1, = np.nonzero((rms > tol) & (rms < 100 * tol))
+    ins2, = np.nonzero(rms >= 100 * tol)
+    added = ins1.size + 2 * ins2.size
+    if x.size + added > max_nodes:
+      status = 1
+      break
+    if added > 0:  # _bvp.py:modify_mesh
+      x = np.sort(np.hstack((x, 0.5 * (x[ins1] + x[ins1 + 1]),
+                             (2 * x[ins2] + x[ins2 + 1]) / 3,
+                             (x[ins2] + 2 * x[ins2 + 1]) / 3)))
+    else:
+      break  # the linear solve satisfies the boundary conditions exactly
+  idx = np.searchsorted(x, _a(z))
+  return y[0, idx], y[1, idx], x, status

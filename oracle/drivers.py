@@ -7,12 +7,13 @@ loop structure of the reference's example scripts (which are the reference's onl
   run_twocol     examples/example_twocol.py:85-96
   run_twocol_so  examples/example_twocol_plusSO.py:99-115
   run_jn2018     examples/run_JansenNadeau_2018.py:201-261 (default flags)
+  run_iteration  examples/example_iteration.py:59-68
 Each returns {step: {field: array}} snapshots taken AFTER the given 1-based step count.
 """
 import numpy as np
 
 from . import (column_timestep, thermwind_solve, thermwind_psibz, psi_so_solve,
-               so_ml_advdiff)
+               so_ml_advdiff, column_solve_equi)
 
 
 def _snap(store, step, snaps, **fields):
@@ -146,4 +147,35 @@ def run_twobasin(m, nsteps, snaps):
       SO_P = psi_so_solve(z, y, bP, m['bs_SO'], m['tau'], L=m['L_Pac'], **so)[0]
     _snap(out, ii + 1, snaps, b_Atl=bA, b_north=bN, b_Pac=bP, Psi_AMOC=Psi_A, Psi_ZOC=Psi_Z,
           Psi_SO_Atl=SO_A, Psi_SO_Pac=SO_P)
+  return out
+
+
+def equi_coef(z, kappa, Area, wA):
+  """c(x) of Column.ode (column.py:161-164) for array / scalar / callable profiles, built the
+  way the reference builds its callables (make_func: np.interp for arrays)."""
+  def fn(a):
+    if callable(a):
+      return a
+    a = np.asarray(a, dtype=float)
+    return (lambda x: a + 0. * x) if a.ndim == 0 else (lambda x: np.interp(x, z, a))
+  kf, af, wf = fn(kappa), fn(Area), fn(wA)
+  ak = lambda x: af(x) * kf(x)
+  return lambda x: (wf(x) - np.gradient(ak(x), x)) / ak(x)
+
+
+def run_iteration(m, niter, snaps, kappa=None):
+  """m: `configs.iteration_member` dict; kappa: callable profile (default: m['kappa'])."""
+  z = m['z']
+  kap = m['kappa'] if kappa is None else kappa
+  b1 = m['b_basin0'].copy()
+  b2 = 0. * z
+  Psi = thermwind_solve(z, b1, b2, m['f'])
+  out = {}
+  snaps = set(snaps)
+  for ii in range(niter):
+    b, bz, _, _ = column_solve_equi(z, equi_coef(z, kap, m['A_basin'], Psi * 1e6), m['bs'],
+                                    m['bbot'])
+    b1 = m['keep'] * b1 + m['relax'] * b  # example_iteration.py:67
+    Psi = thermwind_solve(z, b1, b2, m['f'])
+    _snap(out, ii + 1, snaps, b=b, bz=bz, Psi=Psi, b1=b1)
   return out

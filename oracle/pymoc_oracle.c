@@ -754,3 +754,83 @@ int orc_so_ml_advdiff(const double *y, int ny, const double *surflux,
   free(Psi_mod);
   return 0;
 }
+
+
+/* ---- Column.solve_equi ---------------------------------------------------------
+ * Reference: column.py:161-164 (ode), :124-159 (bc), :187-208 (solve_equi), which hands the
+ * problem to scipy.integrate.solve_bvp (scipy 1.15.3, integrate/_bvp.py; not part of
+ * /root/reference).  The ODE is linear and its second component decouples, so the collocation
+ * system of _bvp.py:collocation_fun
+ *     y[i+1] - y[i] - h/6 (f[i] + f[i+1] + 4 f_mid) = 0,
+ *     y_mid = (y[i] + y[i+1])/2 - h/8 (f[i+1] - f[i])
+ * has the closed-form solution  v[i+1] = g[i] v[i],  S[i+1] = S[i] + w[i] v[i]  below; the
+ * boundary conditions then fix the scale (bbot given) or the offset (bzbot given).  Newton
+ * in solve_bvp converges to this in one step. */
+void orc_column_equi_pass(const double *x, int m, const double *c_n, const double *c_m,
+                          const double *c_1, const double *c_2, double bs, double bbot,
+                          int use_bzbot, double bzbot, double *y, double *rms) {
+  double *v = y + m, *S = y;
+  v[0] = 1.0;
+  S[0] = 0.0;
+  for (int i = 0; i < m - 1; ++i) {
+    const double h = x[i + 1] - x[i];
+    const double al = 0.5 + h * c_n[i] / 8.0;     /* weight of v[i]   in v_mid */
+    const double be = 0.5 - h * c_n[i + 1] / 8.0; /* weight of v[i+1] in v_mid */
+    const double k4 = 4.0 * h / 6.0 * c_m[i];
+    const double g = (1.0 + h * c_n[i] / 6.0 + k4 * al) / (1.0 - h * c_n[i + 1] / 6.0 - k4 * be);
+    const double w = h / 6.0 * (1.0 + g + 4.0 * (al + be * g));
+    v[i + 1] = g * v[i];
+    S[i + 1] = S[i] + w * v[i];
+  }
+  const double Send = S[m - 1];
+  if (!use_bzbot) { /* bc: y1(a) = bbot, y1(b) = bs   (column.py:156-157) */
+    const double v0 = (bs - bbot) / Send;
+    for (int i = 0; i < m; ++i) {
+      S[i] = bbot + v0 * S[i];
+      v[i] = v0 * v[i];
+    }
+    S[m - 1] = bs;
+  } else { /* bc: y2(a) = bzbot, y1(b) = bs   (column.py:158-159) */
+    for (int i = 0; i < m; ++i) {
+      S[i] = bs - bzbot * (Send - S[i]);
+      v[i] = bzbot * v[i];
+    }
+  }
+  if (!rms) return;
+  /* _bvp.py:estimate_rms_residuals with sol = create_spline(y, f, x, h) */
+  const double s37 = sqrt(3.0 / 7.0);
+  for (int i = 0; i < m - 1; ++i) {
+    const double h = x[i + 1] - x[i];
+    const double ya[2] = {y[i], v[i]}, yb[2] = {y[i + 1], v[i + 1]};
+    const double fa[2] = {v[i], c_n[i] * v[i]}, fb[2] = {v[i + 1], c_n[i + 1] * v[i + 1]};
+    double ymid[2], fmid[2], r_mid = 0., r1 = 0., r2 = 0.;
+    for (int k = 0; k < 2; ++k) ymid[k] = 0.5 * (yb[k] + ya[k]) - 0.125 * h * (fb[k] - fa[k]);
+    fmid[0] = ymid[1];
+    fmid[1] = c_m[i] * ymid[1];
+    const double xm = x[i] + 0.5 * h;
+    const double sh = 0.5 * h * s37;
+    const double t1 = (xm + sh) - x[i], t2 = (xm - sh) - x[i];
+    double y1[2], y2[2], d1[2], d2[2];
+    for (int k = 0; k < 2; ++k) {
+      const double slope = (yb[k] - ya[k]) / h;
+      const double t = (fa[k] + fb[k] - 2 * slope) / h;
+      const double q0 = t / h, q1 = (slope - fa[k]) / h - t, q2 = fa[k], q3 = ya[k];
+      /* PPoly evaluation order (scipy/interpolate/_ppoly.pyx:evaluate_poly1) */
+      y1[k] = q3 + q2 * t1 + q1 * (t1 * t1) + q0 * (t1 * t1 * t1);
+      y2[k] = q3 + q2 * t2 + q1 * (t2 * t2) + q0 * (t2 * t2 * t2);
+      d1[k] = q2 + q1 * t1 * 2.0 + q0 * (t1 * t1) * 3.0;
+      d2[k] = q2 + q1 * t2 * 2.0 + q0 * (t2 * t2) * 3.0;
+      const double col = yb[k] - ya[k] - h / 6 * (fa[k] + fb[k] + 4 * fmid[k]);
+      const double rm = 1.5 * col / h / (1 + fabs(fmid[k]));
+      r_mid += rm * rm;
+    }
+    const double f1[2] = {y1[1], c_1[i] * y1[1]}, f2[2] = {y2[1], c_2[i] * y2[1]};
+    for (int k = 0; k < 2; ++k) {
+      const double a = (d1[k] - f1[k]) / (1 + fabs(f1[k]));
+      const double b = (d2[k] - f2[k]) / (1 + fabs(f2[k]));
+      r1 += a * a;
+      r2 += b * b;
+    }
+    rms[i] = sqrt(0.5 * (32.0 / 45.0 * r_mid + 49.0 / 90.0 * (r1 + r2)));
+  }
+}

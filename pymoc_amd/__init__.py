@@ -11,11 +11,12 @@ from .columns import ColumnBatch
 from .thermwind import ThermwindBatch
 from .psi_so import PsiSOBatch
 from .so_ml import SOMLBatch
+from .equilibrium import ColumnEquiBatch
 from . import modules
 from . import utils
 from .modules import Column, Psi_Thermwind, Psi_SO, SO_ML
 from . import configs
 from . import sharding
-from .ensembles import (ColumnThermwindEnsemble, TwoColEnsemble, JN2018Ensemble,
+from .ensembles import (EquiIterationEnsemble, ColumnThermwindEnsemble, TwoColEnsemble, JN2018Ensemble,
                         TwoBasinEnsemble)
 from . import diagnostics

@@ -76,6 +76,17 @@ class pm_so_ml(C.Structure):
   ]
 
 
+class pm_column_equi(C.Structure):
+  """Mirror of `struct pm_column_equi` (include/pymoc_hip.h)."""
+  _fields_ = [
+      ("n", C.c_int32), ("nz", C.c_int32), ("mmax", C.c_int32), ("reserved", C.c_int32),
+      ("m", c_dp), ("active", c_dp), ("x", c_dp), ("Ak", c_dp), ("dAk", c_dp), ("wA", c_dp),
+      ("wA_z", c_dp), ("z", c_dp), ("bs", c_dp), ("bbot", c_dp), ("bzbot", c_dp),
+      ("flags", c_dp), ("zidx", c_dp), ("tol", C.c_double), ("y", c_dp), ("rms", c_dp),
+      ("nadd", c_dp), ("b", c_dp), ("bz", c_dp)
+  ]
+
+
 class pm_jn2018_bc(C.Structure):
   """Mirror of `struct pm_jn2018_bc` (include/pymoc_hip.h)."""
   _fields_ = [
@@ -137,6 +148,8 @@ SIGNATURES = {
     "pm_jn2018_bc_switch": (C.c_int, [C.POINTER(pm_jn2018_bc), C.c_void_p]),
     "pm_jn2018_steps": (C.c_int, [C.POINTER(pm_jn2018), C.c_double, C.c_int32, C.c_void_p]),
     "pm_twobasin_forcing": (C.c_int, [C.c_int32, C.c_int32] + [c_dp] * 9 + [C.c_void_p]),
+    "pm_column_equi_pass": (C.c_int, [C.POINTER(pm_column_equi), C.c_void_p]),
+    "pm_axpby": (C.c_int, [C.c_size_t, C.c_double, c_dp, C.c_double, c_dp, c_dp, C.c_void_p]),
     "pm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pm_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "pm_comm_destroy": (C.c_int, [C.c_void_p]),

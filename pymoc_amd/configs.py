@@ -185,6 +185,52 @@ def jn2018_member(nz=81, ny=51, dt_days=30., db=0.0, B=5.9e3, kapGM=800., tau=0.
               MOC_up_iters=int(np.floor(1. * 360. * DAY / dt)), nb=500)
 
 
+def single_basin_kappa(z, kapfac=1.0):
+  """`kappa` of examples/run_single_global_basin.py:98-99."""
+  return kapfac * 9e-6 * np.exp(-z / 1200) + 7e-5 * np.exp(z / 50)
+
+
+def single_basin_kappaeff(z, kapfac=1.0):
+  """`kappaeff` (BBL taper) of examples/run_single_global_basin.py:101-103."""
+  return (kapfac * 9e-6 * np.exp(-z / 1200) + 7e-5 * np.exp(z / 50)) * (
+      1. - np.maximum(-4500. - z + 500., 0.) / 500.)**2
+
+
+def single_basin_member(nz=46, ny=51, dt_days=30., bs=0.025, B=5.0e4, Ks=1.0e3, KGM=1.0e3,
+                        tau=0.12, kapfac=1.0):
+  """One `examples/run_single_global_basin.py` member (physics of :38-170, default flags):
+  the JN2018 loop with global-ocean parameters.  Same keys as `jn2018_member`, so
+  `JN2018Ensemble` and `oracle.drivers.run_jn2018` run it unchanged."""
+  bs_north, bminSO = 0.0, 0.0
+  h, L = 50., 2e7
+  Bloss = B / L / 2e5
+  l = 2.e6
+  y = np.linspace(0, l, ny)
+  bs_SO_eq = 0. * y + bminSO
+  alpha = (1. - np.cos(np.pi * (l - y[5]) / 7.4e6))
+  bs_SO_eq[6:] = (bs - bminSO) * (1. - np.cos(np.pi * (y[6:] - y[5]) / 7.4e6)) / alpha + bminSO
+  surflux = 0. * y
+  surflux[1:6] = -Bloss
+  rest_mask = 0. * y
+  rest_mask[6:-1] = 1.
+  A_basin = 3.2e14
+  dt = DAY * dt_days
+  z = np.linspace(-4500., 0., nz)
+  b_basin = bs * np.exp(z / 400.) - 0.0001 * z / z[0]
+  b_north = bs_north - 0.0001 * (z / z[0])**2.
+  bs_SO_init = bs_SO_eq.copy()
+  bs_SO_init[:6] = -0.0001
+  bs_SO = bs_SO_init.copy()
+  bs_SO[-1] = bs  # run_single_global_basin.py:137 (after the initial PsiSO.solve())
+  return dict(z=z, y=y, kappa=single_basin_kappa(z, kapfac),
+              kappaeff=single_basin_kappaeff(z, kapfac), kapfac=kapfac,
+              A_basin=A_basin, A_north=A_basin / 100., bs=bs, bs_north=bs_north, h=h, L=L,
+              Ks=Ks, KGM=KGM, v_pist=1.5 / DAY, tau=tau, f=1.2e-4, surflux=surflux,
+              rest_mask=rest_mask, b_rest=bs_SO_eq, bs_SO_init=bs_SO_init,
+              bs_SO0=bs_SO, b_basin0=b_basin, b_north0=b_north, dt=dt,
+              MOC_up_iters=int(np.floor(2. * 360. * DAY / dt)), nb=500)
+
+
 def config5(N=4096, nz=200, ny=51, dt_days=10., seed=20243, members=None):
   """N run_JansenNadeau_2018 members at nz=200, dt=10 d; sweep db, B, kapGM, tau.
 
@@ -248,3 +294,34 @@ def config_twobasin(N=2048, nz=80, ny=51, seed=20244, members=None):
   out.update(tau=tau[sl], K=K[sl], A_Pac=A_Pac[sl], A_Atl=np.full(n, out['A_Atl']),
              A_north=np.full(n, out['A_north']), nsteps=2400, members=idx)
   return out
+
+
+# ----------------------------------------------------- equilibrium iteration
+def iteration_kappa(z, kappa_back=1e-5, kappa_s=3e-5, kappa_4k=3e-4):
+  """`kappa` of examples/example_iteration.py:24-26."""
+  return kappa_back + kappa_s * np.exp(z / 100) + kappa_4k * np.exp(-z / 1000 - 4)
+
+
+def iteration_member(nz=100, bs=0.03, bbot=-0.0004, A_basin=8e13, kappa_4k=3e-4, f=1.2e-4):
+  """examples/example_iteration.py:13-59: one basin column whose equilibrium profile
+  (`Column.solve_equi`) and thermal-wind overturning against b_N = 0 are iterated with
+  under-relaxation 0.2."""
+  z = np.linspace(-3500, 0, nz)
+  return dict(z=z, bs=bs, bbot=bbot, A_basin=A_basin, kappa_4k=kappa_4k, f=f,
+              kappa=iteration_kappa(z, kappa_4k=kappa_4k),
+              b_basin0=bs * np.exp(z / 300.) + bbot, keep=0.8, relax=0.2, niter=30)
+
+
+def config_iteration(N=256, nz=100, seed=20245, members=None):
+  """Ensemble of `iteration_member`s: kappa_4k in logU[1e-4, 6e-4], A_basin in
+  U[5e13, 1.2e14], bs in U[0.02, 0.04]; kappa is SAMPLED on z (array profile)."""
+  rng = np.random.default_rng(seed)
+  k4 = _logu(rng, 1e-4, 6e-4, N)
+  A = rng.uniform(5e13, 1.2e14, N)
+  bs = rng.uniform(0.02, 0.04, N)
+  sl = _slice(members, N)
+  z = np.linspace(-3500, 0, nz)
+  bbot = -0.0004
+  return dict(z=z, bs=bs[sl], bbot=bbot, A_basin=A[sl], kappa_4k=k4[sl], f=1.2e-4,
+              kappa=np.array([iteration_kappa(z, kappa_4k=k) for k in k4[sl]]),
+              b_basin0=bs[sl][:, None] * np.exp(z / 300.)[None, :] + bbot, keep=0.8, relax=0.2, niter=30)

@@ -125,4 +125,31 @@ struct Linspace {
   }
 };
 
+// np.interp(x, xp, fp) for sorted xp (LDS), single query
+__device__ __forceinline__ double interp_sorted(double x, const double *xp, const double *fp,
+                                                int n) {
+  if (x != x) return x;
+  if (n == 1) return (x < xp[0]) ? fp[0] : ((x > xp[0]) ? fp[n - 1] : fp[0]);
+  if (x > xp[n - 1]) return fp[n - 1];
+  if (x < xp[0]) return fp[0];
+  int lo = 0, hi = n;  // upper bound: first index with xp > x
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (x >= xp[mid])
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  const int j = lo - 1;
+  if (j == n - 1) return fp[j];
+  if (xp[j] == x) return fp[j];
+  const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+  double r = slope * (x - xp[j]) + fp[j];
+  if (r != r) {
+    r = slope * (x - xp[j + 1]) + fp[j + 1];
+    if (r != r && fp[j] == fp[j + 1]) r = fp[j];
+  }
+  return r;
+}
+
 }  // namespace pm

@@ -12,7 +12,10 @@
 //  * ys(b): the reference root-finds bs(y) = b with scipy brentq (xtol 2e-12); bs(y) is an
 //    np.interp closure, i.e. piecewise linear, so the root is taken directly: first
 //    crossing north of argmin(bs), one linear solve.  Agrees with brentq to ~1e-15
-//    relative; members whose bs is not monotone north of its minimum are flagged.
+//    relative.  Members whose bs is NOT monotone north of its minimum have several
+//    crossings and the reference returns whichever one brentq's iteration lands on
+//    (examples/run_single_global_basin.py gets there): those members run brentq itself
+//    (brentq_interp below, SciPy's iteration step for step) and are flagged in `status`.
 //  * GM boundary-value problem (c != None): the reference calls scipy solve_bvp
 //    (4th-order Lobatto IIIA collocation, adaptive mesh, tol 1e-3).  Here the same
 //    collocation scheme runs on the grid refined R-fold; u' is eliminated interval by
@@ -26,31 +29,66 @@ namespace pm {
 
 constexpr int SO_WAVES_PER_BLOCK = 4;
 
-// np.interp(x, xp, fp) for sorted xp (LDS), single query
-__device__ __forceinline__ double interp_sorted(double x, const double *xp, const double *fp,
-                                                int n) {
-  if (x != x) return x;
-  if (n == 1) return (x < xp[0]) ? fp[0] : ((x > xp[0]) ? fp[n - 1] : fp[0]);
-  if (x > xp[n - 1]) return fp[n - 1];
-  if (x < xp[0]) return fp[0];
-  int lo = 0, hi = n;  // upper bound: first index with xp > x
-  while (lo < hi) {
-    const int mid = lo + ((hi - lo) >> 1);
-    if (x >= xp[mid])
-      lo = mid + 1;
+// scipy.optimize.brentq(f, xa, xb) for f(x) = np.interp(x, xp, fp) - target with SciPy's
+// defaults xtol = 2e-12, rtol = 4 eps, maxiter = 100 (scipy/optimize/Zeros/brentq.c,
+// scipy 1.15.3): the same bracketing / secant / inverse-quadratic / bisection decisions in
+// the same arithmetic, so a multi-root bracket ends on the root the reference ends on.
+__device__ __noinline__ double brentq_interp(const double *xp, const double *fp, int n,
+                                             double target, double xa, double xb) {
+  const double xtol = 2e-12, rtol = 8.881784197001252e-16;
+  double xpre = xa, xcur = xb, xblk = 0., fblk = 0., spre = 0., scur = 0.;
+  double fpre = interp_sorted(xpre, xp, fp, n) - target;
+  double fcur = interp_sorted(xcur, xp, fp, n) - target;
+  if (fpre == 0) return xpre;
+  if (fcur == 0) return xcur;
+  if (__builtin_signbit(fpre) == __builtin_signbit(fcur)) return __builtin_nan("");
+  for (int it = 0; it < 100; ++it) {
+    if (fpre != 0 && fcur != 0 && (__builtin_signbit(fpre) != __builtin_signbit(fcur))) {
+      xblk = xpre;
+      fblk = fpre;
+      spre = scur = xcur - xpre;
+    }
+    if (fabs(fblk) < fabs(fcur)) {
+      xpre = xcur;
+      xcur = xblk;
+      xblk = xpre;
+      fpre = fcur;
+      fcur = fblk;
+      fblk = fpre;
+    }
+    const double delta = (xtol + rtol * fabs(xcur)) / 2;
+    const double sbis = (xblk - xcur) / 2;
+    if (fcur == 0 || fabs(sbis) < delta) return xcur;
+    if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+      double stry;
+      if (xpre == xblk) {  // secant
+        stry = -fcur * (xcur - xpre) / (fcur - fpre);
+      } else {  // inverse quadratic
+        const double dpre = (fpre - fcur) / (xpre - xcur);
+        const double dblk = (fblk - fcur) / (xblk - xcur);
+        stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+      }
+      const double lim1 = fabs(spre), lim2 = 3 * fabs(sbis) - delta;
+      if (2 * fabs(stry) < (lim1 < lim2 ? lim1 : lim2)) {
+        spre = scur;
+        scur = stry;
+      } else {
+        spre = sbis;
+        scur = sbis;
+      }
+    } else {
+      spre = sbis;
+      scur = sbis;
+    }
+    xpre = xcur;
+    fpre = fcur;
+    if (fabs(scur) > delta)
+      xcur += scur;
     else
-      hi = mid;
+      xcur += (sbis > 0 ? delta : -delta);
+    fcur = interp_sorted(xcur, xp, fp, n) - target;
   }
-  const int j = lo - 1;
-  if (j == n - 1) return fp[j];
-  if (xp[j] == x) return fp[j];
-  const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
-  double r = slope * (x - xp[j]) + fp[j];
-  if (r != r) {
-    r = slope * (x - xp[j + 1]) + fp[j + 1];
-    if (r != r && fp[j] == fp[j + 1]) r = fp[j];
-  }
-  return r;
+  return xcur;
 }
 
 __device__ __forceinline__ double np_maximum(double a, double b) {
@@ -169,6 +207,8 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
       yv = yN;
     } else if (b[p] != b[p] || bs_nan) {
       yv = __builtin_nan("");
+    } else if (ambiguous) {  // several crossings: the one brentq's iteration finds
+      yv = brentq_interp(s_y, s_bs, ny, b[p], s_y[minind], yN);
     } else {
       int j = minind;
       while (j < ny - 2 && !(s_bs[j + 1] >= b[p])) ++j;  // first crossing north of argmin

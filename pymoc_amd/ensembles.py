@@ -6,6 +6,7 @@ classes here reproduce those loops' order of operations and cadence exactly:
   JN2018Ensemble           examples/run_JansenNadeau_2018.py:201-261 (config 5)
   TwoBasinEnsemble         examples/twobasin_NadeauJansen.py:99-122
   ColumnThermwindEnsemble  examples/example_timestepping.py:73-80   (BASELINE config 1)
+  EquiIterationEnsemble    examples/example_iteration.py:59-68      
   TwoColEnsemble           examples/example_twocol.py:85-96         (config 3)
                            examples/example_twocol_plusSO.py:99-115 (config 4, with_so)
 Each member is independent; `cfg` is a dict from `pymoc_amd.configs`.
@@ -14,7 +15,8 @@ import numpy as np
 
 from . import _lib
 from .columns import ColumnBatch
-from .device import DeviceArray
+from .device import DeviceArray, _sh
+from .equilibrium import ColumnEquiBatch
 from .psi_so import PsiSOBatch
 from .so_ml import SOMLBatch
 from .thermwind import ThermwindBatch
@@ -68,6 +70,45 @@ class ColumnThermwindEnsemble(object):
 
   def state(self):
     return dict(b=self.cols.get_b(), Psi=self.tw.Psi.download())
+
+
+class EquiIterationEnsemble(object):
+  """One basin column per member: its equilibrium profile for the current overturning
+  (`Column.solve_equi`) and the thermal-wind overturning against b_N = 0 for the relaxed
+  profile, iterated (example_iteration.py:59-68):
+      wA = AMOC.Psi*1e6;  basin.solve_equi(wA);
+      AMOC.update(b1 = keep*AMOC.b1(z) + relax*basin.b);  AMOC.solve()"""
+
+  def __init__(self, cfg, stream=None):
+    z = cfg['z']
+    nz = z.size
+    b0 = np.atleast_2d(cfg['b_basin0'])
+    self.n, self.nz = n, _ = b0.shape[0], nz
+    self.keep, self.relax = float(cfg['keep']), float(cfg['relax'])
+    self.stream = stream
+    self.tw = ThermwindBatch(z, n, f=cfg['f'], nb=1, stream=stream)
+    self.b1 = DeviceArray.from_host(_rows(b0, n, nz))
+    self.b2 = DeviceArray.zeros((n, nz))
+    self.wA = DeviceArray.zeros((n, nz))
+    self.eq = ColumnEquiBatch.from_profiles(
+        z, _rows(cfg['kappa'], n, nz), _rows(cfg['A_basin'], n, nz), _vec(cfg['bs'], n),
+        _vec(cfg['bbot'], n), n=n, stream=stream, z_dev=self.tw.z)
+    self._solve()
+
+  def _solve(self):
+    self.tw.update(self.b1, self.b2, ops=_lib.PM_TW_SOLVE | _lib.PM_TW_WA_PSI, wA1=self.wA,
+                   nb=1)
+
+  def iterate(self, niter=1):
+    for _ in range(int(niter)):
+      self.eq.solve(self.wA)
+      _lib.check(_lib.lib.pm_axpby(self.n * self.nz, self.keep, self.b1.ptr, self.relax,
+                                   self.eq.b.ptr, self.b1.ptr, _sh(self.stream)))
+      self._solve()
+
+  def state(self):
+    return dict(b=self.eq.get_b(), bz=self.eq.get_bz(), b1=self.b1.download(),
+                Psi=self.tw.Psi.download())
 
 
 class TwoColEnsemble(object):

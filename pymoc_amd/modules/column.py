@@ -50,10 +50,35 @@ class Column(object):
   def dAkappa_dz(self, z):
     return np.gradient(self.Akappa(z), z)
 
+  def bc(self, ya, yb):
+    """Boundary-condition residuals of the equilibrium problem (column.py:124-159)."""
+    if self.bzbot is None:
+      return np.array([ya[0] - self.bbot, yb[0] - self.bs])
+    else:
+      return np.array([ya[1] - self.bzbot, yb[0] - self.bs])
+
+  def ode(self, z, y):
+    """Right-hand side of the equilibrium problem (column.py:161-185)."""
+    return np.vstack(
+        (y[1], (self.wA(z) - self.dAkappa_dz(z)) / self.Akappa(z) * y[1])
+    )
+
   def solve_equi(self, wA):
-    raise NotImplementedError(
-        'Column.solve_equi (SciPy solve_bvp equilibrium solver, column.py:187-208) is '
-        'outside the timestep() path this engine replaces')
+    """Equilibrium profile for a given wA (column.py:187-208).  The reference calls
+    scipy.integrate.solve_bvp; here solve_bvp's collocation solve and residual estimate
+    run on the GPU (`pm_column_equi_pass`) inside the same mesh-refinement loop, the
+    coefficient functions being sampled wherever that loop asks, as SciPy would."""
+    from ..equilibrium import ColumnEquiBatch
+    self.wA = make_func(wA, self.z, 'w')
+    eq = ColumnEquiBatch(
+        self.z, 1, lambda i, x: self.Akappa(x), lambda i, x: self.dAkappa_dz(x), self.bs,
+        self.bbot, self.bzbot
+    )
+    eq.solve(self.wA)
+    # like the reference, solve_equi REBINDS b and bz (column.py:207-208)
+    self.b = eq.get_b()[0]
+    self.bz = eq.get_bz()[0]
+    self.equi_nodes = int(eq.nodes[0])
 
   # ---- device plumbing: one arena, one H2D and one D2H per call
   # arena (float64 slots): [b | wA | vdx_in | b_in | bs bbot bzbot N2min | flags(int32)]

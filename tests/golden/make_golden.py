@@ -22,6 +22,9 @@ Sets:
                        nz=81/dt=30d and nz=200/dt=10d, steps {1,12,13,...}
   G8 sweep             members of the config-2/3/4/5 ensembles run through the reference
   G9 twobasin          twobasin_NadeauJansen physics (3 columns, 2 thermal winds, 2 SO sectors)
+  G11 single_basin     run_single_global_basin physics (the JN2018 loop, global-ocean parameters)
+  G12 equi             Column.solve_equi I/O (incl. meshes solve_bvp refines, max_nodes hit) and
+                       the example_iteration loop (solve_equi + thermal wind, 30 iterations)
   G10 jn2018_files     the diagnostics / pickup .npz payloads of run_JansenNadeau_2018.py and a
                        restart from the pickup
 """
@@ -300,7 +303,8 @@ def g7_so_ml():
 
 def ref_jn2018(m, nsteps, snaps):
   z, y = m['z'], m['y']
-  kappa, kappaeff = configs.jn2018_kappa, configs.jn2018_kappaeff
+  kappa = m.get('kappa_fn', configs.jn2018_kappa)
+  kappaeff = m.get('kappaeff_fn', configs.jn2018_kappaeff)
   b_basin, b_north, bs_SO = m['b_basin0'].copy(), m['b_north0'].copy(), m['bs_SO_init'].copy()
   AMOC = Psi_Thermwind(z=z, b1=b_basin, b2=b_north, f=m['f'])
   AMOC.solve()
@@ -356,6 +360,125 @@ def g7_jn2018():
   save("jn2018_nz81", **pack("", ref_jn2018(m, 1200, {1, 12, 13, 14, 240, 1200})))
   m = configs.jn2018_member(nz=200, dt_days=10.)
   save("jn2018_nz200", **pack("", ref_jn2018(m, 1200, {1, 36, 37, 38, 360, 1200})))
+
+
+def g11_single_basin():
+  """examples/run_single_global_basin.py (default flags, and a kapfac/tau/KGM variant): the
+  JN2018 loop with global-ocean parameters, nz=46, dt=30 d, MOC update every 24 steps."""
+  for tag, kw in (("", {}), ("v_", dict(kapfac=1.5, tau=0.16, KGM=800., B=3.0e4))):
+    m = configs.single_basin_member(**kw)
+    kf = m['kapfac']
+    m['kappa_fn'] = lambda z, kf=kf: configs.single_basin_kappa(z, kf)
+    m['kappaeff_fn'] = lambda z, kf=kf: configs.single_basin_kappaeff(z, kf)
+    snaps = {1, 24, 25, 26, 240, 1200}
+    save("single_basin" + ("_var" if tag else ""), **pack("", ref_jn2018(m, 1200, snaps)))
+
+
+# ------------------------------------------------------------------------ G12
+def equi_cases():
+  """(name, z, kappa, Area, wA, bs, bbot, bzbot): kappa / Area / wA are arrays or scalars."""
+  m = configs.iteration_member()
+  z = m['z']
+  A0 = Psi_Thermwind(z=z, b1=m['b_basin0'].copy())
+  A0.solve()
+  wA = A0.Psi * 1e6
+  z20 = np.linspace(-3500, 0, 20)
+  wA20 = np.interp(z20, z, wA)
+  k20 = configs.iteration_kappa(z20)
+  zs = -3500. * np.linspace(1., 0., 60)**1.6  # stretched grid, finer near the surface
+  zs[-1] = 0.
+  z40 = np.linspace(-3500, 0, 40)
+  wA40 = np.interp(z40, z, wA)
+  KFN = configs.iteration_kappa  # callable profile: evaluated wherever solve_bvp asks
+  cases = [
+      ("iter_arr", z, m['kappa'], 8e13, wA, 0.03, -0.0004, None),
+      ("iter_fn", z, KFN, 8e13, wA, 0.03, -0.0004, None),
+      ("const", z, 2e-5, 8e13, wA, 0.03, -0.0004, None),
+      ("strong", z, 2e-5, 8e13, 4 * wA, 0.03, -0.0004, None),
+      ("down", z20, k20, 8e13, -2 * wA20, 0.03, -0.0004, None),
+      ("coarse", z20, 2e-5, 8e13, 8 * wA20, 0.03, -0.0004, None),
+      ("coarse30", z20, 1e-5, 8e13, 30 * wA20, 0.03, -0.0004, None),
+      ("stretched", zs, configs.iteration_kappa(zs), 6e13 * (1 + 0.3 * zs / 3500.),
+       np.interp(zs, z, wA), 0.025, 0.0, None),
+      ("zero_w", z, m['kappa'], 8e13, 0. * z, 0.03, -0.0004, None),
+      # prescribed bottom stratification: b' grows like exp(int c), the residuals become
+      # O(1) relative and solve_bvp refines the mesh (20 -> 35 / 40, 40 -> 54, 100 -> 104)
+      ("bz_const20", z20, 2e-5, 8e13, wA20, 0.03, -0.0004, 1e-3),
+      ("bz_fn20", z20, KFN, 8e13, wA20, 0.03, -0.0004, 1e-3),
+      ("bz_fn20b", z20, KFN, 8e13, 0.6 * wA20, 0.03, -0.0004, 1e-3),
+      ("bz_fn40", z40, KFN, 8e13, wA40, 0.03, -0.0004, 1e-3),
+      ("bz_fn100", z, KFN, 8e13, wA, 0.03, -0.0004, 1e-3),
+      ("bz_small", z40, KFN, 8e13, 0.3 * wA40, 0.03, -0.0004, 1e-5),
+      # b' grows by e^36: solve_bvp gives up at max_nodes = 1000 (status 1) and returns the
+      # solution of its last mesh; its Newton iterate (finite-difference Jacobian) is then
+      # only converged to ~1e-5, so this case pins behaviour, not digits
+      ("bz_hit", z20, 2e-5, 8e13, 3 * wA20, 0.03, -0.0004, 1e-3),
+  ]
+  return cases
+
+
+def g12_equi():
+  out = {}
+  names, fn_names = [], []
+  for name, z, kap, A, wA, bs, bbot, bzbot in equi_cases():
+    col = Column(z=z, kappa=kap, Area=A, b=0.0, bs=bs, bbot=bbot, bzbot=bzbot)
+    col.solve_equi(wA)
+    names.append(name)
+    p = name + "_"
+    if callable(kap):
+      fn_names.append(name)
+      kap = kap(z)
+    out.update({p + "z": z, p + "kappa": np.asarray(kap, float), p + "Area": np.asarray(A, float),
+                p + "wA": wA, p + "bs": np.array(bs), p + "bbot": np.array(bbot),
+                p + "bzbot": np.array(np.nan if bzbot is None else bzbot),
+                p + "b": col.b.copy(), p + "bz": col.bz.copy()})
+  # the reference's own unit test of solve_equi (tests/modules/test_column.py:219-245): a
+  # CALLABLE wA, evaluated wherever solve_bvp asks
+  z = np.asarray(np.linspace(-4000, 0, 80))
+  col = Column(Area=6e13, z=z, kappa=2e-5, bs=0.05, bbot=0.02, bzbot=0.01, b=0.03, N2min=2e-7)
+  col.solve_equi(np.sin)
+  out.update(unit_z=z, unit_b=col.b.copy(), unit_bz=col.bz.copy())
+  out["names"] = np.array(names)
+  out["fn_names"] = np.array(fn_names)  # cases whose kappa is configs.iteration_kappa itself
+  save("equi", **out)
+
+  # examples/example_iteration.py:13-72 with the analytic kappa (callable profile) and with
+  # kappa sampled on z (array profile): b and Psi after iterations 1, 2, 10, 30
+  for tag in ("fn", "arr"):
+    m = configs.iteration_member()
+    z = m['z']
+    kappa = configs.iteration_kappa if tag == "fn" else m['kappa']
+    AMOC = Psi_Thermwind(z=z, b1=m['b_basin0'].copy())
+    AMOC.solve()
+    basin = Column(z=z, kappa=kappa, Area=m['A_basin'], b=m['b_basin0'].copy(), bs=m['bs'],
+                   bbot=m['bbot'])
+    snaps = {}
+    for ii in range(30):
+      basin.solve_equi(AMOC.Psi * 1e6)
+      AMOC.update(b1=0.8 * AMOC.b1(z) + 0.2 * basin.b)
+      AMOC.solve()
+      if ii + 1 in (1, 2, 10, 30):
+        snaps[ii + 1] = dict(b=basin.b.copy(), bz=basin.bz.copy(), Psi=AMOC.Psi.copy(),
+                             b1=AMOC.b1(z).copy())
+    save("iteration_" + tag, **pack("", snaps))
+  # four members of the config_iteration ensemble
+  c = configs.config_iteration(N=256)
+  pick = np.array([0, 85, 170, 255])
+  acc = {k: [] for k in ("b", "Psi", "b1")}
+  for i in pick:
+    z = c['z']
+    AMOC = Psi_Thermwind(z=z, b1=c['b_basin0'][i].copy())
+    AMOC.solve()
+    basin = Column(z=z, kappa=c['kappa'][i], Area=c['A_basin'][i], b=c['b_basin0'][i].copy(),
+                   bs=c['bs'][i], bbot=c['bbot'])
+    for ii in range(30):
+      basin.solve_equi(AMOC.Psi * 1e6)
+      AMOC.update(b1=0.8 * AMOC.b1(z) + 0.2 * basin.b)
+      AMOC.solve()
+    acc["b"].append(basin.b.copy())
+    acc["Psi"].append(AMOC.Psi.copy())
+    acc["b1"].append(AMOC.b1(z).copy())
+  save("iteration_sweep", members=pick, **{k: np.array(v) for k, v in acc.items()})
 
 
 # ------------------------------------------------------------------------- G8
@@ -579,10 +702,10 @@ def g9_twobasin():
 
 
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
   table = dict(g1=[g1_column_steps], g2=[g2_config1], g3=[g3_thermwind], g4=[g4_twocol],
                g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
-               g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files])
+               g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi])
   for w in which:
     for fn in table[w]:
       fn()

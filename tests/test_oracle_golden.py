@@ -219,6 +219,61 @@ def test_jn2018_trajectory_golden(name, nz, dtd, steps):
                         "Psi_iso_n", "Psi_s"), TOL_TRAJ)
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("single_basin", {}),
+    ("single_basin_var", dict(kapfac=1.5, tau=0.16, KGM=800., B=3.0e4)),
+])
+def test_single_global_basin_trajectory_golden(name, kw):
+  """examples/run_single_global_basin.py: the JN2018 loop with global-ocean parameters (G11)."""
+  g = load_golden(name)
+  steps = (1, 24, 25, 26, 240, 1200)
+  out = drivers.run_jn2018(configs.single_basin_member(**kw), 1200, set(steps))
+  _check_snaps(out, g, ("b_basin", "b_north", "bs_SO", "Psi", "Psi_SO", "Psi_iso_b",
+                        "Psi_iso_n", "Psi_s"), TOL_TRAJ)
+
+
+# ------------------------------------------------------------------ G12 Column.solve_equi
+def _equi_case(g, name):
+  p = name + "_"
+  bzbot = float(g[p + "bzbot"])
+  kappa = configs.iteration_kappa if name in g["fn_names"] else g[p + "kappa"]
+  return (g[p + "z"], kappa, g[p + "Area"], g[p + "wA"], float(g[p + "bs"]),
+          float(g[p + "bbot"]), None if np.isnan(bzbot) else bzbot)
+
+
+def test_solve_equi_golden():
+  """Column.solve_equi against the reference (SciPy solve_bvp): same meshes, 1e-10."""
+  g = load_golden("equi")
+  refined = 0
+  for name in g["names"]:
+    z, kap, A, wA, bs, bbot, bzbot = _equi_case(g, str(name))
+    b, bz, x, st = O.column_solve_equi(z, drivers.equi_coef(z, kap, A, wA), bs, bbot, bzbot)
+    refined += x.size > z.size
+    if name == "bz_hit":  # solve_bvp stops at max_nodes and returns its last solution
+      assert st == 1 and relerr(b, g[name + "_b"]) <= 1e-3
+      continue
+    assert st == 0
+    # 1e-10: solve_bvp's single Newton step uses a finite-difference Jacobian, which leaves
+    # ~1e-12 of the initial error when the solution is large (the bz_* cases reach 1e5)
+    assert relerr(b, g[name + "_b"]) <= 1e-10, name
+    assert relerr(bz, g[name + "_bz"]) <= 1e-10, name
+  assert refined >= 5
+  z = g["unit_z"]
+  b, bz, _, _ = O.column_solve_equi(z, drivers.equi_coef(z, 2e-5, 6e13, np.sin), 0.05, 0.02, 0.01)
+  assert relerr(b, g["unit_b"]) <= 1e-12 and relerr(bz, g["unit_bz"]) <= 1e-11
+  # the reference's own assertion (tests/modules/test_column.py:238-241)
+  assert all(np.around(b, decimals=2) == np.around(np.linspace(-39.95, 0.05, 80), decimals=2))
+
+
+@pytest.mark.parametrize("tag", ["fn", "arr"])
+def test_iteration_trajectory_golden(tag):
+  g = load_golden("iteration_" + tag)
+  m = configs.iteration_member()
+  out = drivers.run_iteration(m, 30, {1, 2, 10, 30},
+                              kappa=configs.iteration_kappa if tag == "fn" else None)
+  _check_snaps(out, g, ("b", "bz", "Psi", "b1"), 1e-11)
+
+
 # --------------------------------------------------------------------- G8 sweep members
 def _member(cfg, i, keys):
   m = dict(cfg)

@@ -116,6 +116,29 @@ def test_jn2018_trajectory_golden(gpu, name, nz, dtd, steps, use_graph, fused):
       assert relerr(st[k][0], g["s%05d_%s" % (s, k)]) <= 1e-10, (s, k)
 
 
+@pytest.mark.parametrize("name,kw,fused", [
+    ("single_basin", {}, False),
+    ("single_basin", {}, True),
+    ("single_basin_var", dict(kapfac=1.5, tau=0.16, KGM=800., B=3.0e4), True),
+])
+def test_single_global_basin_trajectory_golden(gpu, name, kw, fused):
+  """examples/run_single_global_basin.py (G11): same loop as JN2018, global-ocean parameters,
+  nz=46, MOC update every 24 steps -- through JN2018Ensemble unchanged."""
+  g = load_golden(name)
+  m = configs.single_basin_member(**kw)
+  cfg = dict(m)
+  for k in ("b_basin0", "b_north0", "bs_SO0", "surflux", "b_rest", "rest_mask"):
+    cfg[k] = m[k][None]
+  ens = gpu.JN2018Ensemble(cfg, fused=fused)
+  done = 0
+  for s in (1, 24, 25, 26, 240, 1200):
+    ens.run(s - done)
+    done = s
+    st = ens.state()
+    for k in ("b_basin", "b_north", "bs_SO", "Psi", "Psi_SO", "Psi_iso_b", "Psi_iso_n", "Psi_s"):
+      assert relerr(st[k][0], g["s%05d_%s" % (s, k)]) <= 1e-10, (s, k)
+
+
 def test_jn2018_fused_equals_stepwise_bitwise(gpu):
   """The fused per-block kernel against bc_switch + column_steps + so_ml_step launches."""
   c = configs.config5(N=256)
