@@ -301,6 +301,51 @@ typedef struct pm_column_equi {
 
 int pm_column_equi_pass(const pm_column_equi *eq, pm_stream_t stream);
 
+/* Equi_Column.solve (src/pymoc/modules/equi_column.py:408-435; ode :349-406, bc :286-347,
+ * alpha :231-249, bz :251-284, non-dimensional profiles :116-185): the equilibrium overturning
+ * of a basin as a 4th-order boundary-value problem on z* in [-1, 0], with the cell depth H
+ * either given or an unknown parameter, which the reference solves with
+ * scipy.integrate.solve_bvp.  pm_equi_column_newton is ONE mesh iteration of solve_bvp for n
+ * members (each on its own mesh): solve_newton (forward-difference Jacobians, damped Newton,
+ * <= 8 iterations / 4 Jacobians), the rms residual estimate of every interval, the number of
+ * nodes solve_bvp would insert, and the largest boundary residual.  The caller owns
+ * solve_bvp's outer loop (pymoc_amd/equi_column.py): insert nodes, transfer the solution to
+ * the new mesh with the C1 cubic spline of (y, yp), call again.
+ * Profiles are scalars or samples on the model grid zg (np.interp'ed on the device).      */
+#define PM_EQ_HFREE 1       /* H is an unknown parameter (p in/out), else p = H fixed      */
+#define PM_EQ_HAS_BBOT 2    /* bottom condition d2Psi(-1) = b_bot/H, else d3Psi(-1) = -bz(H) */
+#define PM_EQ_KAPPA_ARRAY 4 /* kappa_z / dkappa_z tables are used instead of the scalar kappa */
+#define PM_EQ_PSI_ARRAY 8   /* psi_z table is used (otherwise psi_so = 0)                  */
+typedef struct pm_equi_column {
+  int32_t n, nzg, mmax, reserved;
+  const int32_t *m;       /* [n] mesh nodes of each member, 3 <= m <= mmax                */
+  const int32_t *active;  /* [n] 0 = skip this member (may be NULL)                       */
+  const double *x;        /* [n][mmax] mesh on [-1, 0]                                    */
+  double *y;              /* [n][4][mmax] in: initial guess; out: final Newton iterate    */
+  double *yp;             /* [n][4][mmax] out: ode(x, y) at the nodes (spline derivatives) */
+  double *p;              /* [n] in/out: H (initial guess -> solution with PM_EQ_HFREE)   */
+  const double *f;        /* [n] Coriolis parameter                                       */
+  const double *A;        /* [n] basin area                                               */
+  const double *bs;       /* [n] -b_s/f^2  (Equi_Column.bs)                               */
+  const double *bb;       /* [n] -b_bot/f^2 (Equi_Column.b_bot) with PM_EQ_HAS_BBOT, else B_int */
+  const double *kappa;    /* [n] scalar diffusivity (ignored with PM_EQ_KAPPA_ARRAY)      */
+  const int32_t *flags;   /* [n] PM_EQ_* */
+  const double *zg;       /* [nzg] the model's z grid for array profiles (NULL if unused) */
+  const double *kappa_z;  /* [n][nzg] kappa on zg                                         */
+  const double *dkappa_z; /* [n][nzg] np.gradient(kappa, zg)                              */
+  const double *psi_z;    /* [n][nzg] psi_so on zg                                        */
+  double tol;             /* solve_bvp's tol = bc_tol (the reference uses the default 1e-3) */
+  double *rms;            /* [n][mmax] out: rms residual of every interval (may be NULL)  */
+  int32_t *nadd;          /* [n] out: nodes solve_bvp would insert (may be NULL)          */
+  int32_t *status;        /* [n] out: 2 = singular Jacobian, else 0 (may be NULL)         */
+  int32_t *niter;         /* [n] out: Newton iterations taken (may be NULL)               */
+  double *info;           /* [n][2] out: max rms residual, max |bc residual| (may be NULL) */
+  double *scratch;        /* [n][pm_equi_column_scratch_doubles(mmax)] workspace          */
+} pm_equi_column;
+
+size_t pm_equi_column_scratch_doubles(int32_t mmax);
+int pm_equi_column_newton(const pm_equi_column *eq, pm_stream_t stream);
+
 /* out[i] = alpha*x[i] + beta*y[i] (two products, one sum, in that order): the relaxation
  * b1 <- 0.8*b1 + 0.2*basin.b of examples/example_iteration.py:67.                         */
 int pm_axpby(size_t count, double alpha, const double *x, double beta, const double *y,

@@ -12,9 +12,10 @@ from .thermwind import ThermwindBatch
 from .psi_so import PsiSOBatch
 from .so_ml import SOMLBatch
 from .equilibrium import ColumnEquiBatch
+from .equi_column import EquiColumnBatch
 from . import modules
 from . import utils
-from .modules import Column, Psi_Thermwind, Psi_SO, SO_ML
+from .modules import Column, Psi_Thermwind, Psi_SO, SO_ML, Equi_Column
 from . import configs
 from . import sharding
 from .ensembles import (EquiIterationEnsemble, ColumnThermwindEnsemble, TwoColEnsemble, JN2018Ensemble,

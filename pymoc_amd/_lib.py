@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpymoc_hip.so")
 PM_OK, PM_EINVAL, PM_EHIP, PM_ENCCL, PM_ENODEV = 0, 1, 2, 3, 4
 
 PM_COL_DO_CONV, PM_COL_BZBOT = 1, 2
+PM_EQ_HFREE, PM_EQ_HAS_BBOT, PM_EQ_KAPPA_ARRAY, PM_EQ_PSI_ARRAY = 1, 2, 4, 8
 PM_OP_CONVECT, PM_OP_VERTADVDIFF, PM_OP_HORADV, PM_OP_TIMESTEP = 1, 2, 4, 7
 
 c_dp = C.c_void_p  # device pointers travel as plain addresses
@@ -87,6 +88,18 @@ class pm_column_equi(C.Structure):
   ]
 
 
+class pm_equi_column(C.Structure):
+  """Mirror of `struct pm_equi_column` (include/pymoc_hip.h)."""
+  _fields_ = [
+      ("n", C.c_int32), ("nzg", C.c_int32), ("mmax", C.c_int32), ("reserved", C.c_int32),
+      ("m", c_dp), ("active", c_dp), ("x", c_dp), ("y", c_dp), ("yp", c_dp), ("p", c_dp),
+      ("f", c_dp), ("A", c_dp), ("bs", c_dp), ("bb", c_dp), ("kappa", c_dp), ("flags", c_dp),
+      ("zg", c_dp), ("kappa_z", c_dp), ("dkappa_z", c_dp), ("psi_z", c_dp),
+      ("tol", C.c_double), ("rms", c_dp), ("nadd", c_dp), ("status", c_dp), ("niter", c_dp),
+      ("info", c_dp), ("scratch", c_dp)
+  ]
+
+
 class pm_jn2018_bc(C.Structure):
   """Mirror of `struct pm_jn2018_bc` (include/pymoc_hip.h)."""
   _fields_ = [
@@ -149,6 +162,8 @@ SIGNATURES = {
     "pm_jn2018_steps": (C.c_int, [C.POINTER(pm_jn2018), C.c_double, C.c_int32, C.c_void_p]),
     "pm_twobasin_forcing": (C.c_int, [C.c_int32, C.c_int32] + [c_dp] * 9 + [C.c_void_p]),
     "pm_column_equi_pass": (C.c_int, [C.POINTER(pm_column_equi), C.c_void_p]),
+    "pm_equi_column_scratch_doubles": (C.c_size_t, [C.c_int32]),
+    "pm_equi_column_newton": (C.c_int, [C.POINTER(pm_equi_column), C.c_void_p]),
     "pm_axpby": (C.c_int, [C.c_size_t, C.c_double, c_dp, C.c_double, c_dp, c_dp, C.c_void_p]),
     "pm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pm_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),

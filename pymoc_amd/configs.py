@@ -325,3 +325,30 @@ def config_iteration(N=256, nz=100, seed=20245, members=None):
   return dict(z=z, bs=bs[sl], bbot=bbot, A_basin=A[sl], kappa_4k=k4[sl], f=1.2e-4,
               kappa=np.array([iteration_kappa(z, kappa_4k=k) for k in k4[sl]]),
               b_basin0=bs[sl][:, None] * np.exp(z / 300.)[None, :] + bbot, keep=0.8, relax=0.2, niter=30)
+
+
+# ------------------------------------------------------------- Equi_Column
+def equi_column_cases():
+  """Named `Equi_Column` problems (profiles as numbers / arrays on z, the forms the device
+  solves): the two example scripts (examples/example_Equi_diffusive_thermocline.py:11-21,
+  examples/example_Equi_Bint.py:16-60 with its callables sampled on a 161-level grid) and the
+  constructor configurations of the reference's tests (tests/modules/test_equi_column.py:13-112)."""
+  z80 = np.linspace(-4000, 0, 80)
+  z161 = np.linspace(-4000, 0, 161)
+  a = 6.37e6
+  A = 2 * np.pi * a**2 * 59 / 360 * (np.sin(np.radians(69)) - np.sin(np.radians(-48)))
+  kap = iteration_kappa(z161)
+  cases = {
+      "thermocline": dict(A=1.0e14, b_bot=0.0, b_s=0.02, f=1e-4, kappa=5.0e-5, H=4000.0, nz=200),
+      "Hfree_const": dict(B_int=3e3, A=2.0e14, kappa=3e-5),
+      "H500": dict(z=z80, B_int=3e3, A=2.0e14, kappa=3e-5, H=500.0),
+      "H500_kappa_arr": dict(z=z80, B_int=3e3, A=2.0e14, kappa=np.linspace(3e-5, 1e-5, 80),
+                             H=500.0),
+      "H500_bs": dict(z=z80, A=2.0e14, kappa=3e-5, H=500.0, b_s=0.05),
+      "bbot_fixedH": dict(z=z80, A=1.0e14, kappa=5e-5, H=3000.0, B_int=None, b_bot=0.002,
+                          b_s=0.02, f=1e-4),
+  }
+  for i, (Hm, B) in enumerate(((2000, 3e3), (2000, 1.2e4), (1500, 3e3), (1500, 1.2e4))):
+    pso = 4e6 * np.sin(-np.pi * np.maximum(z161, -Hm) / Hm)**2
+    cases["Bint%d" % i] = dict(B_int=B, A=A, kappa=kap, psi_so=pso, z=z161)
+  return cases

@@ -1,0 +1,166 @@
+"""Drop-in `Equi_Column` with the reference's Python API, solved on the GPU.
+
+Same constructor, attributes and method names as `pymoc.modules.Equi_Column`
+(src/pymoc/modules/equi_column.py:6-435).  The helper methods (`alpha`, `bz`, `bc`, `ode`,
+the non-dimensional profile closures) are host NumPy, as in the reference -- they are what
+SciPy would call back into; `solve()` hands the problem to `pymoc_amd.EquiColumnBatch`, which
+runs solve_bvp's Newton iteration and residual control on the device.
+
+Deviation: `kappa` / `psi_so` given as CALLABLES cannot be solved here (`solve()` raises
+NotImplementedError): the reference calls them with the unknown depth H inside every Newton
+step, which has no device counterpart.  Pass samples on `z` instead -- the reference treats
+those as np.interp closures and so does the kernel.
+"""
+import numpy as np
+
+
+class Equi_Column(object):
+  def __init__(
+      self,
+      f=1.2e-4,
+      b_s=0.025,
+      b_bot=None,
+      B_int=3e3,
+      A=7e13,
+      nz=100,
+      sol_init=None,
+      H_guess=1500.,
+      kappa=6e-5,
+      dkappa_dz=None,
+      psi_so=None,
+      z=None,
+      H=None,
+  ):
+    self.f = f
+    self.A = A
+    self.H = H
+    self.H_guess = H_guess
+    self.z = z
+    self.zi = np.asarray(np.linspace(-1, 0, nz))
+    self._nz = nz
+    self._kappa_in, self._psi_in, self._sol_init_in = kappa, psi_so, sol_init
+    self.kappa = self.init_kappa(kappa)
+    self.dkappa_dz = self.init_dkappa_dz(kappa, dkappa_dz)
+    self.init_psi_so(psi_so)
+    self.init_b_boundaries(b_s, b_bot, B_int)
+    self.sol_init = self.calc_sol_init(sol_init, nz, b_bot)
+
+  # ---- non-dimensional profiles, functions of (z*, H)  (equi_column.py:101-185)
+  def init_kappa(self, kappa):
+    scale = lambda H: H**2 * self.f
+    if callable(kappa):
+      return lambda z, H: kappa(z * H) / scale(H)
+    if isinstance(kappa, np.ndarray):
+      return lambda z, H: np.interp(z * H, self.z, kappa) / scale(H)
+    return lambda z, H: kappa / scale(H)
+
+  def init_dkappa_dz(self, kappa, dkappa_dz=None):
+    if callable(kappa) and callable(dkappa_dz):
+      return lambda z, H: dkappa_dz(z * H) / (H * self.f)
+    if callable(kappa):
+      return lambda z, H: np.gradient(kappa(z * H), z * H) / (H * self.f)
+    if isinstance(kappa, np.ndarray):
+      slope = np.gradient(kappa, self.z)
+      return lambda z, H: np.interp(z * H, self.z, slope) / (H * self.f)
+    return lambda z, H: 0
+
+  def init_psi_so(self, psi_so=None):
+    if callable(psi_so):
+      self.psi_so = lambda z, H: psi_so(z * H) / (self.f * H**3)
+    elif isinstance(psi_so, np.ndarray):
+      self.psi_so = lambda z, H: np.interp(z * H, self.z, psi_so) / (self.f * H**3)
+    else:
+      self.psi_so = lambda z, H: 0
+
+  def calc_sol_init(self, sol_init, nz=None, b_bot=None):
+    if sol_init is not None:
+      return sol_init
+    if nz is None:
+      nz = len(self.z)
+    guess = np.zeros((4, nz))
+    guess[0, :] = 1.0
+    guess[3, :] = -100.0 if b_bot is not None else -self.bz(1500.)
+    return guess
+
+  def init_b_boundaries(self, b_s, b_bot=None, B_int=None):
+    if b_bot is None and B_int is None:
+      raise Exception(
+          'You need to specify either b_bot or B_int for bottom boundary condition'
+      )
+    self.bs = -b_s / self.f**2
+    if b_bot is not None:
+      self.b_bot = -b_bot / self.f**2
+    else:
+      self.B_int = B_int
+
+  def alpha(self, z, H):
+    return H**2 / (self.A * self.kappa(z, H))
+
+  def bz(self, H):
+    return self.B_int / (self.f**3 * H**2 * self.A * self.kappa(-1, H))
+
+  # ---- what SciPy would call back into (equi_column.py:286-406)
+  def bc(self, ya, yb, p=None):
+    try:
+      depth = p[0] if self.H is None else self.H
+      res = [ya[0], yb[0]]
+      if self.H is None:
+        res.append(ya[1])
+      if getattr(self, 'b_bot', None) is not None:
+        res.append(ya[2] - self.b_bot / depth)
+      else:
+        res.append(ya[3] + self.bz(depth))
+      res.append(yb[2] - self.bs / depth)
+      return np.array(res)
+    except TypeError:
+      raise TypeError(
+          'Must provide a p array if column does not have an H value'
+      )
+
+  def ode(self, z, y, p=None):
+    if self.H is None and p is not None and len(p) > 0:
+      H = p[0]
+    elif self.H is not None:
+      H = self.H
+    else:
+      raise TypeError(
+          'Must provide a p array if column does not have an H value'
+      )
+    forcing = y[0] - self.psi_so(z, H) - self.A * self.dkappa_dz(z, H) / (H**2)
+    return np.vstack((y[1], y[2], y[3], self.alpha(z, H) * y[3] * forcing))
+
+  # ---- equi_column.py:408-435
+  def solve(self):
+    from ..equi_column import EquiColumnBatch
+    if callable(self._kappa_in) or callable(self._psi_in):
+      raise NotImplementedError(
+          'Equi_Column.solve on the GPU needs kappa / psi_so as numbers or as arrays on z '
+          '(callables are evaluated with the unknown depth H inside every Newton step of '
+          'scipy.integrate.solve_bvp and have no device counterpart)')
+    bbot_set = getattr(self, 'b_bot', None) is not None
+    f2 = self.f**2
+    eq = EquiColumnBatch(
+        1, f=self.f, b_s=-self.bs * f2, b_bot=-self.b_bot * f2 if bbot_set else None,
+        B_int=None if bbot_set else self.B_int, A=self.A, nz=np.shape(self.sol_init)[1],
+        sol_init=np.asarray(self.sol_init, dtype=np.float64)[None], H_guess=self.H_guess,
+        kappa=self._kappa_in, psi_so=self._psi_in, z=self.z, H=self.H)
+    eq.zi = self.zi
+    eq.bs[:] = self.bs  # exactly the reference's non-dimensional values
+    if bbot_set:
+      eq.bb[:] = self.b_bot
+    eq.solve()
+    self._eq = eq
+    x, y = eq.x[0], eq.y[0]
+    if self.H is None:
+      self.H = eq.H[0]
+    self.status = int(eq.status[0])
+    if self.z is None:
+      self.z = x * self.H
+      self.psi = y[0, :] * self.f * self.H**3 / 1e6
+      self.b = -y[2, :] * self.f**2 * self.H
+    else:
+      sol = eq.sol(0, self.z / self.H)
+      self.psi = sol[0, :] * self.f * self.H**3 / 1e6
+      self.psi[self.z < -self.H] = np.nan
+      self.b = -sol[2, :] * self.f**2 * self.H
+      self.b[self.z < -self.H] = np.nan

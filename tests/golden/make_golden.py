@@ -25,6 +25,8 @@ Sets:
   G11 single_basin     run_single_global_basin physics (the JN2018 loop, global-ocean parameters)
   G12 equi             Column.solve_equi I/O (incl. meshes solve_bvp refines, max_nodes hit) and
                        the example_iteration loop (solve_equi + thermal wind, 30 iterations)
+  G13 equi_column      Equi_Column.solve outputs (z, psi, b, H) for the example scripts' problems
+                       and the reference tests' configurations (np.NaN restored for NumPy 2)
   G10 jn2018_files     the diagnostics / pickup .npz payloads of run_JansenNadeau_2018.py and a
                        restart from the pickup
 """
@@ -42,7 +44,7 @@ sys.path.insert(0, os.environ.get("PYMOC_REFERENCE_SRC", "/root/reference/src"))
 import numpy as np
 import scipy
 
-from pymoc.modules import Column, Psi_Thermwind, Psi_SO, SO_ML  # the REFERENCE
+from pymoc.modules import Column, Psi_Thermwind, Psi_SO, SO_ML, Equi_Column  # the REFERENCE
 from pymoc_amd import configs  # parameter tables only
 
 warnings.simplefilter("ignore")  # the reference divides by zero in Psib (hazard H6)
@@ -481,6 +483,23 @@ def g12_equi():
   save("iteration_sweep", members=pick, **{k: np.array(v) for k, v in acc.items()})
 
 
+# ------------------------------------------------------------------------ G13
+def g13_equi_column():
+  # equi_column.py:433,435 spell nan as `np.NaN`, which NumPy 2 removed: restore the alias for
+  # this run (an environment shim, not a change to the reference)
+  if not hasattr(np, "NaN"):
+    np.NaN = np.nan
+  out, names = {}, []
+  for name, kw in configs.equi_column_cases().items():
+    m = Equi_Column(**kw)
+    m.solve()
+    names.append(name)
+    out.update({name + "_z": m.z, name + "_psi": m.psi, name + "_b": m.b,
+                name + "_H": np.array(m.H)})
+  out["names"] = np.array(names)
+  save("equi_column", **out)
+
+
 # ------------------------------------------------------------------------- G8
 def member_of(cfg, i, keys_1d=(), keys_2d=()):
   m = dict(cfg)
@@ -702,10 +721,10 @@ def g9_twobasin():
 
 
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
   table = dict(g1=[g1_column_steps], g2=[g2_config1], g3=[g3_thermwind], g4=[g4_twocol],
                g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
-               g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi])
+               g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column])
   for w in which:
     for fn in table[w]:
       fn()

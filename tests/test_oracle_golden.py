@@ -274,6 +274,23 @@ def test_iteration_trajectory_golden(tag):
   _check_snaps(out, g, ("b", "bz", "Psi", "b1"), 1e-11)
 
 
+# -------------------------------------------------------------------- G13 Equi_Column.solve
+def test_equi_column_golden():
+  """The restated Equi_Column problem + SciPy's solve_bvp against the reference's outputs."""
+  from oracle import equi_column as EO
+  g = load_golden("equi_column")
+  cases = configs.equi_column_cases()
+  assert sorted(cases) == sorted(str(n) for n in g["names"])
+  for name, kw in cases.items():
+    q = EO.problem(**kw)
+    r = EO.solve(q)
+    z, psi, b = EO.outputs(q, r)
+    assert r["status"] == 0, name
+    assert relerr(z, g[name + "_z"]) <= 1e-14, name
+    assert relerr(psi, g[name + "_psi"]) <= 1e-12 and relerr(b, g[name + "_b"]) <= 1e-12, name
+    assert abs(r["H"] - float(g[name + "_H"])) <= 1e-12 * abs(r["H"]), name
+
+
 # --------------------------------------------------------------------- G8 sweep members
 def _member(cfg, i, keys):
   m = dict(cfg)
