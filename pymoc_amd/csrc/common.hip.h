@@ -35,25 +35,17 @@ constexpr int WAVE = 64;
 //                      wave_shr:1 = 0x138 (lane i <- lane i-1).
 // Lanes without a source keep their own value (bound_ctrl = 0, old = src).
 __device__ __forceinline__ double from_next_lane(double x) {
-#ifdef PM_NO_DPP
-  return __shfl_down(x, 1, WAVE);
-#else
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
   hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
-#endif
 }
 
 __device__ __forceinline__ double from_prev_lane(double x) {
-#ifdef PM_NO_DPP
-  return __shfl_up(x, 1, WAVE);
-#else
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
   hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
-#endif
 }
 
 // ---------------------------------------------------------------- exact division

@@ -48,6 +48,46 @@ def test_no_device_fails_loudly():
     col.timestep(wA=0., dt=1.)
 
 
+def test_cabi_rejects_bad_arguments_before_touching_the_device():
+  """Every compute entry validates shapes / pointers first and reports through
+  pm_last_error; none of these calls reaches a launch, so they run without a GPU."""
+  from pymoc_amd import _lib
+  L, C = _lib.lib, ctypes
+
+  def err():
+    return L.pm_last_error().decode()
+
+  c = _lib.pm_columns()
+  c.ncols, c.nz, c.nsel = 4, 1, 1
+  assert L.pm_column_steps(C.byref(c), None, None, None, 1., 1, 7, 0, None) == _lib.PM_EINVAL
+  assert "nz" in err()
+  c.nz = 10
+  assert L.pm_column_steps(C.byref(c), None, None, None, 1., 1, 7, 0, None) == _lib.PM_EINVAL
+  assert "NULL" in err()
+  assert L.pm_column_steps(None, None, None, None, 1., 1, 7, 0, None) == _lib.PM_EINVAL
+  c.ncols = 0  # an empty batch is fine, pointers may be NULL
+  assert L.pm_column_steps(C.byref(c), None, None, None, 1., 1, 7, 0, None) == _lib.PM_OK
+  t = _lib.pm_thermwind()
+  t.n, t.nz, t.nb = 2, 1, 10
+  assert L.pm_thermwind_update(C.byref(t), 1, None) == _lib.PM_EINVAL
+  so = _lib.pm_psi_so()
+  so.n, so.nz, so.ny = 2, 1, 10
+  assert L.pm_psi_so_update(C.byref(so), 1, None) == _lib.PM_EINVAL
+  ml = _lib.pm_so_ml()
+  ml.n, ml.nz, ml.ny = 2, 10, 2
+  assert L.pm_so_ml_step(C.byref(ml), 1., None) == _lib.PM_EINVAL
+  eq = _lib.pm_column_equi()
+  eq.n, eq.nz, eq.mmax, eq.tol = 2, 10, 2000, 1e-3
+  assert L.pm_column_equi_pass(C.byref(eq), None) == _lib.PM_EINVAL
+  assert "mmax" in err()
+  ec = _lib.pm_equi_column()
+  ec.n, ec.mmax, ec.tol = 2, 64, 1e-3
+  assert L.pm_equi_column_newton(C.byref(ec), None) == _lib.PM_EINVAL
+  assert "NULL" in err()
+  assert L.pm_axpby(4, 1., None, 1., None, None, None) == _lib.PM_EINVAL
+  assert L.pm_equi_column_scratch_doubles(64) >= 64 * 100
+
+
 def test_product_does_not_import_oracle():
   pkg = os.path.join(ROOT, "pymoc_amd")
   for dirpath, _, files in os.walk(pkg):
