@@ -3,8 +3,9 @@
 Same constructor, attributes, methods and error text as `pymoc.modules.Psi_SO`
 (src/pymoc/modules/psi_SO.py:8-375).  `b`, `bs`, `tau` given as callables are sampled on
 their grid (`z` / `y`) and interpolated linearly in between; array and float inputs behave
-exactly like the reference.  `ys` is the direct inverse of the piecewise-linear bs(y)
-(the reference root-finds it with brentq to xtol=2e-12); the GM boundary-value problem
+exactly like the reference.  `ys` is the direct inverse of the piecewise-linear bs(y) where
+that is unique (the reference root-finds it with brentq to xtol=2e-12) and brentq's own
+iteration where bs is not monotone; the GM boundary-value problem
 (`c` not None) is solved by 4th-order collocation on a refined fixed mesh instead of
 SciPy's adaptive solve_bvp (agreement ~1e-6).
 """
@@ -12,7 +13,6 @@ import numpy as np
 
 from .. import _lib
 from ..device import DeviceArray
-from ..psi_so import PsiSOBatch
 from ..utils import make_func, make_array
 
 
@@ -61,37 +61,70 @@ class Psi_SO(object):
     self.Htapertop = Htapertop
     self.Htaperbot = Htaperbot
     self.smax = smax
-    self._batch = None
+    self._arena = None
 
-  # ---- device plumbing
-  def _run(self, ops, b=None):
+  # ---- device plumbing: one arena, one H2D and one D2H per call
+  # arena (float64 slots): [b | bs | tau | KGM | Psi_Ek | Psi | Psi_GM | Ek_raw | GM_raw | ys]
+  def _alloc(self):
     nz, ny = np.size(self.z), np.size(self.y)
-    if self._batch is None:
-      self._batch = PsiSOBatch(self.z, self.y, 1, tau=0.0, diagnostics=True)
-      self._b = DeviceArray((1, nz))
-      self._bs = DeviceArray((1, ny))
-    t = self._batch
-    t.opts = dict(f=self.f, rho=self.rho, L=self.L, c=self.c, bvp_with_Ek=self.bvp_with_Ek,
-                  Hsill=self.Hsill, HEk=self.HEk, Htapertop=self.Htapertop,
-                  Htaperbot=self.Htaperbot, smax=self.smax)
-    t.set_KGM(float(self.KGM))
+    self._nz, self._ny = nz, ny
+    self._nin = nz + 2 * ny + 1 + nz
+    self._host = np.zeros(self._nin)
+    self._out = np.zeros((6, nz))
+    self._arena = DeviceArray((self._nin + 5 * nz,))
+    self._zd = DeviceArray.from_host(np.ascontiguousarray(self.z, dtype=np.float64))
+    self._yd = DeviceArray.from_host(np.ascontiguousarray(self.y, dtype=np.float64))
+    self._status = DeviceArray.zeros((1,), np.int32)
+    p, d = self._arena.ptr, _lib.pm_psi_so()
+    d.n, d.nz, d.ny, d.reserved = 1, nz, ny, 0
+    d.z, d.y = self._zd.ptr, self._yd.ptr
+    off = lambda k: p + 8 * k
+    d.b, d.bs, d.tau, d.KGM = off(0), off(nz), off(nz + ny), off(nz + 2 * ny)
+    o = nz + 2 * ny + 1
+    d.Psi_Ek, d.Psi, d.Psi_GM = off(o), off(o + nz), off(o + 2 * nz)
+    d.Ek_raw, d.GM_raw, d.ys = off(o + 3 * nz), off(o + 4 * nz), off(o + 5 * nz)
+    d.status = self._status.ptr
+    self._desc, self._out_ptr = d, off(o)
+
+  def _run(self, ops, b=None):
+    import ctypes as C
+    if getattr(self, "_arena", None) is None or self._nz != np.size(self.z) or \
+        self._ny != np.size(self.y):
+      self._alloc()
+    nz, ny, h, d = self._nz, self._ny, self._host, self._desc
+    fl = 0
+    for name, bit in (("c", _lib.PM_SO_HAS_C), ("Hsill", _lib.PM_SO_HAS_HSILL),
+                      ("HEk", _lib.PM_SO_HAS_HEK), ("Htapertop", _lib.PM_SO_HAS_HTAPERTOP),
+                      ("Htaperbot", _lib.PM_SO_HAS_HTAPERBOT)):
+      v = getattr(self, name)
+      if v is not None:
+        fl |= bit
+      setattr(d, name, float(v) if v is not None else 0.0)
+    if self.bvp_with_Ek:
+      fl |= _lib.PM_SO_BVP_WITH_EK
+    h[0:nz] = make_array(self.b, self.z, 'b') if b is None else b
+    h[nz:nz + ny] = make_array(self.bs, self.y, 'bs')
     if self._tau_is_float:
-      t.set_tau(float(self._tau_float))
+      h[nz + ny] = self._tau_float
     else:
-      t.set_tau(np.asarray(make_array(self.tau, self.y, 'tau'), dtype=np.float64)[None, :] +
-                0 * self.y)
-    barr = make_array(self.b, self.z, 'b') if b is None else b
-    self._b.upload(np.asarray(barr, dtype=np.float64) + 0 * self.z)
-    self._bs.upload(np.asarray(make_array(self.bs, self.y, 'bs'), dtype=np.float64) + 0 * self.y)
+      fl |= _lib.PM_SO_TAU_ARRAY
+      h[nz + ny:nz + 2 * ny] = make_array(self.tau, self.y, 'tau')
+    h[nz + 2 * ny] = self.KGM
     if ops == _lib.PM_SO_OP_GM:
-      t.Psi_Ek.upload(np.asarray(self.Psi_Ek, dtype=np.float64)[None, :])
-    t.update(self._b, self._bs, ops=ops)
-    return t
+      h[nz + 2 * ny + 1:] = self.Psi_Ek
+    d.flags, d.bvp_refine = fl, 0
+    d.f, d.rho, d.L, d.smax = float(self.f), float(self.rho), float(self.L), float(self.smax)
+    self._arena_upload(h)
+    _lib.check(_lib.lib.pm_psi_so_update(C.byref(d), int(ops), None))
+    _lib.check(_lib.lib.pm_memcpy_d2h(self._out.ctypes.data, self._out_ptr, 6 * nz * 8, None))
+    return self._out
+
+  def _arena_upload(self, h):
+    _lib.check(_lib.lib.pm_memcpy_h2d(self._arena.ptr, h.ctypes.data, h.nbytes, None))
 
   # ---- API (psi_SO.py:106-375)
   def ys(self, b):
-    t = self._run(_lib.PM_SO_OP_EKMAN, b=float(b) + 0 * self.z)
-    return t.ys.download()[0, 0]
+    return self._run(_lib.PM_SO_OP_EKMAN, b=float(b) + 0 * self.z)[5, 0]
 
   def calc_N2(self):
     dz = self.z[1:] - self.z[:-1]
@@ -103,16 +136,16 @@ class Psi_SO(object):
     return make_func(N2, self.z, 'N2')
 
   def calc_Ekman(self):
-    return self._run(_lib.PM_SO_OP_EKMAN).Ek_raw.download()[0]
+    return self._run(_lib.PM_SO_OP_EKMAN)[3].copy()
 
   def calc_GM(self):
-    return self._run(_lib.PM_SO_OP_GM).GM_raw.download()[0]
+    return self._run(_lib.PM_SO_OP_GM)[4].copy()
 
   def solve(self):
-    t = self._run(_lib.PM_SO_OP_SOLVE)
-    self.Psi_Ek = t.Psi_Ek.download()[0]
-    self.Psi_GM = t.Psi_GM.download()[0]
-    self.Psi = t.Psi.download()[0]
+    out = self._run(_lib.PM_SO_OP_SOLVE)
+    self.Psi_Ek = out[0].copy()
+    self.Psi = out[1].copy()
+    self.Psi_GM = out[2].copy()
 
   def update(self, b=None, bs=None):
     if b is not None:
