@@ -1,1 +1,1 @@
-from .coerce import make_func, make_array
+from .coerce import make_func, make_array, check_numpy_version

@@ -31,3 +31,10 @@ def make_array(myst, axis, name):
   if isinstance(myst, float):
     return myst + 0 * axis
   raise TypeError(name, _MSG)
+
+
+def check_numpy_version():
+  """True when NumPy can differentiate on non-uniform grids (np.gradient with coordinate
+  arrays, NumPy >= 1.13) -- the reference's guard (utils/check_numpy_version.py:4-22)."""
+  major, minor = (int(p) for p in np.version.version.split('.')[:2])
+  return (major, minor) >= (1, 13)
