@@ -212,7 +212,8 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
       if (lvl0 + lg * P + p == nz - 1) r.b[p] = bs;
   }
   // b at the level above each owned level
-  const double nb0 = from_next_lane(r.b[0]);
+  // edge lanes only need a finite value here (their levels are boundary / padding slots)
+  const double nb0 = from_next_lane_z(r.b[0]);
   double bup[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) bup[p] = (p < P - 1) ? r.b[p + 1 < P ? p + 1 : p] : nb0;
@@ -250,7 +251,7 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
       for (int p = 0; p < P; ++p) bz[p] = (lvl0 + lg * P + p < nz - 1) ? q[p] : 0.0;
     }
   }
-  const double pbz = from_prev_lane(bz[P - 1]);
+  const double pbz = from_prev_lane_z(bz[P - 1]);
   double bz_dn[P], dbz[P], flx[P], bzz[P], adv[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -408,6 +409,16 @@ __global__ __launch_bounds__(256) void k_column_steps(
         col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);  // step 0: establishes cc
         if (lg == 0) r.b[0] = bbot;
         col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
+        double adjv[P];  // column.py:268 for the cached zconv: changes only with the pattern
+        double bs_eff[P];  // bs for real levels, +inf for padding: `b > bs_eff` is the whole test
+        bool not_bottom[P], is_top[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          adjv[p] = bs + N2min * (g.z[p] - cc.zconv);
+          bs_eff[p] = (lane * P + p < nz) ? bs : __builtin_inf();
+          not_bottom[p] = lane * P + p != 0;
+          is_top[p] = lane * P + p == nz - 1;
+        }
         for (int s = 1; s < nsteps; ++s) {
           double b_old[P];
           unsigned long long im[P];
@@ -417,13 +428,13 @@ __global__ __launch_bounds__(256) void k_column_steps(
 #pragma unroll
           for (int p = 0; p < P; ++p) {
             b_old[p] = r.b[p];
-            const bool ind = (lane * P + p < nz) && (r.b[p] > bs);  // column.py:264
+            const bool ind = r.b[p] > bs_eff[p];  // column.py:264
             im[p] = __builtin_amdgcn_ballot_w64(ind);
-            const double adj = bs + N2min * (g.z[p] - cc.zconv);     // column.py:268
-            r.b[p] = ind ? adj : r.b[p];
-            if (lane * P + p == nz - 1) r.b[p] = none_all ? bs : r.b[p];  // column.py:271
+            // level 0 is left alone: whatever convect writes there, column.py:232 replaces
+            // it with bbot before it is read, and bbot is what the slot already holds
+            r.b[p] = (ind && not_bottom[p]) ? adjv[p] : r.b[p];
+            r.b[p] = (is_top[p] && none_all) ? bs : r.b[p];  // column.py:271
           }
-          if (lg == 0) r.b[0] = bbot;  // column.py:232
           col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
 #pragma unroll
           for (int p = 0; p < P; ++p) same = same && (im[p] == cc.mask[p]);
@@ -433,6 +444,8 @@ __global__ __launch_bounds__(256) void k_column_steps(
             col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);
             if (lg == 0) r.b[0] = bbot;
             col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
+#pragma unroll
+            for (int p = 0; p < P; ++p) adjv[p] = bs + N2min * (g.z[p] - cc.zconv);
           }
         }
       } else {

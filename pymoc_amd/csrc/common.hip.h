@@ -48,6 +48,21 @@ __device__ __forceinline__ double from_prev_lane(double x) {
   return __hiloint2double(hi, lo);
 }
 
+// Zero-filling variants: the lane without a source receives 0.0 (bound_ctrl), which lets the
+// DPP move read its source register directly -- no preparatory copy.  For stencils whose
+// edge lanes only need a FINITE neighbour value (K1: boundary levels advance with dt = 0).
+__device__ __forceinline__ double from_next_lane_z(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double from_prev_lane_z(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------- exact division
 // a / d with a precomputed y = RN(1/d) (itself from a true IEEE division): two
 // Markstein correction steps.  q0 = RN(a*y) is within 1.5 ulp of a/d; after the first

@@ -46,6 +46,11 @@ __global__ void k_selftest_lane_shift(int *mismatch) {
   if (lane > 0 && p_dpp != p_ref) bad = 1;
   if (lane == 63 && n_dpp != x) bad = 1;  // no source: keeps own value
   if (lane == 0 && p_dpp != x) bad = 1;
+  const double n_z = from_next_lane_z(x), p_z = from_prev_lane_z(x);
+  if (lane < 63 && n_z != n_ref) bad = 1;
+  if (lane > 0 && p_z != p_ref) bad = 1;
+  if (lane == 63 && n_z != 0.0) bad = 1;  // no source: zero
+  if (lane == 0 && p_z != 0.0) bad = 1;
   if (bad) atomicAdd(mismatch, 1);
 }
 
