@@ -411,29 +411,31 @@ __global__ __launch_bounds__(256) void k_column_steps(
         col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
         double adjv[P];  // column.py:268 for the cached zconv: changes only with the pattern
         double bs_eff[P];  // bs for real levels, +inf for padding: `b > bs_eff` is the whole test
-        bool not_bottom[P], is_top[P];
+        // Level 0 always ends a step's convect + boundary condition holding bbot (column.py:232
+        // overwrites whatever convect wrote), so its "adjusted" value is bbot itself.
+        auto set_adj = [&]() {
+#pragma unroll
+          for (int p = 0; p < P; ++p)
+            adjv[p] = (lane * P + p == 0) ? bbot : bs + N2min * (g.z[p] - cc.zconv);
+        };
+        set_adj();
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          adjv[p] = bs + N2min * (g.z[p] - cc.zconv);
           bs_eff[p] = (lane * P + p < nz) ? bs : __builtin_inf();
-          not_bottom[p] = lane * P + p != 0;
-          is_top[p] = lane * P + p == nz - 1;
         }
         for (int s = 1; s < nsteps; ++s) {
           double b_old[P];
           unsigned long long im[P];
-          bool none_all = true, same = true;
-#pragma unroll
-          for (int p = 0; p < P; ++p) none_all = none_all && (cc.mask[p] == 0ull);
+          bool same = true;
 #pragma unroll
           for (int p = 0; p < P; ++p) {
             b_old[p] = r.b[p];
             const bool ind = r.b[p] > bs_eff[p];  // column.py:264
             im[p] = __builtin_amdgcn_ballot_w64(ind);
-            // level 0 is left alone: whatever convect writes there, column.py:232 replaces
-            // it with bbot before it is read, and bbot is what the slot already holds
-            r.b[p] = (ind && not_bottom[p]) ? adjv[p] : r.b[p];
-            r.b[p] = (is_top[p] && none_all) ? bs : r.b[p];  // column.py:271
+            r.b[p] = ind ? adjv[p] : r.b[p];
+            // column.py:271 (b[-1] = bs when nothing convects) needs no work here: the step
+            // that established the cached pattern imposed it, and neither vertadvdiff (the
+            // surface level advances with dt = 0) nor an unchanged pattern alters that level
           }
           col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
 #pragma unroll
@@ -444,8 +446,7 @@ __global__ __launch_bounds__(256) void k_column_steps(
             col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);
             if (lg == 0) r.b[0] = bbot;
             col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
-#pragma unroll
-            for (int p = 0; p < P; ++p) adjv[p] = bs + N2min * (g.z[p] - cc.zconv);
+            set_adj();
           }
         }
       } else {
