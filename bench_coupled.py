@@ -22,6 +22,8 @@ def main():
   ap.add_argument("--members", type=int, default=0, help="0 = the per-GPU size of SURVEY 8d")
   ap.add_argument("--steps", type=int, default=0)
   ap.add_argument("--no-graph", action="store_true")
+  ap.add_argument("--unfused", action="store_true",
+                  help="config 5: one launch per component and step instead of the fused loop")
   args = ap.parse_args()
   import numpy as np
   import pymoc_amd
@@ -47,7 +49,7 @@ def main():
       n = args.members or 4096
       cfg = configs.config5(N=n)
       cfg["rest_mask"] = np.repeat(cfg["rest_mask"][None], n, axis=0)
-      ens = pymoc_amd.JN2018Ensemble(cfg, use_graph=not args.no_graph)
+      ens = pymoc_amd.JN2018Ensemble(cfg, use_graph=not args.no_graph, fused=not args.unfused)
       steps, warm, ncol = args.steps or 3600, 2 * cfg["MOC_up_iters"], 2
     ens.run(warm)
     pymoc_amd.synchronize()
