@@ -595,11 +595,63 @@ void orc_psi_so_solve(const double *z, int nz, const double *y, int ny, const do
  * SO_ML   (src/pymoc/modules/SO_ML.py)
  * ========================================================================== */
 
-/* calc_implicit_diffusion, SO_ML.py:136-196.  dense != 0: invert U by Gauss-Jordan
- * with partial pivoting and form (Uinv V) bs like the reference's
- * np.dot(np.dot(np.linalg.inv(U), V), bs); dense == 0: Thomas sweep on U x = V bs. */
-static void so_ml_implicit_diffusion(double *bs, int ny, double s, int dense) {
+/* M = U^-1 V of SO_ML.py:136-196 column by column: column j solves U x = V e_j by the
+ * Thomas algorithm (V e_j has at most three entries).  M[i*ld + j]. */
+static void so_ml_propagator(double *M, int ny, int ld, double s) {
+  const double a = -s / 2., bd = 1 + s, c = -s / 2.;
+  double *cp = (double *)malloc(sizeof(double) * ny * 2), *den = cp + ny;
+  cp[0] = 0.; /* Thomas factors of U: rows 0 and ny-1 identity, interior (-s/2, 1+s, -s/2) */
+  for (int i = 1; i < ny - 1; ++i) {
+    den[i] = bd - a * cp[i - 1];
+    cp[i] = c / den[i];
+  }
+  for (int j = 0; j < ny; ++j) {
+    double dp = 0.;
+    for (int i = 0; i < ny; ++i) {
+      /* r = V[i][j]; V: rows 0 and ny-1 identity, interior (s/2, 1-s, s/2) */
+      double r = 0.;
+      if (i == 0 || i == ny - 1)
+        r = (i == j) ? 1. : 0.;
+      else if (j == i - 1 || j == i + 1)
+        r = s / 2.;
+      else if (j == i)
+        r = 1 - s;
+      dp = (i == 0 || i == ny - 1) ? r : (r - a * dp) / den[i];
+      M[i * ld + j] = dp;
+    }
+    double x = M[(ny - 1) * ld + j];
+    for (int i = ny - 2; i >= 0; --i) {
+      x = M[i * ld + j] - cp[i] * x;
+      M[i * ld + j] = x;
+    }
+  }
+  free(cp);
+}
+
+/* calc_implicit_diffusion, SO_ML.py:136-196.
+ *   mode 0: Thomas sweep on U x = V bs;
+ *   mode 1: invert U by Gauss-Jordan with partial pivoting and form (Uinv V) bs like the
+ *           reference's np.dot(np.dot(np.linalg.inv(U), V), bs);
+ *   mode 2: the propagator M = U^-1 V built once (so_ml_propagator), then bs <- M bs with
+ *           four interleaved fma accumulators -- what the HIP kernel does for ny <= 64 (U, V
+ *           depend only on s = Ks dt / dy^2, i.e. they are static between time steps). */
+static void so_ml_implicit_diffusion(double *bs, int ny, double s, int mode) {
+  const int dense = mode == 1;
   double *rhs = (double *)malloc(sizeof(double) * ny);
+  if (mode == 2) {
+    const int ld = ny | 1;
+    double *M = (double *)malloc(sizeof(double) * (size_t)ny * ld);
+    so_ml_propagator(M, ny, ld, s);
+    for (int i = 0; i < ny; ++i) {
+      double acc[4] = {0., 0., 0., 0.};
+      for (int j = 0; j < ny; ++j) acc[j & 3] = fma(M[i * ld + j], bs[j], acc[j & 3]);
+      rhs[i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+    memcpy(bs, rhs, sizeof(double) * ny);
+    free(M);
+    free(rhs);
+    return;
+  }
   if (!dense) {
     double *cp = (double *)malloc(sizeof(double) * ny * 2), *dp = cp + ny;
     rhs[0] = bs[0];
@@ -695,7 +747,7 @@ int orc_so_ml_advdiff(const double *y, int ny, const double *surflux,
                       const double *rest_mask, const double *b_rest,
                       const orc_so_ml_par *par, double *bs, double *Psi_s,
                       const double *b_basin, const double *Psi_b, int nz, double dt,
-                      int dense_inverse) {
+                      int diffusion_mode) {
   double *Psi_mod = (double *)malloc(sizeof(double) * (nz + 2 * ny));
   double *flux = Psi_mod + nz, *adv = flux + ny;
   int ind = -1;
@@ -746,7 +798,7 @@ int orc_so_ml_advdiff(const double *y, int ny, const double *surflux,
   for (int j = 0; j < ny; ++j) bs[j] = bs[j] + dt * (flux[j] + adv[j]); /* :259 */
   if (Psi_s[1] <= 0) bs[0] = bs[1];                                     /* :264-266 */
   const double s = par->Ks * dt / (dy * dy);                            /* :191 */
-  so_ml_implicit_diffusion(bs, ny, s, dense_inverse);                   /* :269 */
+  so_ml_implicit_diffusion(bs, ny, s, diffusion_mode);                   /* :269 */
   if (Psi_s[1] > 0) /* :274 */
     bs[0] = b_basin[first_pos];
   else

@@ -114,10 +114,45 @@ __device__ __forceinline__ void ml_tables(const MlLds &w, int ny, double s) {
   __builtin_amdgcn_wave_barrier();
 }
 
+// The Crank-Nicolson matrices U, V (:155-190) depend only on s = Ks dt / dy^2: they are the
+// same for every member and every step of a launch.  For ny <= 64 the launch therefore builds
+// the propagator M = U^-1 V ONCE per block (lane j solves U x = V e_j by the Thomas algorithm
+// with the tabulated factors; V e_j has at most three entries) and a step applies it as one
+// dense mat-vec, lane i accumulating row i with four interleaved fma chains -- the
+// reference's own formulation, np.dot(np.dot(inv(U), V), bs) (:196), instead of ~100 serial
+// Thomas steps per member and step.  Rows have an odd leading dimension (conflict-free).
+__device__ __forceinline__ int ml_prop_ld(int ny) { return ny | 1; }
+
+__device__ __forceinline__ void ml_build_propagator(double *M, const MlLds &w, int ny, double s,
+                                                    int lane) {
+  const int ld = ml_prop_ld(ny), j = lane;
+  if (j >= ny) return;
+  const double ta = -s / 2.;
+  double dp = 0.;
+  for (int i = 0; i < ny; ++i) {
+    double r = 0.;  // V[i][j]: rows 0 and ny-1 identity, interior (s/2, 1-s, s/2)
+    if (i == 0 || i == ny - 1)
+      r = (i == j) ? 1. : 0.;
+    else if (j == i - 1 || j == i + 1)
+      r = s / 2.;
+    else if (j == i)
+      r = 1 - s;
+    dp = (i == 0 || i == ny - 1) ? r : (r - ta * dp) / w.den[i];
+    M[i * ld + j] = dp;
+  }
+  double x = M[(ny - 1) * ld + j];
+  for (int i = ny - 2; i >= 0; --i) {
+    x = M[i * ld + j] - w.cp[i] * x;
+    M[i * ld + j] = x;
+  }
+}
+
 // One SO_ML.advdiff step on the member staged in `w` (bs, bb, pm valid; tables valid).
+// M: the block's propagator (ny <= 64) or nullptr (ordered Thomas sweep).
 // Returns false where the reference raises IndexError (state untouched).
 __device__ __forceinline__ bool ml_step(const MlLds &w, const MlStatic &c, int nz, int ny,
-                                        int lane, int first_pos, double dt) {
+                                        int lane, int first_pos, double dt,
+                                        const double *M = nullptr) {
   // Psi_s = np.interp(bs, b_basin, Psi_mod) (:232)
   for (int j = lane; j < ny; j += 64) w.ps[j] = interp_sorted(w.bs[j], w.bb, w.pm, nz);
   // argmin(bs): first minimum, a NaN wins (np.argmin)
@@ -183,8 +218,35 @@ __device__ __forceinline__ bool ml_step(const MlLds &w, const MlStatic &c, int n
     if (lane == 0) w.bs[0] = v;
     __builtin_amdgcn_wave_barrier();
   }
-  // Crank-Nicolson diffusion (:191-196): U x = V bs
+  // Crank-Nicolson diffusion (:191-196)
   const double s = c.s;
+  if (M != nullptr) {  // bs <- (U^-1 V) bs
+    double xi = 0.;
+    if (lane < ny) {
+      const double *row = M + lane * ml_prop_ld(ny);
+      double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+      int j = 0;
+      for (; j + 4 <= ny; j += 4) {
+        a0 = __builtin_fma(row[j], w.bs[j], a0);
+        a1 = __builtin_fma(row[j + 1], w.bs[j + 1], a1);
+        a2 = __builtin_fma(row[j + 2], w.bs[j + 2], a2);
+        a3 = __builtin_fma(row[j + 3], w.bs[j + 3], a3);
+      }
+      if (j < ny) a0 = __builtin_fma(row[j], w.bs[j], a0);
+      if (j + 1 < ny) a1 = __builtin_fma(row[j + 1], w.bs[j + 1], a1);
+      if (j + 2 < ny) a2 = __builtin_fma(row[j + 2], w.bs[j + 2], a2);
+      xi = (a0 + a1) + (a2 + a3);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < ny) w.bs[lane] = xi;
+    __builtin_amdgcn_wave_barrier();
+    const double v = upwell ? bsouth : w.bs[1];  // final BC re-set (:274)
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) w.bs[0] = v;
+    __builtin_amdgcn_wave_barrier();
+    return true;
+  }
+  // U x = V bs by the Thomas algorithm
   for (int j = lane; j < ny; j += 64) {
     double r;
     if (j == 0 || j == ny - 1)
@@ -272,10 +334,16 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_so_ml_step(pm_so_ml
   c.dy = a.y[1] - a.y[0];
   c.s = a.Ks * dt / (c.dy * c.dy);  // :191
   bool ok = ml_prepare(w, nz, lane, first_pos);
+  ml_tables(w, ny, c.s);
+  double *M = nullptr;
+  if (ny <= 64) {  // block-uniform
+    M = lds_all + (size_t)(blockDim.x >> 6) * MlLds::doubles(nz, ny);
+    if (wave == 0) ml_build_propagator(M, w, ny, c.s, lane);
+    __syncthreads();
+  }
   if (ok) {
     ml_flux_tables(w, c, ny, lane);
-    ml_tables(w, ny, c.s);
-    ok = ml_step(w, c, nz, ny, lane, first_pos, dt);
+    ok = ml_step(w, c, nz, ny, lane, first_pos, dt, M);
   }
   if (!ok) {  // IndexError in the reference: leave the state untouched
     if (a.status && lane == 0 && m_ok) a.status[m] = 1;
@@ -420,10 +488,14 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
   mc.s = a.ml.Ks * dt / (mc.dy * mc.dy);
   int first_pos;
   bool ml_ok = ml_prepare(w, nz, lane, first_pos);
-  if (ml_ok) {
-    ml_flux_tables(w, mc, ny, lane);
-    ml_tables(w, ny, mc.s);
+  ml_tables(w, ny, mc.s);
+  double *M = nullptr;
+  if (ny <= 64) {  // block-uniform
+    M = lds_all + (size_t)(blockDim.x >> 6) * MlLds::doubles(nz, ny);
+    if (wave == 0) ml_build_propagator(M, w, ny, mc.s, lane);
+    __syncthreads();
   }
+  if (ml_ok) ml_flux_tables(w, mc, ny, lane);
   int status = ml_ok ? 0 : 1;
 
   ConvCache<P> ccb, ccn;
@@ -453,7 +525,7 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
         if (i < nz) w.bb[i] = rb.b[p];
       }
       __builtin_amdgcn_wave_barrier();
-      if (!ml_step(w, mc, nz, ny, lane, first_pos, dt)) {
+      if (!ml_step(w, mc, nz, ny, lane, first_pos, dt, M)) {
         ml_ok = false;  // IndexError in the reference; the mixed layer stops evolving
         status = 1;
       }
@@ -497,12 +569,16 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
 inline size_t ml_lds_bytes(int nz, int ny) {
   return (size_t)(2 * nz + 10 * ny) * sizeof(double);
 }
+// the block-shared propagator of the Crank-Nicolson step (ny <= 64)
+inline size_t ml_prop_bytes(int ny) {
+  return ny <= 64 ? (size_t)ny * (size_t)(ny | 1) * sizeof(double) : 0;
+}
 
 inline int launch_so_ml(const pm_so_ml &a, double dt, hipStream_t st) {
-  const size_t per_wave = ml_lds_bytes(a.nz, a.ny);
+  const size_t per_wave = ml_lds_bytes(a.nz, a.ny), prop = ml_prop_bytes(a.ny);
   int wpb = ML_WAVES_PER_BLOCK;
-  while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
-  const size_t lds = per_wave * wpb;
+  while (wpb > 1 && per_wave * wpb + prop > 160 * 1024) wpb >>= 1;
+  const size_t lds = per_wave * wpb + prop;
   if (lds > 160 * 1024) return fail(PM_EINVAL, "so_ml needs %zu B of LDS per member", lds);
   if (lds > 64 * 1024)
     PM_HIP(hipFuncSetAttribute((const void *)k_so_ml_step,
@@ -515,10 +591,10 @@ inline int launch_so_ml(const pm_so_ml &a, double dt, hipStream_t st) {
 
 template <int P>
 int launch_jn2018_steps(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st) {
-  const size_t per_wave = ml_lds_bytes(a.cols.nz, a.ml.ny);
+  const size_t per_wave = ml_lds_bytes(a.cols.nz, a.ml.ny), prop = ml_prop_bytes(a.ml.ny);
   int wpb = ML_WAVES_PER_BLOCK;
-  while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
-  const size_t lds = per_wave * wpb;
+  while (wpb > 1 && per_wave * wpb + prop > 160 * 1024) wpb >>= 1;
+  const size_t lds = per_wave * wpb + prop;
   if (lds > 160 * 1024) return fail(PM_EINVAL, "jn2018 needs %zu B of LDS per member", lds);
   if (lds > 64 * 1024)
     PM_HIP(hipFuncSetAttribute((const void *)k_jn2018_steps<P>,
