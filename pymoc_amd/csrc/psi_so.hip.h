@@ -20,8 +20,9 @@
 //    (4th-order Lobatto IIIA collocation, adaptive mesh, tol 1e-3).  Here the same
 //    collocation scheme runs on the grid refined R-fold; u' is eliminated interval by
 //    interval, each lane condenses its R sub-intervals to one 2x2 element (static
-//    condensation), and the remaining nz-point tridiagonal system is solved by a Thomas
-//    sweep staged through LDS.
+//    condensation), and the remaining nz-point system is solved without a serial sweep: the
+//    node elimination `so_merge` is associative, so a prefix and a suffix scan of the
+//    elements (in-lane merges + 6 shuffle steps each) give every node its closing row.
 #pragma once
 #include "common.hip.h"
 
@@ -141,6 +142,27 @@ __device__ __forceinline__ SoElem so_merge(const SoElem &E, const SoElem &e) {
   return o;
 }
 
+__device__ __forceinline__ SoElem so_shfl_up(const SoElem &e, int d) {
+  SoElem o;
+  o.a11 = __shfl_up(e.a11, d, 64);
+  o.a12 = __shfl_up(e.a12, d, 64);
+  o.c1 = __shfl_up(e.c1, d, 64);
+  o.a21 = __shfl_up(e.a21, d, 64);
+  o.a22 = __shfl_up(e.a22, d, 64);
+  o.c2 = __shfl_up(e.c2, d, 64);
+  return o;
+}
+__device__ __forceinline__ SoElem so_shfl_down(const SoElem &e, int d) {
+  SoElem o;
+  o.a11 = __shfl_down(e.a11, d, 64);
+  o.a12 = __shfl_down(e.a12, d, 64);
+  o.c1 = __shfl_down(e.c1, d, 64);
+  o.a21 = __shfl_down(e.a21, d, 64);
+  o.a22 = __shfl_down(e.a22, d, 64);
+  o.c2 = __shfl_down(e.c2, d, 64);
+  return o;
+}
+
 template <int P>
 __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a, int ops) {
   extern __shared__ double lds_all[];
@@ -152,11 +174,11 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   const int nz = a.nz, ny = a.ny;
   const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
   const bool tau_arr = (a.flags & PM_SO_TAU_ARRAY) != 0;
-  const int per_wave = 3 * ny + (has_c ? 11 * nz : 0);
+  const int per_wave = 3 * ny + (has_c ? 2 * nz : 0);
   double *s_y = lds_all + (size_t)wave * per_wave;
   double *s_bs = s_y + ny;
   double *s_tau = s_bs + ny;
-  double *s_w = s_tau + ny;  // BVP workspace: 11 arrays of nz
+  double *s_w = s_tau + ny;  // BVP workspace: T and N2 on the column grid
   const size_t base = (size_t)m * nz;
 
   // ---- stage the member's surface profiles; min / argmin of bs (np.min, np.argmin)
@@ -313,9 +335,6 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   } else {
     // --- F2010 boundary-value smoother (psi_SO.py:308-323)
     double *s_T = s_w, *s_N2 = s_w + nz;
-    double *e11 = s_w + 2 * nz, *e12 = e11 + nz, *ec1 = e12 + nz, *e21 = ec1 + nz,
-           *e22 = e21 + nz, *ec2 = e22 + nz;
-    double *s_cp = ec2 + nz, *s_dp = s_cp + nz, *s_u = s_dp + nz;
     const double c2 = a.c * a.c;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -336,6 +355,9 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
     __builtin_amdgcn_wave_barrier();
     const int R = a.bvp_refine > 0 ? a.bvp_refine : 8;
     const double rc2 = 1. / c2, rR = 1. / (double)R;
+    SoElem Ecl[P];  // condensed element of interval [z_k, z_k+1], k = lane*P + p
+#pragma unroll
+    for (int p = 0; p < P; ++p) Ecl[p] = SoElem{0., 0., 0., 0., 0., 0.};
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int k = lane * P + p;  // interval [z_k, z_k+1]
@@ -343,7 +365,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
         const double zk = z[p], hz = a.z[k + 1] - zk;
         const double N0 = s_N2[k], N1 = s_N2[k + 1], T0 = s_T[k], T1 = s_T[k + 1];
         const double sN = (N1 - N0) / hz, sT = (T1 - T0) / hz;
-        SoElem E;
+        SoElem E = {0., 0., 0., 0., 0., 0.};
         double xl = zk, ql = N0 * rc2, rl = ql * T0;
         for (int j = 0; j < R; ++j) {
           double xr, qr, rr;
@@ -365,15 +387,9 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
           ql = qr;
           rl = rr;
         }
-        e11[k] = E.a11;
-        e12[k] = E.a12;
-        ec1[k] = E.c1;
-        e21[k] = E.a21;
-        e22[k] = E.a22;
-        ec2[k] = E.c2;
+        Ecl[p] = E;
       }
     }
-    __builtin_amdgcn_wave_barrier();
     // boundary values (bc_GM, :270-275); Psi_Ek[0], Psi_Ek[-1] live in lanes 0 / last
     double ua = 0., ub = 0.;
     if (a.flags & PM_SO_BVP_WITH_EK) {
@@ -385,76 +401,62 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
       ua = -(__shfl(ek_sv[0], 0, 64) * 1e6);
       ub = -(__shfl(v_last, last_lane, 64) * 1e6);
     }
-    // Assemble the nz-point tridiagonal rows from the condensed elements (parallel), then a
-    // Thomas sweep that every lane runs redundantly.  The sweep has no LDS stores (lane i
-    // keeps row i's factors in registers), so its broadcast loads pipeline ahead of the
-    // dependency chain, and one reciprocal per row serves both quotients.
-    double r_lo[P], r_di[P], r_up[P], r_rh[P];
+    // The nz-1 condensed elements are combined by the associative node-elimination `so_merge`:
+    // a prefix scan gives L_k (the element of [z_0, z_k+1]) and a suffix scan R_k (the element
+    // of [z_k, z_nz-1]); interior node i then closes with its own row
+    //   L_{i-1}.a21 ua + (L_{i-1}.a22 + R_i.a11) u_i + R_i.a12 ub = L_{i-1}.c2 + R_i.c1.
+    // Each scan is P-1 merges inside a lane, 6 shuffle steps across the wave and P merges to
+    // fold the carried element in -- no serial sweep over the rows.
+    const int ne = nz - 1;                       // number of elements
+    const int nv = ne - lane * P;                // valid elements of this lane (may be <= 0)
+    const int cnt = nv < 0 ? 0 : (nv > P ? P : nv);
+    SoElem Lp[P], Rp[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      Lp[p] = (p == 0) ? Ecl[0] : ((p < cnt) ? so_merge(Lp[p > 0 ? p - 1 : 0], Ecl[p]) : Lp[p > 0 ? p - 1 : 0]);
+    }
+#pragma unroll
+    for (int p = P - 1; p >= 0; --p) {
+      if (p == P - 1)
+        Rp[p] = Ecl[p];
+      else
+        Rp[p] = (p + 1 < cnt) ? so_merge(Ecl[p], Rp[p + 1]) : Ecl[p];
+    }
+    // wave scans of the lane totals (lanes with cnt == 0 carry nothing)
+    SoElem TL = Lp[P - 1];  // element of all valid intervals of this lane (Lp saturates at cnt-1)
+    SoElem TR = Rp[0];
+    const bool has = cnt > 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const SoElem o = so_shfl_up(TL, d);
+      if (lane >= d && has) TL = so_merge(o, TL);  // lanes to the left of a valid lane are full
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const SoElem o = so_shfl_down(TR, d);
+      const bool ohas = __shfl_down(has ? 1 : 0, d, 64) != 0 && lane + d < 64;
+      if (has && ohas) TR = so_merge(TR, o);
+    }
+    const SoElem XL = so_shfl_up(TL, 1);    // everything left of this lane
+    const SoElem XR = so_shfl_down(TR, 1);  // everything right of this lane
+    const bool xr_has = __shfl_down(has ? 1 : 0, 1, 64) != 0 && lane < 63;
+    // L_{i-1} of this lane's first node lives in the previous lane
+    SoElem Lfull[P], Rfull[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      Lfull[p] = (lane > 0) ? so_merge(XL, Lp[p]) : Lp[p];
+      Rfull[p] = xr_has ? so_merge(Rp[p], XR) : Rp[p];
+    }
+    const SoElem Lprev = so_shfl_up(Lfull[P - 1], 1);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = lane * P + p;
-      const bool row = i >= 1 && i <= nz - 2;
-      const int ii = row ? i : 1;
-      r_lo[p] = e21[ii - 1];
-      r_di[p] = e22[ii - 1] + e11[ii];
-      r_up[p] = e12[ii];
-      r_rh[p] = ec2[ii - 1] + ec1[ii];
-    }
-    __builtin_amdgcn_wave_barrier();
-    double *t_lo = e11, *t_di = e12, *t_up = ec1, *t_rh = e21;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int i = lane * P + p;
-      if (i >= 1 && i <= nz - 2) {
-        t_lo[i] = r_lo[p];
-        t_di[i] = r_di[p];
-        t_up[i] = r_up[p];
-        t_rh[i] = r_rh[p];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    {
-      double cp = 0., dp = ua;  // row 0: u_0 = ua
-      double my_cp[P], my_dp[P];
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        my_cp[p] = 0.;
-        my_dp[p] = ua;
-      }
-#pragma unroll 2
-      for (int i = 1; i < nz - 1; ++i) {
-        const double lo = t_lo[i];
-        const double inv = 1.0 / (t_di[i] - lo * cp);
-        cp = t_up[i] * inv;
-        dp = (t_rh[i] - lo * dp) * inv;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          my_cp[p] = (lane * P + p == i) ? cp : my_cp[p];
-          my_dp[p] = (lane * P + p == i) ? dp : my_dp[p];
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int i = lane * P + p;
-        if (i < nz - 1) {
-          s_cp[i] = my_cp[p];
-          s_dp[i] = my_dp[p];
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      double u = ub;
-      double my_u[P];
-#pragma unroll
-      for (int p = 0; p < P; ++p) my_u[p] = (lane * P + p == 0) ? ua : ub;
-#pragma unroll 2
-      for (int i = nz - 2; i >= 1; --i) {
-        u = s_dp[i] - s_cp[i] * u;
-#pragma unroll
-        for (int p = 0; p < P; ++p) my_u[p] = (lane * P + p == i) ? u : my_u[p];
-      }
-#pragma unroll
-      for (int p = 0; p < P; ++p) temp[p] = my_u[p];
+      const SoElem &Lm = (p == 0) ? Lprev : Lfull[p > 0 ? p - 1 : 0];
+      const SoElem &Rm = Rfull[p];
+      double u = (i == 0) ? ua : ub;
+      if (i >= 1 && i <= nz - 2)
+        u = (Lm.c2 + Rm.c1 - Lm.a21 * ua - Rm.a12 * ub) / (Lm.a22 + Rm.a11);
+      temp[p] = u;
     }
   }
   // limit Psi_GM to -Psi_Ek on isopycnals that do not outcrop (:329-330)
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
 template <int P>
 int launch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
   const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
-  const size_t per_wave = (size_t)(3 * a.ny + (has_c ? 11 * a.nz : 0)) * sizeof(double);
+  const size_t per_wave = (size_t)(3 * a.ny + (has_c ? 2 * a.nz : 0)) * sizeof(double);
   int wpb = SO_WAVES_PER_BLOCK;
   while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
   const size_t lds = per_wave * wpb;
