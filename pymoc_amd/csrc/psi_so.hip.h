@@ -232,8 +232,16 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
     } else if (ambiguous) {  // several crossings: the one brentq's iteration finds
       yv = brentq_interp(s_y, s_bs, ny, b[p], s_y[minind], yN);
     } else {
-      int j = minind;
-      while (j < ny - 2 && !(s_bs[j + 1] >= b[p])) ++j;  // first crossing north of argmin
+      // first crossing north of argmin: bs is non-decreasing there (not `ambiguous`), so the
+      // first j with bs[j+1] >= b is a lower bound -- 6 probes instead of a walk over y
+      int j = minind, hi = ny - 2;
+      while (j < hi) {
+        const int mid = (j + hi) >> 1;
+        if (s_bs[mid + 1] >= b[p])
+          hi = mid;
+        else
+          j = mid + 1;
+      }
       const double f0 = s_bs[j], f1 = s_bs[j + 1];
       if (f0 == b[p])
         yv = s_y[j];
