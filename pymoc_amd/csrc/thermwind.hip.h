@@ -105,10 +105,28 @@ __device__ __forceinline__ void psib_cell_terms(double t, double d, double yk, d
 // One isopycnal class: sum_k clip((top_k - bg)/(top_k - bot_k), 0, 1) * u_k over cells
 // [k0, k0+n) in NumPy's pairwise order, for TW_JT classes at once.  Cell arrays in LDS:
 // top, d = top - bot, y = RN(1/d) or NaN, u.
+// Range test of a pass: every class of the pass lies in [gmin, gmax] (wave-uniform scalars);
+// gbot[g] / gtop[g] hold min(bot) / max(top) of the 8 cells k = 8g .. 8g+7 (-inf / +inf when a
+// cell of the group is degenerate or inverted).  If gmax <= gbot[g] every mask of the group
+// is exactly 1 for every class of the pass (fl(top-g) >= fl(top-bot) > 0, quotient >= 1), so
+// the terms are the u_k themselves; if gmin >= gtop[g] every mask is exactly 0 and the group
+// only adds zeros.  Both shortcuts leave every partial sum of NumPy's pairwise order
+// bit-identical (x + 0 = x).
+struct PsibRange {
+  const double *gbot, *gtop;
+  double gmin, gmax;
+};
+
+__device__ __forceinline__ double tw_uniform(double x) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ void psib_block_sum(const double *top, const double *dd,
                                                const double *yy, const double *u, int k0,
                                                int n, const double (&bg)[TW_JT],
-                                               double (&res)[TW_JT]) {
+                                               double (&res)[TW_JT], const PsibRange &rg) {
   double term[TW_JT];
   if (n < 8) {
 #pragma unroll
@@ -121,20 +139,50 @@ __device__ __forceinline__ void psib_block_sum(const double *top, const double *
     return;
   }
   double r[8][TW_JT];
+  {  // first group of 8 initialises the accumulators (k0 is a multiple of 8)
+    const double gb = tw_uniform(rg.gbot[k0 >> 3]), gt = tw_uniform(rg.gtop[k0 >> 3]);
+    if (rg.gmax <= gb) {
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    psib_cell_terms(top[k0 + a], dd[k0 + a], yy[k0 + a], u[k0 + a], bg, term);
+      for (int a = 0; a < 8; ++a) {
+        const double uk = u[k0 + a];
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) r[a][j] = term[j];
+        for (int j = 0; j < TW_JT; ++j) r[a][j] = uk;
+      }
+    } else if (rg.gmin >= gt) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int j = 0; j < TW_JT; ++j) r[a][j] = 0.;
+    } else {
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        psib_cell_terms(top[k0 + a], dd[k0 + a], yy[k0 + a], u[k0 + a], bg, term);
+#pragma unroll
+        for (int j = 0; j < TW_JT; ++j) r[a][j] = term[j];
+      }
+    }
   }
   const int nfull = n - (n % 8);
   for (int k = 8; k < nfull; k += 8) {
+    const int g = (k0 + k) >> 3;
+    const double gb = tw_uniform(rg.gbot[g]), gt = tw_uniform(rg.gtop[g]);
+    if (rg.gmax <= gb) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      const int kk = k0 + k + a;
-      psib_cell_terms(top[kk], dd[kk], yy[kk], u[kk], bg, term);
+      for (int a = 0; a < 8; ++a) {
+        const double uk = u[k0 + k + a];
 #pragma unroll
-      for (int j = 0; j < TW_JT; ++j) r[a][j] += term[j];
+        for (int j = 0; j < TW_JT; ++j) r[a][j] += uk;
+      }
+    } else if (rg.gmin >= gt) {
+      // all masks 0: the group adds zeros
+    } else {
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int kk = k0 + k + a;
+        psib_cell_terms(top[kk], dd[kk], yy[kk], u[kk], bg, term);
+#pragma unroll
+        for (int j = 0; j < TW_JT; ++j) r[a][j] += term[j];
+      }
     }
   }
 #pragma unroll
@@ -153,8 +201,8 @@ __device__ __forceinline__ void psib_block_sum(const double *top, const double *
 __device__ __noinline__ void psib_block_sum_call(const double *top, const double *dd,
                                                  const double *yy, const double *u, int k0,
                                                  int n, const double (&bg)[TW_JT],
-                                                 double (&res)[TW_JT]) {
-  psib_block_sum(top, dd, yy, u, k0, n, bg, res);
+                                                 double (&res)[TW_JT], const PsibRange &rg) {
+  psib_block_sum(top, dd, yy, u, k0, n, bg, res, rg);
 }
 
 // np.add.reduce pairwise recursion (blocks of <= 128, left half rounded down to a
@@ -163,19 +211,19 @@ template <int D>
 __device__ __forceinline__ void psib_pairwise(const double *top, const double *dd,
                                               const double *yy, const double *u, int k0,
                                               int n, const double (&bg)[TW_JT],
-                                              double (&res)[TW_JT]) {
+                                              double (&res)[TW_JT], const PsibRange &rg) {
   if constexpr (D == 0) {
-    psib_block_sum_call(top, dd, yy, u, k0, n, bg, res);
+    psib_block_sum_call(top, dd, yy, u, k0, n, bg, res, rg);
   } else {
     if (n <= 128) {
-      psib_block_sum_call(top, dd, yy, u, k0, n, bg, res);
+      psib_block_sum_call(top, dd, yy, u, k0, n, bg, res, rg);
       return;
     }
     int n2 = n / 2;
     n2 -= n2 % 8;
     double l[TW_JT], r[TW_JT];
-    psib_pairwise<D - 1>(top, dd, yy, u, k0, n2, bg, l);
-    psib_pairwise<D - 1>(top, dd, yy, u, k0 + n2, n - n2, bg, r);
+    psib_pairwise<D - 1>(top, dd, yy, u, k0, n2, bg, l, rg);
+    psib_pairwise<D - 1>(top, dd, yy, u, k0 + n2, n - n2, bg, r, rg);
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) res[j] = l[j] + r[j];
   }
@@ -217,12 +265,15 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
   const bool m_ok = m_raw < a.n;
   const int m = m_ok ? m_raw : a.n - 1;
   const int nz = a.nz, nb = a.nb;
-  const int per_wave = 4 * nz + nb;
+  const int ngrp = (nz + 7) >> 3;
+  const int per_wave = 4 * nz + nb + 2 * ngrp;
   double *s_a = lds_all + (size_t)wave * per_wave;  // [nz]  increments / top
   double *s_b = s_a + nz;                           // [nz]  d = top - bot
   double *s_c = s_b + nz;                           // [nz]  u
   double *s_y = s_c + nz;                           // [nz]  RN(1/d), NaN for degenerate cells
   double *s_psib = s_y + nz;                        // [nb]
+  double *s_gbot = s_psib + nb;                     // [ngrp] min(bot) of each 8-cell group
+  double *s_gtop = s_gbot + ngrp;                   // [ngrp] max(top)
   const size_t base = (size_t)m * nz;
 
   double z[P], zu[P], b1[P], b2[P], b1u[P], b2u[P], Psi[P];
@@ -337,10 +388,31 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
       s_b[k] = d;
       s_c[k] = u;
       s_y[k] = regular ? 1.0 / d : __builtin_nan("");
+      // staged in the psib row (free until the first pass writes it) for the group ranges
+      if (nb >= nz) s_psib[k] = (regular && d > 0.) ? bot : -__builtin_inf();
     }
   }
   __builtin_amdgcn_wave_barrier();
   const int nc = nz - 1;
+  for (int g = lane; g < ngrp; g += 64) {
+    double gb = __builtin_inf(), gt = -__builtin_inf();
+    bool ok = nb >= nz;
+    for (int a = 0; a < 8; ++a) {
+      const int k = g * 8 + a;
+      if (k < nc && ok) {
+        const double bk = s_psib[k];
+        ok = bk != -__builtin_inf();
+        gb = bk < gb ? bk : gb;
+        gt = s_a[k] > gt ? s_a[k] : gt;
+      }
+    }
+    s_gbot[g] = ok ? gb : -__builtin_inf();  // never "all masks 1"
+    s_gtop[g] = ok ? gt : __builtin_inf();   // never "all masks 0"
+  }
+  __builtin_amdgcn_wave_barrier();
+  PsibRange rg;
+  rg.gbot = s_gbot;
+  rg.gtop = s_gtop;
   for (int i0 = 0; i0 < nb; i0 += 64 * TW_JT) {
     double bg[TW_JT], res[TW_JT];
 #pragma unroll
@@ -348,19 +420,24 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
       const int i = i0 + j * 64 + lane;
       bg[j] = lin.at(i < nb ? i : nb - 1);
     }
+    {  // class range of this pass (bgrid ascends; NaN ranges fail both tests)
+      const int ilast = i0 + 64 * TW_JT - 1;
+      rg.gmin = lin.at(i0);
+      rg.gmax = lin.at(ilast < nb ? ilast : nb - 1);
+    }
     if constexpr (BIG == 2) {
-      psib_pairwise<4>(s_a, s_b, s_y, s_c, 0, nc, bg, res);
+      psib_pairwise<4>(s_a, s_b, s_y, s_c, 0, nc, bg, res, rg);
     } else if constexpr (BIG == 1) {
       // 128 < nc <= 256: NumPy's recursion is exactly two blocks, both inlined
       int n2 = nc / 2;
       n2 -= n2 % 8;
       double r2[TW_JT];
-      psib_block_sum(s_a, s_b, s_y, s_c, 0, n2, bg, res);
-      psib_block_sum(s_a, s_b, s_y, s_c, n2, nc - n2, bg, r2);
+      psib_block_sum(s_a, s_b, s_y, s_c, 0, n2, bg, res, rg);
+      psib_block_sum(s_a, s_b, s_y, s_c, n2, nc - n2, bg, r2, rg);
 #pragma unroll
       for (int j = 0; j < TW_JT; ++j) res[j] = res[j] + r2[j];
     } else {
-      psib_block_sum(s_a, s_b, s_y, s_c, 0, nc, bg, res);  // nc <= 128: one pairwise block
+      psib_block_sum(s_a, s_b, s_y, s_c, 0, nc, bg, res, rg);  // nc <= 128: one pairwise block
     }
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) {
@@ -395,7 +472,7 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
 
 template <int P, int BIG>
 int launch_thermwind_impl(const pm_thermwind &a, int ops, hipStream_t st) {
-  const size_t per_wave = (size_t)(4 * a.nz + a.nb) * sizeof(double);
+  const size_t per_wave = (size_t)(4 * a.nz + a.nb + 2 * ((a.nz + 7) / 8)) * sizeof(double);
   int wpb = TW_WAVES_PER_BLOCK;
   while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
   const size_t lds = per_wave * wpb;
