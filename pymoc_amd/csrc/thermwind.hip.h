@@ -22,7 +22,7 @@
 namespace pm {
 
 constexpr int TW_WAVES_PER_BLOCK = 4;
-constexpr int TW_JT = 4;  // isopycnal classes per lane per pass
+constexpr int TW_JT = 2;  // isopycnal classes per lane per pass
 
 __device__ __forceinline__ double np_clip01(double v) {
   // np.clip(v, 0, 1) = minimum(maximum(v, 0), 1); both propagate NaN
