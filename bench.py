@@ -3,9 +3,11 @@
 
 Workload (configs[1] of BASELINE.json): an ensemble of 1024
 independent advective-diffusive Columns per GPU, nz=100, fp64, prescribed static upwelling
-wA, convective adjustment on odd members, dt=30 d.  A "step" is one Column.timestep of
-every column of the rank's shard.  Steps are issued as launches of `--steps-per-launch`
-fused steps (wA is static in this config, so any fusion depth is the same job).
+wA, convective adjustment on odd members, dt=30 d.  A bench "step" is one pass of the hot
+path over the rank's batch: ONE launch that advances every column by `--steps-per-launch`
+(default 1000) model time steps -- the config's whole job, wA being static (the coupled
+drivers fuse a MOC-update interval the same way).  `value` counts Column.timestep calls:
+columns x steps x steps-per-launch / time.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -78,9 +80,10 @@ def load_traffic(path, key):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=20000)
-  ap.add_argument("--warmup", type=int, default=2000)
-  ap.add_argument("--steps-per-launch", type=int, default=1000)
+  ap.add_argument("--steps", type=int, default=20, help="timed launches (bench steps)")
+  ap.add_argument("--warmup", type=int, default=2, help="untimed launches")
+  ap.add_argument("--steps-per-launch", type=int, default=1000,
+                  help="model time steps fused in one launch (= one bench step)")
   ap.add_argument("--columns", type=int, default=1024, help="columns per GPU")
   ap.add_argument("--nz", type=int, default=100)
   ap.add_argument("--lanes", type=int, default=0, help="lanes per column (0 = auto)")
@@ -114,7 +117,7 @@ def main():
   gathered = DeviceArray((world, C, nz)) if use_gather else None
   dt = cfg["dt"]
 
-  run_steps(batch, wA, dt, W, F, args.lanes)
+  run_steps(batch, wA, dt, W * F, F, args.lanes)
   stream.sync()
 
   ev0, ev1 = Event(), Event()
@@ -122,7 +125,7 @@ def main():
   pymoc_amd.synchronize()
   t0 = time.perf_counter()
   ev0.record(stream)
-  launches = run_steps(batch, wA, dt, K, F, args.lanes)
+  launches = run_steps(batch, wA, dt, K * F, F, args.lanes)
   ev1.record(stream)
   if use_gather:  # diagnostic output: RCCL all-gather of the final buoyancy
     comm.allgather_device(batch.b, gathered, stream)
@@ -138,10 +141,9 @@ def main():
 
   if rank == 0:
     lanes = args.lanes or 64
-    value = world * C * K / elapsed
+    value = world * C * K * F / elapsed
     launch_s = kernel_ms * 1e-3 / launches
-    steps_per_launch_eff = K / launches
-    alg_bytes = 24.0 * nz * C * steps_per_launch_eff  # read b, read wA, write b per step
+    alg_bytes = 24.0 * nz * C * F  # read b, read wA, write b per model step
     achieved = alg_bytes / launch_s / 1e9
     traffic = load_traffic(os.path.join(ROOT, "profiles", "traffic_r01.json"),
                            "column_steps_F%d_C%d_nz%d" % (F, C, nz))
@@ -154,7 +156,8 @@ def main():
             "workload": "BASELINE configs[1]: ensemble of %d independent Columns nz=%d "
                         "fp64 per GPU, static wA, do_conv on odd members, dt=30 d "
                         "(pymoc_amd.configs.config2, seed 20240)" % (C, nz),
-            "columns_per_gpu": C, "nz": nz, "steps_per_launch": F,
+            "columns_per_gpu": C, "nz": nz, "model_steps_per_step": F,
+            "step": "one launch = %d Column.timestep calls of every column" % F,
             "lanes_per_column": lanes,
             "parallelism": "ensemble sharded over %d GPU(s), RCCL all-gather of the "
                            "final state" % world},

@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_alu_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --no-cpu-baseline --no-single-step --steps 4000 --warmup 1000"
+BENCH="python3 $REPO/bench.py --no-cpu-baseline --no-single-step --steps 4 --warmup 1"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/sq -- $BENCH > $OUT/bench.json 2> $OUT/err.txt
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OUT/grbm -- $BENCH > /dev/null 2>> $OUT/err.txt
 python3 - <<PY
