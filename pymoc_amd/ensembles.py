@@ -164,7 +164,8 @@ class TwoColEnsemble(object):
     # and feed wAb = (Psi_iso_b - SO.Psi)*1e6 inside the thermal-wind launch
     if self.so is not None:
       self.so.update(self._b_basin, self.bs_SO)
-    self.tw.update(self._b_basin, self._b_north, ops=_TW_ALL, Psi_SO=self._psi_so(),
+    self.tw.update(self._b_basin, self._b_north, ops=_TW_ALL, store_psib=False,
+                   Psi_SO=self._psi_so(),
                    wA1=self.wA.ptr, wA2=self.wA.ptr + self._off)
 
   def run(self, nsteps):
@@ -251,7 +252,9 @@ class JN2018Ensemble(object):
   def _update(self):
     b_basin, b_north = self.cols.b.ptr, self.cols.b.ptr + self._off
     self.so.update(b_basin, self.ml.bs)
-    self.tw.update(b_basin, b_north, ops=_TW_ALL, Psi_SO=self.so.Psi, wA1=self.wA.ptr,
+    # psib / bgrid go to HBM only when a diagnostics recorder will read them
+    self.tw.update(b_basin, b_north, ops=_TW_ALL, store_psib=self.recorder is not None,
+                   Psi_SO=self.so.Psi, wA1=self.wA.ptr,
                    wA2=self.wA.ptr + self._off)
 
   def _step(self):
@@ -371,8 +374,8 @@ class TwoBasinEnsemble(object):
     bA = self.cols.b.ptr
     bN = self.cols.b.ptr + self._off if b_north is None else b_north
     bP = self.cols.b.ptr + 2 * self._off
-    self.amoc.update(bA, bN, ops=_TW_ALL)
-    self.zoc.update(bA, bP, ops=_TW_ALL)
+    self.amoc.update(bA, bN, ops=_TW_ALL, store_psib=False)
+    self.zoc.update(bA, bP, ops=_TW_ALL, store_psib=False)
     self.so_atl.update(bA, self.bs_SO)
     self.so_pac.update(bP, self.bs_SO)
     w = self.wA.ptr

@@ -38,13 +38,16 @@ class ThermwindBatch(object):
     return x.ptr if isinstance(x, DeviceArray) else int(x)
 
   def update(self, b1, b2, ops=_lib.PM_TW_SOLVE | _lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ,
-             Psi_SO=None, wA1=None, wA2=None, nb=None):
+             Psi_SO=None, wA1=None, wA2=None, nb=None, store_psib=True):
+    """store_psib=False keeps `psib` / `bgrid` in the kernel's LDS only (the remap to the
+    columns' levels does not need them in HBM: 2 x 8 nb bytes per member and update saved)."""
     d = pm_thermwind()
     d.n, d.nz, d.nb, d.reserved = self.n, self.nz, int(nb or self.nb), 0
     if d.nb > self.nb:
       raise ValueError("nb exceeds the batch's allocation")
     d.z, d.b1, d.b2, d.f = self.z.ptr, self._ptr(b1), self._ptr(b2), self.f.ptr
-    d.Psi, d.bgrid, d.psib = self.Psi.ptr, self.bgrid.ptr, self.psib.ptr
+    d.Psi = self.Psi.ptr
+    d.bgrid, d.psib = (self.bgrid.ptr, self.psib.ptr) if store_psib else (None, None)
     d.psibz1, d.psibz2 = self.psibz1.ptr, self.psibz2.ptr
     d.Psi_SO, d.wA1, d.wA2 = self._ptr(Psi_SO), self._ptr(wA1), self._ptr(wA2)
     check(lib.pm_thermwind_update(C.byref(d), int(ops), _sh(self.stream)))
