@@ -92,3 +92,19 @@ def test_equi_column_api_contract(gpu):
   c3 = gpu.Equi_Column(z=z, B_int=3e3, A=2.0e14, kappa=lambda zz: -3e-5 * zz / 4e3, H=500.0)
   with pytest.raises(NotImplementedError):
     c3.solve()
+
+
+def test_equi_column_failure_modes_match_solve_bvp(gpu):
+  """A singular Jacobian ends with status 2 like SciPy; NaN or hopeless members of a batch end
+  with a status of their own without disturbing their neighbours."""
+  z = np.linspace(-4000, 0, 80)
+  kw = dict(z=z, A=2e14, kappa=3e-5, H=500.0, B_int=None, b_bot=4e3)
+  m = gpu.Equi_Column(**kw)
+  m.solve()
+  r = EO.solve(EO.problem(**kw))
+  assert m.status == r["status"] == 2 and m._eq.x[0].size == r["x"].size
+  eq = gpu.EquiColumnBatch(3, B_int=np.array([3e3, np.nan, 3e3]), A=2e14,
+                           kappa=np.array([3e-5, 3e-5, 1e-9]), nz=40).solve()
+  ref = EO.solve(EO.problem(B_int=3e3, A=2e14, kappa=3e-5, nz=40))
+  assert eq.status[0] == 0 and eq.status[1] != 0 and eq.status[2] != 0
+  assert abs(eq.H[0] - ref["H"]) <= 1e-9 * ref["H"] and eq.x[0].size == ref["x"].size
