@@ -70,6 +70,12 @@ lines += ["## HBM-side traffic of `k_column_steps` (PMC, separate passes)", "",
           "%.1f MB of algorithmic bytes (24 B x nz x columns x 1000 fused steps): the state "
           "lives in registers for the whole launch, so only the compulsory first read and "
           "last write reach the memory side." % (traffic / 1e6, alg / 1e6), ""]
+if os.path.exists(os.path.join(ROOT, "profiles", tag, "test_suite_kernel_stats.csv")):
+  lines += ["## Kernel inventory of the GPU test suite", "",
+            "`rocprofv3 --kernel-trace --stats -- python3 -m pytest tests -q -m gpu` -> "
+            "`profiles/%s/test_suite_kernel_stats.csv`: every kernel the parity tests exercise "
+            "(all `pm::k_*` of `libpymoc_hip.so`; the only foreign entries are the runtime's "
+            "`__amd_rocclr_copyBuffer` / `fillBufferAligned` for memcpy / memset)." % tag, ""]
 open(os.path.join(ROOT, "profiles", tag + "_summary.md"), "w").write("\n".join(lines))
 json.dump({"column_steps_F1000_C1024_nz100": traffic,
            "_fetch_KiB": fetch, "_write_KiB": write, "_fetch_corr": fcorr, "_write_corr": wcorr},
