@@ -149,6 +149,9 @@ typedef struct pm_thermwind {
   const double *Psi_SO; /* [n][nz] in, may be NULL                               */
   double *wA1;          /* [n][nz] out, may be NULL                              */
   double *wA2;          /* [n][nz] out, may be NULL                              */
+  const double *b1_mid; /* [n][nz] b1 at the midpoints z[k] + (z[k+1]-z[k])/2 of the     */
+  const double *b2_mid; /*         intervals, for CALLABLE profiles (solve_bvp evaluates */
+                        /*         them there); NULL = linear between the levels        */
 } pm_thermwind;
 
 int pm_thermwind_update(const pm_thermwind *tw, int32_t ops, pm_stream_t stream);

@@ -160,11 +160,15 @@ def column_ensemble_steps(z, kappa, area, b, wA, dt, do_conv, bs, bbot, N2min, n
 
 
 # --------------------------------------------------------------- Psi_Thermwind
-def thermwind_solve(z, b1, b2, f):
+def thermwind_solve(z, b1, b2, f, b1_mid=None, b2_mid=None):
+  """b1_mid / b2_mid: the profiles at the interval midpoints (for callable profiles)."""
   z, b1, b2 = _a(z), _a(b1), _a(b2)
   Psi = np.empty_like(z)
-  lib().orc_thermwind_solve(_p(z), _p(b1), _p(b2), C.c_int(z.size), C.c_double(f),
-                            _p(Psi))
+  m1 = None if b1_mid is None else _a(b1_mid)
+  m2 = None if b2_mid is None else _a(b2_mid)
+  lib().orc_thermwind_solve_mid(_p(z), _p(b1), _p(b2), C.c_int(z.size), C.c_double(f),
+                                _p(m1) if m1 is not None else None,
+                                _p(m2) if m2 is not None else None, _p(Psi))
   return Psi
 
 

@@ -320,8 +320,11 @@ void orc_column_ensemble_steps(const double *z, const double *kappa, const doubl
  * With np.interp profiles the right-hand side is piecewise linear, the collocation
  * residual vanishes identically on the initial mesh (no refinement), and the
  * collocation equations reduce to the two running integrals below. */
-void orc_thermwind_solve(const double *z, const double *b1, const double *b2, int nz,
-                         double f, double *Psi) {
+/* b1m / b2m: optional b1, b2 at the interval midpoints z[i] + h/2 (callable profiles are
+ * evaluated there by solve_bvp); NULL = the np.interp closure of the level values. */
+void orc_thermwind_solve_mid(const double *z, const double *b1, const double *b2, int nz,
+                             double f, const double *b1m_in, const double *b2m_in,
+                             double *Psi) {
   const double rf = 1. / f; /* psi_thermwind.py:123: 1. / self.f * (...) */
   double *g = (double *)malloc(sizeof(double) * nz * 3);
   double *G = g + nz, *I = g + 2 * nz;
@@ -333,7 +336,8 @@ void orc_thermwind_solve(const double *z, const double *b1, const double *b2, in
     const double zm = z[i] + 0.5 * h;
     /* rhs at the collocation midpoint through the same np.interp closures */
     const double s1 = (b1[i + 1] - b1[i]) / h, s2 = (b2[i + 1] - b2[i]) / h;
-    const double b1m = s1 * (zm - z[i]) + b1[i], b2m = s2 * (zm - z[i]) + b2[i];
+    const double b1m = b1m_in ? b1m_in[i] : s1 * (zm - z[i]) + b1[i];
+    const double b2m = b2m_in ? b2m_in[i] : s2 * (zm - z[i]) + b2[i];
     const double gm = rf * (b2m - b1m);
     G[i + 1] = G[i] + h / 6. * (g[i] + g[i + 1] + 4. * gm);
     const double Gm = 0.5 * (G[i] + G[i + 1]) - 0.125 * h * (g[i + 1] - g[i]);
@@ -343,6 +347,11 @@ void orc_thermwind_solve(const double *z, const double *b1, const double *b2, in
   for (int i = 0; i < nz; ++i)
     Psi[i] = (I[i] - I[nz - 1] * ((z[i] - z[0]) / span)) / 1e6; /* Sv, :135 */
   free(g);
+}
+
+void orc_thermwind_solve(const double *z, const double *b1, const double *b2, int nz,
+                         double f, double *Psi) {
+  orc_thermwind_solve_mid(z, b1, b2, nz, f, NULL, NULL, Psi);
 }
 
 static double np_clip01(double v) {

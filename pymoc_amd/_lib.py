@@ -43,7 +43,7 @@ class pm_thermwind(C.Structure):
       ("n", C.c_int32), ("nz", C.c_int32), ("nb", C.c_int32), ("reserved", C.c_int32),
       ("z", c_dp), ("b1", c_dp), ("b2", c_dp), ("f", c_dp), ("Psi", c_dp),
       ("bgrid", c_dp), ("psib", c_dp), ("psibz1", c_dp), ("psibz2", c_dp),
-      ("Psi_SO", c_dp), ("wA1", c_dp), ("wA2", c_dp)
+      ("Psi_SO", c_dp), ("wA1", c_dp), ("wA2", c_dp), ("b1_mid", c_dp), ("b2_mid", c_dp)
   ]
 
 

@@ -302,6 +302,11 @@ def iteration_kappa(z, kappa_back=1e-5, kappa_s=3e-5, kappa_4k=3e-4):
   return kappa_back + kappa_s * np.exp(z / 100) + kappa_4k * np.exp(-z / 1000 - 4)
 
 
+def iteration_b_basin(z, bs=0.03, bbot=-0.0004):
+  """`b_basin` of examples/example_iteration.py:33-34 (a callable initial profile)."""
+  return bs * np.exp(z / 300.) + bbot
+
+
 def iteration_member(nz=100, bs=0.03, bbot=-0.0004, A_basin=8e13, kappa_4k=3e-4, f=1.2e-4):
   """examples/example_iteration.py:13-59: one basin column whose equilibrium profile
   (`Column.solve_equi`) and thermal-wind overturning against b_N = 0 are iterated with

@@ -303,7 +303,8 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
       if (i < nz - 1) {
         const double zm = z[p] + 0.5 * h[p];
         const double s1 = (b1u[p] - b1[p]) / h[p], s2 = (b2u[p] - b2[p]) / h[p];
-        const double b1m = s1 * (zm - z[p]) + b1[p], b2m = s2 * (zm - z[p]) + b2[p];
+        const double b1m = a.b1_mid ? a.b1_mid[base + i] : s1 * (zm - z[p]) + b1[p];
+        const double b2m = a.b2_mid ? a.b2_mid[base + i] : s2 * (zm - z[p]) + b2[p];
         const double gm = rf * (b2m - b1m);
         s_a[i] = h[p] / 6. * (g[p] + gu[p] + 4. * gm);  // dG over [z_i, z_i+1]
       }

@@ -2,9 +2,11 @@
 
 Same constructor, attributes (`Psi`, `bgrid`, `b1`, `b2`, `f`, `z`, `sol_init`), methods
 and error text as `pymoc.modules.Psi_Thermwind` (src/pymoc/modules/psi_thermwind.py:7-232).
-Profiles given as callables are sampled on `z` (between grid nodes the engine interpolates
-linearly, the reference would call the function at SciPy's collocation midpoints:
-SURVEY hazard H7); array and float profiles behave exactly like the reference.
+Array and float profiles behave exactly like the reference.  Profiles given as CALLABLES are
+evaluated on `z` and at the collocation midpoints, where SciPy's solve_bvp evaluates them, so
+`solve()` agrees with the reference to ~1e-8 at nz = 100 (what remains is the node or two that
+solve_bvp's residual control inserts for curved profiles; SURVEY hazard H7); in `Psib` they
+are sampled on `z`, exactly as the reference does.
 """
 import numpy as np
 
@@ -30,13 +32,15 @@ class Psi_Thermwind(object):
       raise TypeError('z needs to be numpy array providing grid levels')
     self.b1 = make_func(b1, self.z, 'b1')
     self.b2 = make_func(b2, self.z, 'b2')
+    self._b1_callable, self._b2_callable = callable(b1), callable(b2)
     self.sol_init = np.zeros((2, nz)) if sol_init is None else sol_init
     self._batch = None
     self._nb = 0
     self._nz = 0
 
   # ---- device plumbing: one arena, one H2D and one D2H per call
-  # arena (float64 slots): in  [b1 | b2 | Psi_in | f]   out [Psi | psibz1 | psibz2 | bgrid | psib]
+  # arena (float64 slots): in  [b1 | b2 | Psi_in | f | b1_mid | b2_mid]
+  #                        out [Psi | psibz1 | psibz2 | bgrid | psib]
   def _run(self, ops, nb, need_psi):
     import ctypes as C
     from .. import _lib
@@ -44,7 +48,7 @@ class Psi_Thermwind(object):
     if self._batch is None or self._nb < nb or self._nz != nz:
       self._nb, self._nz = max(int(nb), 1), nz
       self._zd = DeviceArray.from_host(np.ascontiguousarray(self.z, dtype=np.float64))
-      self._nin = 3 * nz + 1
+      self._nin = 5 * nz + 1
       self._arena = DeviceArray((self._nin + 3 * nz + 2 * self._nb,))
       self._host = np.zeros(self._nin)
       self._batch = True
@@ -54,6 +58,11 @@ class Psi_Thermwind(object):
     if need_psi:
       h[2 * nz:3 * nz] = self.Psi
     h[3 * nz] = self.f
+    mid = (self._b1_callable or self._b2_callable) and bool(ops & _lib.PM_TW_SOLVE)
+    if mid:  # x_middle of scipy's collocation_fun
+      zm = self.z[:-1] + 0.5 * (self.z[1:] - self.z[:-1])
+      h[3 * nz + 1:4 * nz] = self.b1(zm)
+      h[4 * nz + 1:5 * nz] = self.b2(zm)
     _lib.check(_lib.lib.pm_memcpy_h2d(p, h.ctypes.data, h.nbytes, None))
     o = p + self._nin * 8
     d = _lib.pm_thermwind()
@@ -64,6 +73,8 @@ class Psi_Thermwind(object):
     d.psibz1, d.psibz2 = o + nz * 8, o + 2 * nz * 8
     d.bgrid, d.psib = o + 3 * nz * 8, o + (3 * nz + self._nb) * 8
     d.Psi_SO, d.wA1, d.wA2 = None, None, None
+    d.b1_mid = p + (3 * nz + 1) * 8 if mid else None
+    d.b2_mid = p + (4 * nz + 1) * 8 if mid else None
     _lib.check(_lib.lib.pm_thermwind_update(C.byref(d), int(ops), None))
     out = np.empty(3 * nz + 2 * self._nb)
     _lib.check(_lib.lib.pm_memcpy_d2h(out.ctypes.data, o, out.nbytes, None))
@@ -91,5 +102,8 @@ class Psi_Thermwind(object):
   def update(self, b1=None, b2=None):
     if b1 is not None:
       self.b1 = make_func(b1, self.z, 'b1')
+      self._b1_callable = callable(b1)
     if b2 is not None:
       self.b2 = make_func(b2, self.z, 'b2')
+      self._b2_callable = callable(b2)
+

@@ -27,6 +27,8 @@ Sets:
                        the example_iteration loop (solve_equi + thermal wind, 30 iterations)
   G13 equi_column      Equi_Column.solve outputs (z, psi, b, H) for the example scripts' problems
                        and the reference tests' configurations (np.NaN restored for NumPy 2)
+  G14 thermwind_callable  Psi_Thermwind.solve with CALLABLE profiles (hazard H7: solve_bvp evaluates
+                       them at its collocation midpoints and refines the mesh)
   G10 jn2018_files     the diagnostics / pickup .npz payloads of run_JansenNadeau_2018.py and a
                        restart from the pickup
 """
@@ -500,6 +502,21 @@ def g13_equi_column():
   save("equi_column", **out)
 
 
+# ------------------------------------------------------------------------ G14
+def g14_thermwind_callable():
+  out = {}
+  for nz in (100, 200):
+    z = np.asarray(np.linspace(-3500, 0, nz))
+    A = Psi_Thermwind(z=z, b1=configs.iteration_b_basin)  # as examples/example_iteration.py:38
+    A.solve()
+    out["nz%d_Psi" % nz] = A.Psi.copy()
+    B = Psi_Thermwind(z=z, b1=configs.iteration_b_basin,
+                      b2=lambda zz: 0.004 * np.exp(zz / 800.), f=1e-4)
+    B.solve()
+    out["nz%d_Psi2" % nz] = B.Psi.copy()
+  save("thermwind_callable", **out)
+
+
 # ------------------------------------------------------------------------- G8
 def member_of(cfg, i, keys_1d=(), keys_2d=()):
   m = dict(cfg)
@@ -721,10 +738,10 @@ def g9_twobasin():
 
 
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
   table = dict(g1=[g1_column_steps], g2=[g2_config1], g3=[g3_thermwind], g4=[g4_twocol],
                g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
-               g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column])
+               g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column], g14=[g14_thermwind_callable])
   for w in which:
     for fn in table[w]:
       fn()

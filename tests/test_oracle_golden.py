@@ -291,6 +291,24 @@ def test_equi_column_golden():
     assert abs(r["H"] - float(g[name + "_H"])) <= 1e-12 * abs(r["H"]), name
 
 
+# ------------------------------------------------- G14 thermal wind with callable profiles
+def test_thermwind_callable_profiles_golden():
+  """Callable b1 / b2 (hazard H7): with the profiles evaluated at the collocation midpoints
+  the solve is within 1e-7 of the reference at nz >= 100; what is left is the node or two
+  solve_bvp inserts.  Sampling on z alone (the array path) is 1.4e-3 away."""
+  g = load_golden("thermwind_callable")
+  b2f = lambda zz: 0.004 * np.exp(zz / 800.)
+  for nz in (100, 200):
+    z = np.linspace(-3500, 0, nz)
+    zm = z[:-1] + 0.5 * (z[1:] - z[:-1])
+    b1, b1m = configs.iteration_b_basin(z), np.append(configs.iteration_b_basin(zm), 0.)
+    Psi = O.thermwind_solve(z, b1, 0. * z, 1.2e-4, b1_mid=b1m, b2_mid=0. * z)
+    assert relerr(Psi, g["nz%d_Psi" % nz]) <= 1e-7
+    Psi2 = O.thermwind_solve(z, b1, b2f(z), 1e-4, b1_mid=b1m, b2_mid=np.append(b2f(zm), 0.))
+    assert relerr(Psi2, g["nz%d_Psi2" % nz]) <= 1e-7
+    assert relerr(O.thermwind_solve(z, b1, 0. * z, 1.2e-4), g["nz%d_Psi" % nz]) > 1e-5
+
+
 # --------------------------------------------------------------------- G8 sweep members
 def _member(cfg, i, keys):
   m = dict(cfg)
