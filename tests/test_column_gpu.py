@@ -147,3 +147,35 @@ def test_config2_full_size_properties(gpu):
   noconv = ~c["do_conv"]
   assert np.array_equal(b_one[noconv, -1], c["bs"][noconv])
 
+
+
+@pytest.mark.parametrize("nz,G", [(17, 0), (64, 0), (100, 0), (128, 0), (100, 32), (250, 0)])
+def test_convective_pattern_churn_vs_oracle(gpu, nz, G):
+  """Fuzz of the speculative convective step: noisy profiles, strong oscillating forcing,
+  surface values above AND below the interior, bbot above bs on some members -- the convecting
+  pattern of the batch changes 300 ... 1700 times in the 400 steps (counted on the oracle), so
+  the redo branch and the cached adjustment are exercised throughout.  400 fused steps, bit-identical to the oracle, and to 8 x 50 fused steps."""
+  rng = np.random.default_rng(1000 + nz)
+  n = 96
+  z = np.linspace(-4000, 0, nz) + np.concatenate(
+      ([0.], rng.uniform(-0.3, 0.3, nz - 2) * 4000 / (nz - 1), [0.]))  # jittered grid
+  kappa = 10**rng.uniform(-5, -3.5, (n, 1)) * (1 + 0.5 * rng.random((n, nz)))
+  area = 10**rng.uniform(13, 14, (n, 1)) * np.ones((1, nz))
+  b0 = 0.02 * np.exp(z / 400.)[None, :] * (1 + 0.3 * rng.standard_normal((n, nz)))
+  wA = 3e7 * np.sin(np.pi * (z / 4000.)[None, :] * rng.integers(1, 6, (n, 1))) * \
+      rng.uniform(0.2, 2.0, (n, 1))
+  bs = rng.uniform(0.0, 0.03, n)
+  bbot = np.where(rng.random(n) < 0.2, bs + 0.005, rng.uniform(-0.002, 0.002, n))
+  N2min = 10**rng.uniform(-8, -6, n)
+  dzmin = np.diff(z).min()
+  dt = 0.45 * min(dzmin**2 / (2 * kappa.max()), dzmin / (np.abs(wA).max() / area.min() + 1e-30))
+  do_conv = np.ones(n, bool)
+  ref = O.column_ensemble_steps(z, kappa, area, b0, wA, dt, do_conv, bs, bbot, N2min, 400)
+  batch = gpu.ColumnBatch(z, kappa, area, b0, bs=bs, bbot=bbot, N2min=N2min, do_conv=do_conv)
+  batch.steps(wA, dt, 400, lanes_per_col=G)
+  assert np.array_equal(batch.get_b(), ref, equal_nan=True)
+  batch2 = gpu.ColumnBatch(z, kappa, area, b0, bs=bs, bbot=bbot, N2min=N2min, do_conv=do_conv)
+  for _ in range(8):
+    batch2.steps(wA, dt, 50, lanes_per_col=G)
+  assert np.array_equal(batch2.get_b(), ref, equal_nan=True)
+  assert np.isfinite(ref).all()
