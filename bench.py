@@ -80,8 +80,8 @@ def load_traffic(path, key):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=20, help="timed launches (bench steps)")
-  ap.add_argument("--warmup", type=int, default=2, help="untimed launches")
+  ap.add_argument("--steps", type=int, default=50, help="timed launches (bench steps)")
+  ap.add_argument("--warmup", type=int, default=5, help="untimed launches")
   ap.add_argument("--steps-per-launch", type=int, default=1000,
                   help="model time steps fused in one launch (= one bench step)")
   ap.add_argument("--columns", type=int, default=1024, help="columns per GPU")
