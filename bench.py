@@ -118,6 +118,9 @@ def main():
   dt = cfg["dt"]
 
   run_steps(batch, wA, dt, W * F, F, args.lanes)
+  if use_gather:  # RCCL sets its channels up at the first call of each collective: not timed
+    comm.allgather_device(batch.b, gathered, stream)
+    comm.max_host(0.0)
   stream.sync()
 
   ev0, ev1 = Event(), Event()
