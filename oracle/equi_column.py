@@ -13,23 +13,31 @@ from scipy import integrate
 
 
 def problem(f=1.2e-4, b_s=0.025, b_bot=None, B_int=3e3, A=7e13, nz=100, H_guess=1500.,
-            kappa=6e-5, psi_so=None, z=None, H=None):
-  """Parameter dict of one equilibrium column (profiles: numbers or arrays on z)."""
+            kappa=6e-5, psi_so=None, z=None, H=None, dkappa_dz=None):
+  """Parameter dict of one equilibrium column (profiles: numbers, arrays on z or callables)."""
   return dict(f=f, b_s=b_s, b_bot=b_bot, B_int=B_int, A=A, nz=nz, H_guess=H_guess,
-              kappa=kappa, psi_so=psi_so, z=z, H=H)
+              kappa=kappa, psi_so=psi_so, z=z, H=H, dkappa_dz=dkappa_dz)
 
 
 def _profiles(q):
   f, z = q['f'], q['z']
-  kap, pso = q['kappa'], q['psi_so']
-  if isinstance(kap, np.ndarray):
+  kap, pso, dkz = q['kappa'], q['psi_so'], q.get('dkappa_dz')
+  if callable(kap):  # equi_column.py:125-128, :146-149
+    kappa = lambda x, H: kap(x * H) / (H**2 * f)
+    if callable(dkz):
+      dkappa = lambda x, H: dkz(x * H) / (H * f)
+    else:
+      dkappa = lambda x, H: np.gradient(kap(x * H), x * H) / (H * f)
+  elif isinstance(kap, np.ndarray):
     dk = np.gradient(kap, z)
     kappa = lambda x, H: np.interp(x * H, z, kap) / (H**2 * f)
     dkappa = lambda x, H: np.interp(x * H, z, dk) / (H * f)
   else:
     kappa = lambda x, H: kap / (H**2 * f)
     dkappa = lambda x, H: 0
-  if isinstance(pso, np.ndarray):
+  if callable(pso):
+    psi = lambda x, H: pso(x * H) / (f * H**3)
+  elif isinstance(pso, np.ndarray):
     psi = lambda x, H: np.interp(x * H, z, pso) / (f * H**3)
   else:
     psi = lambda x, H: 0

@@ -357,3 +357,15 @@ def equi_column_cases():
     pso = 4e6 * np.sin(-np.pi * np.maximum(z161, -Hm) / Hm)**2
     cases["Bint%d" % i] = dict(B_int=B, A=A, kappa=kap, psi_so=pso, z=z161)
   return cases
+
+
+def equi_bint_callable_case(i):
+  """Case i of examples/example_Equi_Bint.py:16-60 with its CALLABLE kappa, dkappa_dz and
+  psi_so (the drop-in class tabulates them; the oracle calls them like the reference)."""
+  Hm, B = ((2000, 3e3), (2000, 1.2e4), (1500, 3e3), (1500, 1.2e4))[i]
+  a = 6.37e6
+  A = 2 * np.pi * a**2 * 59 / 360 * (np.sin(np.radians(69)) - np.sin(np.radians(-48)))
+  kappa = lambda z: 1e-5 + 3e-5 * np.exp(z / 100) + 3e-4 * np.exp(-z / 1000 - 4)
+  dkappa_dz = lambda z: 3e-5 / 100 * np.exp(z / 100) - 3e-4 / 1000 * np.exp(-z / 1000 - 4)
+  psi_so = lambda z: 4. * 1e6 * np.sin(-np.pi * np.maximum(z, -Hm) / Hm)**2
+  return dict(B_int=B, A=A, kappa=kappa, dkappa_dz=dkappa_dz, psi_so=psi_so)

@@ -13,9 +13,10 @@ the solution to a refined mesh through the C1 cubic spline of `create_spline`, a
 with solve_bvp's status codes (0 converged, 1 max_nodes, 2 singular Jacobian, 3 boundary
 residual not met after 10 iterations).
 
-Profiles (`kappa`, `psi_so`) are scalars or samples on the model grid `z`, exactly the cases
-the reference turns into np.interp closures; callables cannot run on the device (they would
-have to be called with the unknown depth H inside Newton's iteration) and are rejected.
+Profiles (`kappa`, `psi_so`) are scalars or samples on a grid `z`, exactly the cases the
+reference turns into np.interp closures; callables cannot run on the device (they would have
+to be called with the unknown depth H inside Newton's iteration): the drop-in class tabulates
+them on a fine grid first (`pymoc_amd.modules.Equi_Column`).
 """
 import ctypes as C
 
@@ -55,7 +56,7 @@ class EquiColumnBatch(object):
 
   def __init__(self, n, f=1.2e-4, b_s=0.025, b_bot=None, B_int=3e3, A=7e13, nz=100,
                sol_init=None, H_guess=1500., kappa=6e-5, psi_so=None, z=None, H=None,
-               tol=1e-3, max_nodes=1000, stream=None):
+               tol=1e-3, max_nodes=1000, stream=None, dkappa_dz=None):
     _lib.require_device()
     if b_bot is None and B_int is None:
       raise Exception('You need to specify either b_bot or B_int for bottom boundary condition')
@@ -77,7 +78,11 @@ class EquiColumnBatch(object):
       if self.zg is None:
         raise ValueError('array kappa needs the grid z')
       self.kappa_z = np.broadcast_to(kap, (n, self.zg.size)).copy()
-      self.dkappa_z = np.array([np.gradient(k, self.zg) for k in self.kappa_z])
+      if dkappa_dz is not None:  # samples of a given derivative (callable profiles, tabulated)
+        self.dkappa_z = np.broadcast_to(np.asarray(dkappa_dz, np.float64),
+                                        (n, self.zg.size)).copy()
+      else:
+        self.dkappa_z = np.array([np.gradient(k, self.zg) for k in self.kappa_z])
       self.kappa = np.zeros(n)
     else:
       self.kappa = vec(kap)

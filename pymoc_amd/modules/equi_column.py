@@ -6,12 +6,17 @@ the non-dimensional profile closures) are host NumPy, as in the reference -- the
 SciPy would call back into; `solve()` hands the problem to `pymoc_amd.EquiColumnBatch`, which
 runs solve_bvp's Newton iteration and residual control on the device.
 
-Deviation: `kappa` / `psi_so` given as CALLABLES cannot be solved here (`solve()` raises
-NotImplementedError): the reference calls them with the unknown depth H inside every Newton
-step, which has no device counterpart.  Pass samples on `z` instead -- the reference treats
-those as np.interp closures and so does the kernel.
+Deviation: `kappa` / `dkappa_dz` / `psi_so` given as CALLABLES are tabulated on a fine uniform
+grid (TABLE_POINTS levels over [-TABLE_DEPTH_FACTOR * depth, 0]) and interpolated linearly on
+the device: the reference calls them with the unknown depth H inside every Newton step, which
+has no device counterpart.  Against the reference this costs ~1e-8 (measured on the callables
+of examples/example_Equi_Bint.py: same meshes, H to 4e-10, psi / b to 7e-9; golden G13);
+numbers and arrays on `z` are exact.
 """
 import numpy as np
+
+TABLE_POINTS = 65537        # levels of the table a callable profile is sampled on
+TABLE_DEPTH_FACTOR = 4.0    # the table reaches this many times H (or H_guess) deep
 
 
 class Equi_Column(object):
@@ -38,7 +43,7 @@ class Equi_Column(object):
     self.z = z
     self.zi = np.asarray(np.linspace(-1, 0, nz))
     self._nz = nz
-    self._kappa_in, self._psi_in, self._sol_init_in = kappa, psi_so, sol_init
+    self._kappa_in, self._dkappa_in, self._psi_in = kappa, dkappa_dz, psi_so
     self.kappa = self.init_kappa(kappa)
     self.dkappa_dz = self.init_dkappa_dz(kappa, dkappa_dz)
     self.init_psi_so(psi_so)
@@ -132,18 +137,32 @@ class Equi_Column(object):
   # ---- equi_column.py:408-435
   def solve(self):
     from ..equi_column import EquiColumnBatch
-    if callable(self._kappa_in) or callable(self._psi_in):
-      raise NotImplementedError(
-          'Equi_Column.solve on the GPU needs kappa / psi_so as numbers or as arrays on z '
-          '(callables are evaluated with the unknown depth H inside every Newton step of '
-          'scipy.integrate.solve_bvp and have no device counterpart)')
+    kappa_in, psi_in, zg, dk_in = self._kappa_in, self._psi_in, self.z, None
+    if callable(kappa_in) or callable(psi_in):
+      # tabulate: callables -> samples; array / scalar companions are re-sampled the way the
+      # reference's closures would evaluate them (np.interp on self.z, or constant)
+      depth = TABLE_DEPTH_FACTOR * (self.H if self.H is not None else self.H_guess)
+      if self.z is not None:
+        depth = max(depth, -float(np.min(self.z)))
+      zg = np.linspace(-depth, 0., TABLE_POINTS)
+      sample = lambda v: (v(zg) if callable(v) else
+                          (np.interp(zg, self.z, v) if isinstance(v, np.ndarray) else None))
+      if callable(kappa_in):
+        dk_in = (self._dkappa_in(zg) if callable(self._dkappa_in)
+                 else np.gradient(kappa_in(zg), zg))
+        kappa_in = kappa_in(zg)
+      elif isinstance(kappa_in, np.ndarray):
+        dk_in = np.interp(zg, self.z, np.gradient(kappa_in, self.z))
+        kappa_in = sample(kappa_in)
+      if callable(psi_in) or isinstance(psi_in, np.ndarray):
+        psi_in = np.asarray(sample(psi_in), dtype=np.float64)
     bbot_set = getattr(self, 'b_bot', None) is not None
     f2 = self.f**2
     eq = EquiColumnBatch(
         1, f=self.f, b_s=-self.bs * f2, b_bot=-self.b_bot * f2 if bbot_set else None,
         B_int=None if bbot_set else self.B_int, A=self.A, nz=np.shape(self.sol_init)[1],
         sol_init=np.asarray(self.sol_init, dtype=np.float64)[None], H_guess=self.H_guess,
-        kappa=self._kappa_in, psi_so=self._psi_in, z=self.z, H=self.H)
+        kappa=kappa_in, psi_so=psi_in, z=zg, H=self.H, dkappa_dz=dk_in)
     eq.zi = self.zi
     eq.bs[:] = self.bs  # exactly the reference's non-dimensional values
     if bbot_set:

@@ -498,6 +498,12 @@ def g13_equi_column():
     names.append(name)
     out.update({name + "_z": m.z, name + "_psi": m.psi, name + "_b": m.b,
                 name + "_H": np.array(m.H)})
+  for i in range(4):  # the example script's own callables
+    m = Equi_Column(**configs.equi_bint_callable_case(i))
+    m.solve()
+    name = "Bint_fn%d" % i
+    out.update({name + "_z": m.z, name + "_psi": m.psi, name + "_b": m.b,
+                name + "_H": np.array(m.H)})
   out["names"] = np.array(names)
   save("equi_column", **out)
 

@@ -89,9 +89,23 @@ def test_equi_column_api_contract(gpu):
   assert c2.dkappa_dz(-0.5, 500.) == np.interp(-250., z, np.gradient(karr, z)) / (500. * 1.2e-4)
   assert c2.psi_so(-0.5, 500.) == np.interp(-250., z, (z + 2000)**2) / (1.2e-4 * 500.**3)
   assert np.array_equal(c2.bc(ya, yb), np.array([1., 5., 3. - c2.b_bot / 500., 7. - c2.bs / 500.]))
-  c3 = gpu.Equi_Column(z=z, B_int=3e3, A=2.0e14, kappa=lambda zz: -3e-5 * zz / 4e3, H=500.0)
-  with pytest.raises(NotImplementedError):
-    c3.solve()
+
+
+def test_equi_column_callable_profiles_are_tabulated(gpu):
+  """examples/example_Equi_Bint.py with its own callables (kappa, dkappa_dz, psi_so): the
+  drop-in class samples them on a 65537-level table; same meshes as the reference, depth and
+  profiles to 1e-7 (measured: H 4e-10, psi / b 7e-9)."""
+  g = load_golden("equi_column")
+  for i in range(4):
+    m = gpu.Equi_Column(**configs.equi_bint_callable_case(i))
+    m.solve()
+    name = "Bint_fn%d" % i
+    assert m.status == 0
+    Href = float(g[name + "_H"])
+    assert abs(m.H - Href) <= 1e-7 * Href, (i, m.H, Href)
+    zr, pr, br = g[name + "_z"], g[name + "_psi"], g[name + "_b"]
+    assert m.z.size == zr.size and relerr(m.z, zr) <= 1e-7
+    assert relerr(m.psi, pr) <= 1e-7 and relerr(m.b, br) <= 1e-7, i
 
 
 def test_equi_column_failure_modes_match_solve_bvp(gpu):

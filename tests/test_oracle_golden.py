@@ -289,6 +289,13 @@ def test_equi_column_golden():
     assert relerr(z, g[name + "_z"]) <= 1e-14, name
     assert relerr(psi, g[name + "_psi"]) <= 1e-12 and relerr(b, g[name + "_b"]) <= 1e-12, name
     assert abs(r["H"] - float(g[name + "_H"])) <= 1e-12 * abs(r["H"]), name
+  for i in range(4):  # examples/example_Equi_Bint.py with its callables
+    q = EO.problem(**configs.equi_bint_callable_case(i))
+    r = EO.solve(q)
+    z, psi, b = EO.outputs(q, r)
+    name = "Bint_fn%d" % i
+    assert relerr(psi, g[name + "_psi"]) <= 1e-12 and relerr(b, g[name + "_b"]) <= 1e-12
+    assert abs(r["H"] - float(g[name + "_H"])) <= 1e-12 * abs(r["H"])
 
 
 # ------------------------------------------------- G14 thermal wind with callable profiles
