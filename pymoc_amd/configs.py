@@ -369,3 +369,14 @@ def equi_bint_callable_case(i):
   dkappa_dz = lambda z: 3e-5 / 100 * np.exp(z / 100) - 3e-4 / 1000 * np.exp(-z / 1000 - 4)
   psi_so = lambda z: 4. * 1e6 * np.sin(-np.pi * np.maximum(z, -Hm) / Hm)**2
   return dict(B_int=B, A=A, kappa=kappa, dkappa_dz=dkappa_dz, psi_so=psi_so)
+
+
+# ----------------------------------------- callable surface profiles for Psi_SO (hazard H7)
+def so_bs_callable(y, bs=0.03, bmin=0.0, l=2.e6):
+  """Surface buoyancy across the channel as a FUNCTION of y (example_twocol_plusSO.py:57-58)."""
+  return (bs - bmin) * (y / l)**2 + bmin
+
+
+def so_tau_callable(y, tau0=0.13, l=2.e6):
+  """A wind-stress profile peaking mid-channel."""
+  return tau0 * (0.3 + 0.7 * np.sin(np.pi * y / l)**2)

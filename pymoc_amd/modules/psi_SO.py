@@ -1,15 +1,20 @@
 """Drop-in `Psi_SO` with the reference's Python API, computing on the GPU.
 
 Same constructor, attributes, methods and error text as `pymoc.modules.Psi_SO`
-(src/pymoc/modules/psi_SO.py:8-375).  `b`, `bs`, `tau` given as callables are sampled on
-their grid (`z` / `y`) and interpolated linearly in between; array and float inputs behave
-exactly like the reference.  `ys` is the direct inverse of the piecewise-linear bs(y) where
+(src/pymoc/modules/psi_SO.py:8-375).  Array and float inputs behave exactly like the
+reference; a callable `b` is only ever evaluated on `z` (exact); callable `bs` / `tau`, which
+the reference evaluates between grid points (inside brentq and the 100-point wind average),
+are tabulated on a FINE_Y-point refinement of `y` that the kernel interpolates linearly
+(1e-4 from the reference where bs(y) is flat, i.e. where the outcrop latitude is ill-conditioned;
+1e-6 otherwise).  `ys` is the direct inverse of the piecewise-linear bs(y) where
 that is unique (the reference root-finds it with brentq to xtol=2e-12) and brentq's own
 iteration where bs is not monotone; the GM boundary-value problem
 (`c` not None) is solved by 4th-order collocation on a refined fixed mesh instead of
 SciPy's adaptive solve_bvp (agreement ~1e-6).
 """
 import numpy as np
+
+FINE_Y = 2048  # points of the y table that callable bs / tau are sampled on
 
 from .. import _lib
 from ..device import DeviceArray
@@ -48,6 +53,7 @@ class Psi_SO(object):
     self.b = make_func(b, self.z, 'b')
     self.bs = make_func(bs, self.y, 'bs')
     self.tau = make_func(tau, self.y, 'tau')
+    self._bs_callable, self._tau_callable = callable(bs), callable(tau)
     self._tau_is_float = isinstance(tau, float)
     self._tau_float = tau if self._tau_is_float else None
     self.f = f
@@ -65,15 +71,23 @@ class Psi_SO(object):
 
   # ---- device plumbing: one arena, one H2D and one D2H per call
   # arena (float64 slots): [b | bs | tau | KGM | Psi_Ek | Psi | Psi_GM | Ek_raw | GM_raw | ys]
+  def _kernel_y(self):
+    """The meridional grid handed to the kernel: `y` itself, or its refinement when bs / tau
+    are callables (same end points, so every use of y[0] / y[-1] is unchanged)."""
+    if (self._bs_callable or self._tau_callable) and np.size(self.y) < FINE_Y:
+      return np.linspace(self.y[0], self.y[-1], FINE_Y)
+    return self.y
+
   def _alloc(self):
-    nz, ny = np.size(self.z), np.size(self.y)
+    self._yk = np.ascontiguousarray(self._kernel_y(), dtype=np.float64)
+    nz, ny = np.size(self.z), np.size(self._yk)
     self._nz, self._ny = nz, ny
     self._nin = nz + 2 * ny + 1 + nz
     self._host = np.zeros(self._nin)
     self._out = np.zeros((6, nz))
     self._arena = DeviceArray((self._nin + 5 * nz,))
     self._zd = DeviceArray.from_host(np.ascontiguousarray(self.z, dtype=np.float64))
-    self._yd = DeviceArray.from_host(np.ascontiguousarray(self.y, dtype=np.float64))
+    self._yd = DeviceArray.from_host(self._yk)
     self._status = DeviceArray.zeros((1,), np.int32)
     p, d = self._arena.ptr, _lib.pm_psi_so()
     d.n, d.nz, d.ny, d.reserved = 1, nz, ny, 0
@@ -89,7 +103,7 @@ class Psi_SO(object):
   def _run(self, ops, b=None):
     import ctypes as C
     if getattr(self, "_arena", None) is None or self._nz != np.size(self.z) or \
-        self._ny != np.size(self.y):
+        self._ny != np.size(self._kernel_y()):
       self._alloc()
     nz, ny, h, d = self._nz, self._ny, self._host, self._desc
     fl = 0
@@ -103,12 +117,12 @@ class Psi_SO(object):
     if self.bvp_with_Ek:
       fl |= _lib.PM_SO_BVP_WITH_EK
     h[0:nz] = make_array(self.b, self.z, 'b') if b is None else b
-    h[nz:nz + ny] = make_array(self.bs, self.y, 'bs')
+    h[nz:nz + ny] = make_array(self.bs, self._yk, 'bs')
     if self._tau_is_float:
       h[nz + ny] = self._tau_float
     else:
       fl |= _lib.PM_SO_TAU_ARRAY
-      h[nz + ny:nz + 2 * ny] = make_array(self.tau, self.y, 'tau')
+      h[nz + ny:nz + 2 * ny] = make_array(self.tau, self._yk, 'tau')
     h[nz + 2 * ny] = self.KGM
     if ops == _lib.PM_SO_OP_GM:
       h[nz + 2 * ny + 1:] = self.Psi_Ek
@@ -152,3 +166,4 @@ class Psi_SO(object):
       self.b = make_func(b, self.z, 'b')
     if bs is not None:
       self.bs = make_func(bs, self.y, 'bs')
+      self._bs_callable = callable(bs)

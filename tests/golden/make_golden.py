@@ -29,6 +29,8 @@ Sets:
                        and the reference tests' configurations (np.NaN restored for NumPy 2)
   G14 thermwind_callable  Psi_Thermwind.solve with CALLABLE profiles (hazard H7: solve_bvp evaluates
                        them at its collocation midpoints and refines the mesh)
+  G15 psi_so_callable  Psi_SO.solve with CALLABLE bs / tau (evaluated between grid points by the
+                       reference: inside brentq and the 100-point wind average)
   G10 jn2018_files     the diagnostics / pickup .npz payloads of run_JansenNadeau_2018.py and a
                        restart from the pickup
 """
@@ -523,6 +525,22 @@ def g14_thermwind_callable():
   save("thermwind_callable", **out)
 
 
+# ------------------------------------------------------------------------ G15
+def g15_psi_so_callable():
+  m = configs.twocol_so_member(nz=100, ny=40)
+  z, y = m['z'], m['y']
+  out = {}
+  for tag, kw in (("slope", dict(c=None)), ("bvp", dict(c=0.1, bvp_with_Ek=True))):
+    for ttag, tau in (("taufn", configs.so_tau_callable), ("tau", 0.13)):
+      so = Psi_SO(z=z, y=y, b=m['b_basin0'], bs=configs.so_bs_callable, tau=tau, f=m['f'],
+                  L=m['L'], KGM=m['KGM'], **kw)
+      so.solve()
+      p = tag + "_" + ttag + "_"
+      out.update({p + "Psi": so.Psi.copy(), p + "Psi_Ek": so.Psi_Ek.copy(),
+                  p + "Psi_GM": so.Psi_GM.copy()})
+  save("psi_so_callable", **out)
+
+
 # ------------------------------------------------------------------------- G8
 def member_of(cfg, i, keys_1d=(), keys_2d=()):
   m = dict(cfg)
@@ -744,10 +762,10 @@ def g9_twobasin():
 
 
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
   table = dict(g1=[g1_column_steps], g2=[g2_config1], g3=[g3_thermwind], g4=[g4_twocol],
                g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
-               g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column], g14=[g14_thermwind_callable])
+               g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column], g14=[g14_thermwind_callable], g15=[g15_psi_so_callable])
   for w in which:
     for fn in table[w]:
       fn()
