@@ -193,6 +193,30 @@ def main():
           "ms_per_step": ms1, "column_timesteps_per_s": C / (ms1 * 1e-3),
           "achieved_GBps_algorithmic": 24.0 * nz * C / (ms1 * 1e-3) / 1e9,
           "achieved_GBps_with_static_coefficients": 48.0 * nz * C / (ms1 * 1e-3) / 1e9}
+    if not args.no_single_step and world == 1 and C == 1024 and nz == 100:
+      # the SAME kernel where it is memory-bound: one step per launch on an ensemble far
+      # beyond the caches (262144 columns: 1.26 GB cross HBM per launch); not part of `value`
+      Cb = 262144
+      cb = configs.config2(N=Cb, nz=nz)
+      big = pymoc_amd.ColumnBatch(cb["z"], cb["kappa"], cb["Area"], cb["b0"], bs=cb["bs"],
+                                  bbot=cb["bbot"], N2min=cb["N2min"], do_conv=cb["do_conv"],
+                                  stream=stream)
+      wAb = DeviceArray.from_host(cb["wA"], stream=stream)
+      run_steps(big, wAb, dt, 3, 1, args.lanes)
+      stream.sync()
+      e0, e1 = Event(), Event()
+      e0.record(stream)
+      run_steps(big, wAb, dt, 20, 1, args.lanes)
+      e1.record(stream)
+      stream.sync()
+      msb = e0.elapsed_ms(e1) / 20
+      real = 48.0 * nz * Cb  # b, wA, kappa, Area, dAkappa in; b out
+      out["streaming_262144_columns"] = {
+          "ms_per_step": msb, "column_timesteps_per_s": Cb / (msb * 1e-3),
+          "hbm_GBps": real / (msb * 1e-3) / 1e9,
+          "frac_of_hbm_peak": real / (msb * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+          "achieved_GBps_algorithmic": 24.0 * nz * Cb / (msb * 1e-3) / 1e9}
+      del big, wAb
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(cfg)
     print(json.dumps(out), flush=True)
