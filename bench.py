@@ -1,25 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- column-timesteps/s of the HIP column engine on BASELINE config 2.
+"""bench.py -- throughput of the HIP engine on BASELINE.json's configs, one JSON line.
 
-Workload (configs[1] of BASELINE.json): an ensemble of 1024
-independent advective-diffusive Columns per GPU, nz=100, fp64, prescribed static upwelling
-wA, convective adjustment on odd members, dt=30 d.  A bench "step" is one pass of the hot
-path over the rank's batch: ONE launch that advances every column by `--steps-per-launch`
-(default 1000) model time steps -- the config's whole job, wA being static (the coupled
-drivers fuse a MOC-update interval the same way).  `value` counts Column.timestep calls:
-columns x steps x steps-per-launch / time.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
 
-  python bench.py --gpus 1 --steps K --warmup W
+Default (`--config 2`, BASELINE configs[1], the configuration the metric is quoted on): an
+ensemble of 1024 independent advective-diffusive Columns per GPU, nz=100, fp64.  A bench
+"step" is one pass of the hot path over the rank's batch: ONE launch that advances every
+column by `--steps-per-launch` (default 1000 = the config's whole job; wA is static) model
+time steps.  `value` counts Column.timestep calls: columns x K x steps-per-launch / time.
+At N=1 the same line also carries, under "coupled", the driver-run numbers of the coupled
+configs 3, 4 and 5 at their SURVEY 8d sizes and full run lengths (2400 / 2400 / 3600 model
+steps), each with its dominant kernel's roofline and a CPU baseline.
+
+`--config 3|4|5` makes a coupled config the headline instead: a bench step is then one
+MOC-update interval (MOC_up_iters model steps of both columns [+ the mixed layer] and one
+refresh of the diagnostics); with N>1 every rank owns a fixed number of members (weak
+scaling) and {b_basin, b_north, Psi_AMOC, Psi_SO} are all-gathered with RCCL on device
+buffers every Diag_iters model steps and at the end, inside the timed region.
+
+N>1: one process per GPU.  Either the driver's launcher
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-      --master-port P bench.py --gpus N --steps K --warmup W
+      --master-port P bench.py --gpus N ...
+or plain `python bench.py --gpus N ...`, which starts the N ranks itself through
+pymoc_amd/launch.py (no torch anywhere in the product).  RCCL barrier + device sync on
+both sides of the timed region, max over ranks, rank 0 prints the line.
 
-One process per GPU; the launcher only provides RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*.
-Ranks own disjoint member blocks (weak scaling: 1024 columns per GPU), synchronise with
-an RCCL barrier on both sides of the timed region, and all-gather the final buoyancy
-(the diagnostic output) with RCCL inside it.  Rank 0 prints ONE JSON line.
+The CPU baselines (oracle/, the plain-C restatement of the reference's algorithm driven
+member by member like the reference's loops) are timed FIRST, before this process touches
+the GPU: on 1 core and on all cores this process may use (`multiprocessing`, fork).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -30,7 +42,153 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6   # fp64 vector: 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz
+
+SIZES = {  # per-GPU members and run length of each config
+    2: dict(members=1024, nsteps=1000, ncol=1),
+    3: dict(members=4096, nsteps=2400, ncol=2),
+    4: dict(members=8192, nsteps=2400, ncol=2),
+    5: dict(members=4096, nsteps=3600, ncol=2),
+}
+WORKLOAD = {
+    2: "BASELINE configs[1]: ensemble of %d independent Columns nz=%d fp64 per GPU, static wA, "
+       "do_conv on odd members, dt=30 d (pymoc_amd.configs.config2, seed 20240)",
+    3: "BASELINE configs[2]: %d two-column + Psi_Thermwind members per GPU (example_twocol.py "
+       "physics, nz=%d, MOC_up_iters=24, nb=500; pymoc_amd.configs.config3, seed 20241)",
+    4: "BASELINE configs[3]: %d two-column + SO-channel members per GPU (example_twocol_plusSO.py"
+       " physics, nz=%d, ny=40, c=0.1 GM boundary-value smoother; pymoc_amd.configs.config4, "
+       "seed 20242)",
+    5: "BASELINE configs[4]: %d run_JansenNadeau_2018.py members per GPU (nz=%d, dt=10 d, "
+       "ny=51, MOC_up_iters=36, nb=500; pymoc_amd.configs.config5, seed 20243)",
+}
+
+
+# ------------------------------------------------------------------------- flop models
+def flops_column_step(nz):
+  """K1: ~14 flop per interior level incl. the 3 divisions (SURVEY 8d 'Flops')."""
+  return 14.0 * (nz - 2)
+
+
+def flops_thermwind_update(nz, nb):
+  """K2 + K3 per member and update: solve 12 nz, Psib 6 nb (nz-1), Psibz 2 x 10 nz."""
+  return 12.0 * nz + 6.0 * nb * (nz - 1) + 20.0 * nz
+
+
+def flops_so_ml_step(ny):
+  return 30.0 * ny
+
+
+# ------------------------------------------------------------------------ CPU baselines
+def usable_cores():
+  """Cores this process may really use: affinity mask, capped by a cgroup CPU quota."""
+  n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+  try:
+    with open("/sys/fs/cgroup/cpu.max") as f:
+      quota, period = f.read().split()
+    if quota != "max":
+      n = max(1, min(n, int(math.ceil(float(quota) / float(period)))))
+  except Exception:
+    pass
+  return n
+
+
+def _cpu_worker(job):
+  """One worker = one core: repeat whole member runs of its slice until the budget is
+  spent.  Returns (column-timesteps done, seconds)."""
+  config, lo, hi, n_total, nz, budget = job
+  import oracle as O
+  from oracle import drivers as D
+  from pymoc_amd import configs
+  size = SIZES[config]
+  if config == 2:
+    c = configs.config2(N=n_total, nz=nz, members=(lo, hi))
+    a = (c["z"], c["kappa"], c["Area"])
+    chunk, done, b = 250, 0, c["b0"]
+    O.column_ensemble_steps(*a, b[:1], c["wA"][:1], c["dt"], c["do_conv"][:1], c["bs"][:1],
+                            c["bbot"][:1], c["N2min"][:1], 2)  # page in
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget:
+      b = O.column_ensemble_steps(*a, b, c["wA"], c["dt"], c["do_conv"], c["bs"], c["bbot"],
+                                  c["N2min"], chunk)
+      done += chunk
+    return (hi - lo) * done, time.perf_counter() - t0
+  cfg = {3: configs.config3, 4: configs.config4, 5: configs.config5}[config](
+      N=n_total, members=(lo, hi))
+  nsteps = size["nsteps"]
+  units, j = 0, 0
+  t0 = time.perf_counter()
+  while time.perf_counter() - t0 < budget:
+    m = configs.member(cfg, j % (hi - lo), config)
+    if config == 3:
+      D.run_twocol(m, nsteps, ())
+    elif config == 4:
+      D.run_twocol(m, nsteps, (), so=True, bvp_refine=8)
+    else:
+      D.run_jn2018(m, nsteps, ())
+    units += size["ncol"] * nsteps
+    j += 1
+  return units, time.perf_counter() - t0
+
+
+def cpu_baseline(config, nz, budget_1=6.0, budget_all=6.0, max_workers=0):
+  """The oracle on the same workload: (i) 1 process = 1 core, (ii) one process per usable
+  core.  Bounded samples: every worker repeats full-length runs of members of its slice of
+  the ensemble for `budget` seconds."""
+  import multiprocessing as mp
+  size = SIZES[config]
+  n = size["members"]
+  unit = "column-timesteps/s"
+  u1, t1 = _cpu_worker((config, 0, min(n, 64), n, nz, budget_1))
+  cores = usable_cores()
+  workers = min(cores, max_workers) if max_workers else cores
+  workers = max(1, min(workers, n))
+  per = n // workers
+  jobs = [(config, w * per, (w + 1) * per, n, nz, budget_all) for w in range(workers)]
+  ctx = mp.get_context("fork")
+  t0 = time.perf_counter()
+  with ctx.Pool(workers) as pool:
+    res = pool.map(_cpu_worker, jobs, chunksize=1)
+  wall = time.perf_counter() - t0
+  rate_all = sum(u / t for u, t in res)
+  what = {2: "the config-2 column batch stepped 250 steps at a time",
+          3: "full 2400-step example_twocol member runs",
+          4: "full 2400-step example_twocol_plusSO member runs (GM BVP on the 8-fold mesh)",
+          5: "full 3600-step run_JansenNadeau_2018 member runs"}[config]
+  base = {"value": u1 / t1, "unit": unit, "cores": 1, "kind": "port",
+          "sample": "%s, members [0,%d) of the same ensemble, %.1f s on 1 core "
+                    "(oracle/pymoc_oracle.c gcc -O2 + oracle/drivers.py, member by member "
+                    "like the reference's loops)" % (what, min(n, 64), t1),
+          "coupled_steps_per_s": u1 / t1 / size["ncol"],
+          "all_cores": {"value": rate_all, "unit": unit, "cores": workers,
+                        "host_cores": os.cpu_count(), "usable_cores": cores,
+                        "coupled_steps_per_s": rate_all / size["ncol"],
+                        "sample": "%d forked workers x %.1f s, each on its own %d-member "
+                                  "slice (%.1f s wall incl. start-up)" %
+                                  (workers, budget_all, per, wall)}}
+  return base
+
+
+# ------------------------------------------------------------------------ GPU helpers
+def time_calls(fn, reps, stream, Event, warm=2):
+  """ms per call of `fn` (HIP events on the stream the kernels are launched on)."""
+  for _ in range(warm):
+    fn()
+  e0, e1 = Event(), Event()
+  e0.record(stream)
+  for _ in range(reps):
+    fn()
+  e1.record(stream)
+  stream.sync()
+  return e0.elapsed_ms(e1) / reps
+
+
+def load_json(path):
+  try:
+    with open(path) as f:
+      return json.load(f)
+  except Exception:
+    return {}
 
 
 def run_steps(batch, wA, dt, nsteps, per_launch, lanes):
@@ -44,71 +202,13 @@ def run_steps(batch, wA, dt, nsteps, per_launch, lanes):
   return launches
 
 
-def cpu_baseline(cfg, budget_s=12.0):
-  """The oracle (plain C port of the reference algorithm, 1 thread) on the same
-  workload: whole 1024-column x 1000-step jobs until `budget_s` of CPU time is spent."""
-  import oracle as O
-  ncols, nz = cfg["b0"].shape
-  O.column_ensemble_steps(cfg["z"], cfg["kappa"][:8], cfg["Area"][:8], cfg["b0"][:8],
-                          cfg["wA"][:8], cfg["dt"], cfg["do_conv"][:8], cfg["bs"][:8],
-                          cfg["bbot"][:8], cfg["N2min"][:8], 10)  # page in
-  chunk = 250
-  t0 = time.perf_counter()
-  done = 0
-  b = cfg["b0"]
-  while time.perf_counter() - t0 < budget_s:
-    b = O.column_ensemble_steps(cfg["z"], cfg["kappa"], cfg["Area"], b, cfg["wA"],
-                                cfg["dt"], cfg["do_conv"], cfg["bs"], cfg["bbot"],
-                                cfg["N2min"], chunk)
-    done += chunk
-  el = time.perf_counter() - t0
-  return {"value": ncols * done / el, "unit": "column-timesteps/s", "cores": 1,
-          "kind": "port",
-          "sample": "%d columns x nz=%d x %d steps of the same config-2 workload in %.1f s "
-                    "(oracle/pymoc_oracle.c, gcc -O2, 1 thread of %d host cores)" %
-                    (ncols, nz, done, el, os.cpu_count())}
-
-
-def load_traffic(path, key):
-  try:
-    with open(path) as f:
-      return json.load(f).get(key)
-  except Exception:
-    return None
-
-
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=50, help="timed launches (bench steps)")
-  ap.add_argument("--warmup", type=int, default=5, help="untimed launches")
-  ap.add_argument("--steps-per-launch", type=int, default=1000,
-                  help="model time steps fused in one launch (= one bench step)")
-  ap.add_argument("--columns", type=int, default=1024, help="columns per GPU")
-  ap.add_argument("--nz", type=int, default=100)
-  ap.add_argument("--lanes", type=int, default=0, help="lanes per column (0 = auto)")
-  ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--no-single-step", action="store_true")
-  ap.add_argument("--force-rccl", action="store_true",
-                  help="use the RCCL communicator even with one rank (plumbing check)")
-  args = ap.parse_args()
-
-  import pymoc_amd
-  from pymoc_amd import configs, sharding
-  from pymoc_amd.device import DeviceArray, Event, Stream
-
-  rank, world, local_rank = sharding.world_info()
-  if world != args.gpus:
-    raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run "
-                     "(one process per GPU)" % (args.gpus, world))
-  pymoc_amd._lib.require_device(local_rank)
-  stream = Stream()
-  comm = (sharding.RcclCommunicator(stream=stream) if args.force_rccl
-          else sharding.make_communicator(stream=stream))
-
-  C, nz, F, K, W = args.columns, args.nz, args.steps_per_launch, args.steps, args.warmup
-  lo, hi = rank * C, (rank + 1) * C
-  cfg = configs.config2(N=world * C, nz=nz, members=(lo, hi))
+# ------------------------------------------------------------------------- config 2
+def bench_config2(args, env):
+  pymoc_amd, configs, DeviceArray, Event = (env["pymoc_amd"], env["configs"],
+                                            env["DeviceArray"], env["Event"])
+  stream, comm, rank, world = env["stream"], env["comm"], env["rank"], env["world"]
+  C, nz, F, K, W = args.members or 1024, args.nz, args.steps_per_launch, args.steps, args.warmup
+  cfg = configs.config2(N=world * C, nz=nz, members=(rank * C, (rank + 1) * C))
   batch = pymoc_amd.ColumnBatch(cfg["z"], cfg["kappa"], cfg["Area"], cfg["b0"],
                                 bs=cfg["bs"], bbot=cfg["bbot"], N2min=cfg["N2min"],
                                 do_conv=cfg["do_conv"], stream=stream)
@@ -135,90 +235,320 @@ def main():
   stream.sync()
   comm.barrier(stream)
   pymoc_amd.synchronize()
-  elapsed = time.perf_counter() - t0
-  elapsed = comm.max_host(elapsed)
+  elapsed = comm.max_host(time.perf_counter() - t0)
   kernel_ms = ev0.elapsed_ms(ev1)
-
   nonfinite = int(batch.get_nonfinite().sum())
   b_final = batch.get_b()
+  if rank != 0:
+    return None
 
-  if rank == 0:
-    lanes = args.lanes or 64
-    value = world * C * K * F / elapsed
-    launch_s = kernel_ms * 1e-3 / launches
-    alg_bytes = 24.0 * nz * C * F  # read b, read wA, write b per model step
-    achieved = alg_bytes / launch_s / 1e9
-    traffic = load_traffic(os.path.join(ROOT, "profiles", "traffic_r01.json"),
-                           "column_steps_F%d_C%d_nz%d" % (F, C, nz))
-    out = {
-        "metric": "column-timesteps/sec (ensemble) at nz=%d" % nz,
-        "value": value, "unit": "column-timesteps/s", "n_gpus": world, "steps": K,
-        "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {
-            "workload": "BASELINE configs[1]: ensemble of %d independent Columns nz=%d "
-                        "fp64 per GPU, static wA, do_conv on odd members, dt=30 d "
-                        "(pymoc_amd.configs.config2, seed 20240)" % (C, nz),
-            "columns_per_gpu": C, "nz": nz, "model_steps_per_step": F,
-            "step": "one launch = %d Column.timestep calls of every column" % F,
-            "lanes_per_column": lanes,
-            "parallelism": "ensemble sharded over %d GPU(s), RCCL all-gather of the "
-                           "final state" % world},
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-            "traffic_unit": "bytes per launch (FETCH_SIZE+WRITE_SIZE, calibrated; profiles/)",
-            "kernel": "k_column_steps<%d,%d>" % (lanes, -(-nz // lanes)),
-            "kernel_ms_per_launch": launch_s * 1e3, "launches": launches,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "note": "algorithmic bytes = 24*nz per column-step (SURVEY 8d); with %d steps "
-                    "fused per launch the state stays in registers, so real HBM traffic "
-                    "(`traffic`) is far below it" % F},
-        "nonfinite_columns": nonfinite,
-        "checksum": float(np.sum(b_final)),
-    }
-    if not args.no_single_step:
-      # streaming mode for comparison: one step per launch (b, wA and the static
-      # coefficients cross HBM/L2 every step); not part of `value`
-      n1 = 2000
-      run_steps(batch, wA, dt, 200, 1, args.lanes)
-      stream.sync()
-      e0, e1 = Event(), Event()
-      e0.record(stream)
-      run_steps(batch, wA, dt, n1, 1, args.lanes)
-      e1.record(stream)
-      stream.sync()
-      ms1 = e0.elapsed_ms(e1) / n1
-      out["single_step_launches"] = {
-          "ms_per_step": ms1, "column_timesteps_per_s": C / (ms1 * 1e-3),
-          "achieved_GBps_algorithmic": 24.0 * nz * C / (ms1 * 1e-3) / 1e9,
-          "achieved_GBps_with_static_coefficients": 48.0 * nz * C / (ms1 * 1e-3) / 1e9}
-    if not args.no_single_step and world == 1 and C == 1024 and nz == 100:
-      # the SAME kernel where it is memory-bound: one step per launch on an ensemble far
-      # beyond the caches (262144 columns: 1.26 GB cross HBM per launch); not part of `value`
-      Cb = 262144
-      cb = configs.config2(N=Cb, nz=nz)
-      big = pymoc_amd.ColumnBatch(cb["z"], cb["kappa"], cb["Area"], cb["b0"], bs=cb["bs"],
-                                  bbot=cb["bbot"], N2min=cb["N2min"], do_conv=cb["do_conv"],
-                                  stream=stream)
-      wAb = DeviceArray.from_host(cb["wA"], stream=stream)
-      run_steps(big, wAb, dt, 3, 1, args.lanes)
-      stream.sync()
-      e0, e1 = Event(), Event()
-      e0.record(stream)
-      run_steps(big, wAb, dt, 20, 1, args.lanes)
-      e1.record(stream)
-      stream.sync()
-      msb = e0.elapsed_ms(e1) / 20
-      real = 48.0 * nz * Cb  # b, wA, kappa, Area, dAkappa in; b out
-      out["streaming_262144_columns"] = {
-          "ms_per_step": msb, "column_timesteps_per_s": Cb / (msb * 1e-3),
-          "hbm_GBps": real / (msb * 1e-3) / 1e9,
-          "frac_of_hbm_peak": real / (msb * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-          "achieved_GBps_algorithmic": 24.0 * nz * Cb / (msb * 1e-3) / 1e9}
-      del big, wAb
-    if world == 1 and not args.no_cpu_baseline:
-      out["cpu_baseline"] = cpu_baseline(cfg)
+  G, P = batch.kernel_shape(args.lanes)
+  value = world * C * K * F / elapsed
+  launch_s = kernel_ms * 1e-3 / launches
+  flop = flops_column_step(nz) * C * F
+  alg_bytes = 24.0 * nz * C * F  # read b, read wA, write b per model step
+  tf = flop / launch_s / 1e12
+  prof = load_json(os.path.join(ROOT, "profiles", "k1_counters.json"))
+  key = "column_steps_F%d_C%d_nz%d" % (F, C, nz)
+  out = {
+      "metric": "column-timesteps/sec (ensemble) at nz=%d" % nz,
+      "value": value, "unit": "column-timesteps/s", "n_gpus": world, "steps": K,
+      "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
+      "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+      "config": {
+          "workload": WORKLOAD[2] % (C, nz), "columns_per_gpu": C, "nz": nz,
+          "model_steps_per_step": F,
+          "step": "one launch = %d Column.timestep calls of every column" % F,
+          "lanes_per_column": G, "levels_per_lane": P,
+          "parallelism": "ensemble sharded over %d GPU(s), RCCL all-gather of the final "
+                         "state" % world},
+      "roofline": {
+          "bound": "fp64-valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+          "frac": tf / FP64_PEAK_TFLOPS,
+          "kernel": "k_column_steps<%d,%d,true,true>" % (G, P),
+          "kernel_ms_per_launch": launch_s * 1e3, "launches": launches,
+          "flop_model": "14*(nz-2) = %d flop per column-step (SURVEY 8d), x %d columns x %d "
+                        "fused steps per launch; the peak counts an FMA as 2 flop, this "
+                        "arithmetic (the reference's, unfused, 3 divisions per level) cannot "
+                        "use FMAs for its adds/multiplies" % (flops_column_step(nz), C, F),
+          "issue_frac": (prof.get(key) or {}).get("issue_frac"),
+          "issue_frac_source": "VALU-issue cycles / wave cycles (SQ_ACTIVE_INST_VALU x 4 / "
+                               "SQ_WAVE_CYCLES), replayed from profiles/k1_counters.json "
+                               "(separate rocprofv3 --pmc pass, not measured in this run)",
+          "traffic": (prof.get(key) or {}).get("hbm_bytes_per_launch"),
+          "traffic_source": "FETCH_SIZE+WRITE_SIZE per launch, gfx950-corrected, replayed "
+                            "from profiles/k1_counters.json (not measured in this run)",
+          "algorithmic_bytes_per_launch": alg_bytes,
+          "algorithmic_hbm_GBps": alg_bytes / launch_s / 1e9,
+          "why_not_hbm": "with %d steps fused per launch the state stays in registers: HBM "
+                         "sees the compulsory 48*nz B per column per LAUNCH, so the "
+                         "algorithmic 24*nz B per column-step is not traffic and HBM is not "
+                         "the roof; see roofline_hbm_regime for the regime where it is" % F},
+      "nonfinite_columns": nonfinite,
+      "checksum": float(np.sum(b_final)),
+  }
+  if not args.no_single_step:
+    # one step per launch (b, wA and the static coefficients cross HBM/L2 every step): the
+    # regime of BASELINE config 1 and of user loops that refresh Psi every step
+    ms1 = time_calls(lambda: batch.steps(wA, dt, 1, lanes_per_col=args.lanes), 2000, stream,
+                     Event, warm=200)
+    out["single_step_launches"] = {
+        "ms_per_step": ms1, "column_timesteps_per_s": C / (ms1 * 1e-3),
+        "hbm_GBps_if_streamed": 48.0 * nz * C / (ms1 * 1e-3) / 1e9,
+        "note": "launch-latency-bound at %d columns" % C}
+  if not args.no_single_step and world == 1 and C == 1024 and nz == 100:
+    # the SAME kernel where HBM does bind: one step per launch on an ensemble far beyond the
+    # caches (262144 columns: 1.26 GB cross HBM per launch)
+    Cb = 262144
+    cb = configs.config2(N=Cb, nz=nz)
+    big = pymoc_amd.ColumnBatch(cb["z"], cb["kappa"], cb["Area"], cb["b0"], bs=cb["bs"],
+                                bbot=cb["bbot"], N2min=cb["N2min"], do_conv=cb["do_conv"],
+                                stream=stream)
+    wAb = DeviceArray.from_host(cb["wA"], stream=stream)
+    msb = time_calls(lambda: big.steps(wAb, dt, 1, lanes_per_col=args.lanes), 20, stream,
+                     Event, warm=3)
+    real = 48.0 * nz * Cb  # b, wA, kappa, Area, dAkappa in; b out (coefficients streamed)
+    gbps = real / (msb * 1e-3) / 1e9
+    out["roofline_hbm_regime"] = {
+        "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": gbps / HBM_PEAK_GBPS,
+        "workload": "the same kernel, ONE step per launch on %d columns x nz=%d" % (Cb, nz),
+        "bytes_model": "48*nz B per column-step: b, wA and the three static coefficient "
+                       "arrays in, b out (SURVEY 8d: a build that streams coefficients "
+                       "adds 24*nz)",
+        "kernel": "k_column_steps<%d,%d,false,false>" % (G, P), "kernel_ms_per_launch": msb,
+        "column_timesteps_per_s": Cb / (msb * 1e-3)}
+    del big, wAb
+  return out
+
+
+# ---------------------------------------------------------------------- configs 3, 4, 5
+def make_ensemble(config, env, members, comm=None, n_total=None):
+  pymoc_amd, configs = env["pymoc_amd"], env["configs"]
+  rank, world, stream = env["rank"], env["world"], env["stream"]
+  n_total = n_total or members
+  lo = rank * members if comm is not None else 0
+  sl = (lo, lo + members)
+  kw = dict(stream=stream)
+  if comm is not None:
+    kw.update(comm=comm, n_total=n_total)
+  if config == 3:
+    cfg = configs.config3(N=n_total, members=sl)
+    ens = pymoc_amd.TwoColEnsemble(cfg, diag_iters=240, **kw)
+  elif config == 4:
+    cfg = dict(configs.config4(N=n_total, members=sl), bvp_refine=8)
+    ens = pymoc_amd.TwoColEnsemble(cfg, **kw)
+  else:
+    cfg = configs.config5(N=n_total, members=sl)
+    cfg["rest_mask"] = np.repeat(cfg["rest_mask"][None], members, axis=0)
+    ens = pymoc_amd.JN2018Ensemble(cfg, **kw)
+  return cfg, ens
+
+
+def kernel_breakdown(config, cfg, ens, env, reps=20):
+  """Event-timed cost of each kernel of the coupled loop on the ensemble's current state,
+  and the roofline figure of the dominant one."""
+  Event, stream = env["Event"], env["stream"]
+  from pymoc_amd import _lib
+  n, nz, M = ens.n, ens.nz, ens.M
+  tw_ops = _lib.PM_TW_SOLVE | _lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ
+  parts = {}
+  if config in (3, 4):
+    off = ens._off
+    parts["k_thermwind"] = (time_calls(
+        lambda: ens.tw.update(ens.cols.b.ptr, ens.cols.b.ptr + off, ops=tw_ops,
+                              store_psib=False, Psi_SO=ens._psi_so(), wA1=ens.wA.ptr,
+                              wA2=ens.wA.ptr + off), reps, stream, Event), 1)
+    if ens.so is not None:
+      parts["k_psi_so"] = (time_calls(lambda: ens.so.update(ens.cols.b.ptr, ens.bs_SO), reps,
+                                      stream, Event), 1)
+    parts["k_column_steps"] = (time_calls(
+        lambda: ens.cols.steps(ens.wA, ens.dt, M, lanes_per_col=ens.lanes), reps, stream,
+        Event), 1)
+  else:
+    off = ens._off
+    parts["k_thermwind"] = (time_calls(
+        lambda: ens.tw.update(ens.cols.b.ptr, ens.cols.b.ptr + off, ops=tw_ops,
+                              store_psib=False, Psi_SO=ens.so.Psi, wA1=ens.wA.ptr,
+                              wA2=ens.wA.ptr + off), reps, stream, Event), 1)
+    parts["k_psi_so"] = (time_calls(lambda: ens.so.update(ens.cols.b.ptr, ens.ml.bs), reps,
+                                    stream, Event), 1)
+    parts["k_jn2018_steps"] = (time_calls(lambda: ens._fused_steps(M), reps, stream, Event), 1)
+  total = sum(ms * cnt for ms, cnt in parts.values())
+  shares = {k: {"ms_per_moc_interval": ms * cnt, "share": ms * cnt / total}
+            for k, (ms, cnt) in parts.items()}
+  dom = max(parts, key=lambda k: parts[k][0] * parts[k][1])
+  ms = parts[dom][0]
+  ny = getattr(ens, "ny", 0)
+  if dom == "k_thermwind":
+    flop = n * flops_thermwind_update(nz, ens.nb)
+    alg = n * 64.0 * nz
+    model = ("12 nz + 6 nb (nz-1) + 20 nz = %d flop per member and update (SURVEY 8d: solve, "
+             "Psib, Psibz), x %d members" % (flops_thermwind_update(nz, ens.nb), n))
+  elif dom == "k_column_steps":
+    flop = 2 * n * M * flops_column_step(nz)
+    alg = 2 * n * M * 24.0 * nz
+    model = "14*(nz-2) flop per column-step x %d columns x %d fused steps" % (2 * n, M)
+  elif dom == "k_jn2018_steps":
+    flop = n * M * (2 * flops_column_step(nz) + flops_so_ml_step(ny))
+    alg = n * M * (2 * 24.0 * nz + 8.0 * (2 * nz + 2 * ny))
+    model = ("per coupled step 2 x 14 (nz-2) (columns) + 30 ny (mixed layer) = %d flop, x %d "
+             "members x %d fused steps" % (2 * flops_column_step(nz) + flops_so_ml_step(ny), n, M))
+  else:
+    flop, alg, model = float("nan"), float("nan"), "n/a"
+  tf = flop / (ms * 1e-3) / 1e12
+  roof = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+          "frac": tf / FP64_PEAK_TFLOPS, "kernel": dom, "kernel_ms_per_launch": ms,
+          "flop_model": model, "traffic": None,
+          "algorithmic_hbm_GBps": alg / (ms * 1e-3) / 1e9}
+  return shares, roof
+
+
+def bench_coupled(config, args, env, members, nsteps=None, warm_blocks=None, sharded=False,
+                  breakdown=True):
+  """Time a coupled config.  nsteps=None: K MOC intervals (headline mode)."""
+  pymoc_amd = env["pymoc_amd"]
+  stream, comm, rank, world = env["stream"], env["comm"], env["rank"], env["world"]
+  use_comm = comm if sharded else None
+  cfg, ens = make_ensemble(config, env, members, use_comm, world * members if sharded else None)
+  M = ens.M
+  steps = nsteps if nsteps is not None else args.steps * M
+  warm = (warm_blocks if warm_blocks is not None else args.warmup) * M
+  ens.run(warm)
+  if use_comm is not None:
+    ens.gather_diagnostics()  # RCCL channel set-up of this collective: not timed
+    comm.max_host(0.0)
+  stream.sync()
+  comm.barrier(stream)
+  pymoc_amd.synchronize()
+  g0 = ens.diag.ngathers if ens.diag is not None else 0
+  t0 = time.perf_counter()
+  ens.run(steps)
+  if use_comm is not None:
+    ens.gather_diagnostics()  # the final output gather
+  stream.sync()
+  comm.barrier(stream)
+  pymoc_amd.synchronize()
+  el = comm.max_host(time.perf_counter() - t0)
+  bad = ens.nonfinite_members()
+  ncol = SIZES[config]["ncol"]
+  tot = world * members if sharded else members
+  res = {"members_per_gpu": members, "nz": int(ens.nz), "model_steps": steps,
+         "MOC_up_iters": M, "seconds": el, "coupled_steps_per_s": tot * steps / el,
+         "column_timesteps_per_s": ncol * tot * steps / el,
+         "nonfinite_members": int(bad.size),
+         "nonfinite_member_ids": [int(cfg["members"][i]) for i in bad[:16]]}
+  if use_comm is not None:
+    res["gathers_in_timed_region"] = ens.diag.ngathers - g0
+    res["gather_bytes_per_rank"] = ens.diag.bytes_per_rank
+  if breakdown and rank == 0:
+    shares, roof = kernel_breakdown(config, cfg, ens, env)
+    res["kernels"] = shares
+    res["roofline"] = roof
+  return res, ens
+
+
+def headline_coupled(config, args, env):
+  members = args.members or SIZES[config]["members"]
+  res, ens = bench_coupled(config, args, env, members, sharded=True)
+  if env["rank"] != 0:
+    return None
+  world, K, W, M = env["world"], args.steps, args.warmup, ens.M
+  out = {
+      "metric": "column-timesteps/sec (ensemble) at nz=%d" % ens.nz,
+      "value": res["column_timesteps_per_s"], "unit": "column-timesteps/s", "n_gpus": world,
+      "steps": K, "warmup": W, "ms_per_step": res["seconds"] * 1e3 / K,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+      "data": "synthetic",
+      "config": {"workload": WORKLOAD[config] % (members, ens.nz),
+                 "members_per_gpu": members, "nz": int(ens.nz), "model_steps_per_step": M,
+                 "step": "one MOC interval = %d model steps of every column + one refresh of "
+                         "the overturning diagnostics" % M,
+                 "parallelism": "ensemble sharded over %d GPU(s); RCCL all-gather of "
+                                "{b_basin,b_north,Psi_AMOC,Psi_SO} every %s model steps and at "
+                                "the end" % (world, ens.diag_iters)},
+      "roofline": res.pop("roofline"),
+  }
+  out.update(res)
+  return out
+
+
+# ------------------------------------------------------------------------------ main
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=20, help="timed bench steps")
+  ap.add_argument("--warmup", type=int, default=5, help="untimed bench steps")
+  ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
+  ap.add_argument("--steps-per-launch", type=int, default=1000,
+                  help="config 2: model time steps fused in one launch (= one bench step)")
+  ap.add_argument("--members", "--columns", type=int, default=0,
+                  help="members (columns) per GPU; 0 = the SURVEY 8d size of the config")
+  ap.add_argument("--nz", type=int, default=100, help="config 2 only")
+  ap.add_argument("--lanes", type=int, default=0, help="config 2: lanes per column (0 = auto)")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-single-step", action="store_true")
+  ap.add_argument("--no-coupled", action="store_true",
+                  help="config 2 at N=1: skip the configs 3-5 entries")
+  ap.add_argument("--cpu-workers", type=int, default=0, help="cap of the all-core baseline")
+  ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget per baseline leg")
+  ap.add_argument("--force-rccl", action="store_true",
+                  help="use the RCCL communicator even with one rank (plumbing check)")
+  args = ap.parse_args()
+
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # plain `python bench.py --gpus N`: start the N ranks ourselves, before anything here
+    # touches the GPU (pymoc_amd/launch.py loaded by path: importing the package would
+    # dlopen the engine)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "pymoc_launch", os.path.join(ROOT, "pymoc_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    sys.exit(launch.spawn([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                          args.gpus))
+
+  rank = int(os.environ.get("RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world != args.gpus:
+    raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+  # CPU baselines first: nothing below this block has touched the GPU yet
+  cpu = {}
+  want_coupled = args.config == 2 and world == 1 and not args.no_coupled
+  if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    for c in ([args.config] + ([3, 4, 5] if want_coupled else [])):
+      cpu[c] = cpu_baseline(c, args.nz if c == 2 else 100, args.cpu_seconds, args.cpu_seconds,
+                            args.cpu_workers)
+
+  import pymoc_amd
+  from pymoc_amd import configs, sharding
+  from pymoc_amd.device import DeviceArray, Event, Stream
+  _, _, local_rank = sharding.world_info()
+  pymoc_amd._lib.require_device(local_rank)
+  stream = Stream()
+  comm = (sharding.RcclCommunicator(stream=stream) if (args.force_rccl and world == 1)
+          else sharding.make_communicator(stream=stream))
+  env = dict(pymoc_amd=pymoc_amd, configs=configs, DeviceArray=DeviceArray, Event=Event,
+             stream=stream, comm=comm, rank=rank, world=world)
+
+  if args.config == 2:
+    out = bench_config2(args, env)
+    if want_coupled and out is not None:
+      out["coupled"] = {}
+      for c in (3, 4, 5):
+        res, ens = bench_coupled(c, args, env, SIZES[c]["members"],
+                                 nsteps=SIZES[c]["nsteps"], warm_blocks=10)
+        res["workload"] = WORKLOAD[c] % (SIZES[c]["members"], ens.nz)
+        if c in cpu:
+          res["cpu_baseline"] = cpu[c]
+        out["coupled"]["config%d" % c] = res
+        del ens
+  else:
+    out = headline_coupled(args.config, args, env)
+  if out is not None:
+    if args.config in cpu:
+      out["cpu_baseline"] = cpu[args.config]
     print(json.dumps(out), flush=True)
   comm.barrier(stream)
   comm.close()

@@ -118,6 +118,12 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
                     const double *b_in, double dt, int32_t nsteps, int32_t ops,
                     int32_t lanes_per_col, pm_stream_t stream);
 
+/* The work decomposition pm_column_steps would use for a batch of this shape: lanes
+ * cooperating on one column (`lanes_per_col` = 0 lets the library choose) and levels held
+ * per lane; reporting only (bench.py names the kernel instantiation with it).            */
+int pm_column_kernel_shape(int32_t ncols, int32_t nz, int32_t lanes_per_col,
+                           int32_t *lanes, int32_t *levels_per_lane);
+
 /* ------------------------------------------------------------------ Psi_Thermwind
  * Replaces pymoc.modules.Psi_Thermwind for n independent members on one grid z[nz]:
  *   Psi_Thermwind.solve  src/pymoc/modules/psi_thermwind.py:125-135  (PM_TW_SOLVE)

@@ -59,8 +59,8 @@ class ColumnBatch(object):
       raise ValueError("b must be (ncols, nz)")
     self.stream = stream
     self.z_host = z
-    self.z = DeviceArray.from_host(z)
-    self.b = DeviceArray.from_host(b)
+    self.z = DeviceArray.from_host(z, stream=stream)
+    self.b = DeviceArray.from_host(b, stream=stream)
     self.nsel = 2 if kappa_alt is not None else 1
     self.kappa = DeviceArray((self.nsel, ncols, nz))
     self.dAk = DeviceArray((self.nsel, ncols, nz))
@@ -71,8 +71,8 @@ class ColumnBatch(object):
     self.bzbot = DeviceArray((ncols,))
     self.N2min = DeviceArray((ncols,))
     self.flags = DeviceArray((ncols,), np.int32)
-    self.ksel = DeviceArray.zeros((ncols,), np.int32)
-    self.nonfinite = DeviceArray.zeros((ncols,), np.int32) if report_nonfinite else None
+    self.ksel = DeviceArray.zeros((ncols,), np.int32, stream=stream)
+    self.nonfinite = DeviceArray.zeros((ncols,), np.int32, stream=stream) if report_nonfinite else None
     self._flags_host = np.zeros(ncols, dtype=np.int32)
     self.set_params(bs=bs, bbot=bbot, bzbot=bzbot, N2min=N2min, do_conv=do_conv)
     self._wA = None
@@ -152,6 +152,13 @@ class ColumnBatch(object):
     d.flags, d.ksel = self.flags.ptr, self.ksel.ptr
     d.nonfinite = self.nonfinite.ptr if self.nonfinite else None
     return d
+
+  def kernel_shape(self, lanes_per_col=0):
+    """(lanes per column, levels per lane) the library uses for this batch."""
+    g, p = C.c_int32(0), C.c_int32(0)
+    check(lib.pm_column_kernel_shape(self.ncols, self.nz, int(lanes_per_col), C.byref(g),
+                                     C.byref(p)))
+    return g.value, p.value
 
   def steps(self, wA, dt, nsteps=1, ops=_lib.PM_OP_TIMESTEP, vdx_in=None, b_in=None,
             lanes_per_col=0):

@@ -25,6 +25,26 @@ def _slice(members, N):
   return slice(int(lo), int(hi))
 
 
+# keys of each ensemble config that carry one entry per member (first axis = member)
+PER_MEMBER = {
+    2: ("kappa", "Area", "wA", "b0", "bs", "bbot", "N2min", "do_conv"),
+    3: ("kappa", "A_basin", "A_north", "bs", "bs_north", "bbot", "b_basin0", "b_north0"),
+    4: ("kappa", "tau", "KGM", "A_basin", "A_north", "bs", "bs_north", "bbot", "bs_SO",
+        "b_basin0", "b_north0"),
+    5: ("bs", "bs_north", "KGM", "tau", "surflux", "b_rest", "bs_SO_init", "bs_SO0",
+        "b_basin0", "b_north0"),
+}
+
+
+def member(cfg, j, config):
+  """Member j (local index) of an ensemble config as the single-member dict the
+  member-by-member drivers take (`twocol_member` / `jn2018_member` layout)."""
+  m = dict(cfg)
+  for k in PER_MEMBER[config]:
+    m[k] = cfg[k][j]
+  return m
+
+
 def config1(nz=100):
   """Single Column + Psi_Thermwind updated every step (examples/example_timestepping.py
   :18-80 physics at nz=100, 1000 steps).  The script's dt=60 d is for its nz=70 grid;

@@ -253,6 +253,32 @@ int pm_graph_destroy(pm_graph_t graph) {
 }
 
 // -------------------------------------------------------------------- Column
+static int column_shape(int ncols, int nz, int lanes_per_col, int *G_out, int *P_out) {
+  int G = lanes_per_col ? lanes_per_col : auto_lanes_per_col(ncols, nz);
+  PM_REQUIRE(G == 16 || G == 32 || G == 64, "lanes_per_col must be 0, 16, 32 or 64");
+  int P = pick_levels_per_lane(G, (nz + G - 1) / G);
+  while (P < 0 && G < 64) {
+    G *= 2;
+    P = pick_levels_per_lane(G, (nz + G - 1) / G);
+  }
+  PM_REQUIRE(P > 0, "nz=%d does not fit %d lanes", nz, G);
+  *G_out = G;
+  *P_out = P;
+  return PM_OK;
+}
+
+int pm_column_kernel_shape(int32_t ncols, int32_t nz, int32_t lanes_per_col, int32_t *lanes,
+                           int32_t *levels_per_lane) {
+  PM_REQUIRE(lanes && levels_per_lane, "NULL output");
+  PM_REQUIRE(nz >= 2 && nz <= 1024, "nz must be in [2,1024]");
+  int G = 0, P = 0;
+  const int rc = column_shape(ncols, nz, lanes_per_col, &G, &P);
+  if (rc != PM_OK) return rc;
+  *lanes = G;
+  *levels_per_lane = P;
+  return PM_OK;
+}
+
 int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_in,
                     const double *b_in, double dt, int32_t nsteps, int32_t ops,
                     int32_t lanes_per_col, pm_stream_t stream) {
@@ -269,14 +295,9 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
   PM_REQUIRE(!(ops & PM_OP_VERTADVDIFF) || wA, "wA is NULL");
   PM_REQUIRE(!vdx_in || b_in, "b_in is needed if vdx_in is provided");
   if (c.ncols == 0 || nsteps == 0 || ops == 0) return PM_OK;
-  int G = lanes_per_col ? lanes_per_col : auto_lanes_per_col(c.ncols, c.nz);
-  PM_REQUIRE(G == 16 || G == 32 || G == 64, "lanes_per_col must be 0, 16, 32 or 64");
-  int P = pick_levels_per_lane(G, (c.nz + G - 1) / G);
-  while (P < 0 && G < 64) {
-    G *= 2;
-    P = pick_levels_per_lane(G, (c.nz + G - 1) / G);
-  }
-  PM_REQUIRE(P > 0, "nz=%d does not fit %d lanes", c.nz, G);
+  int G = 0, P = 0;
+  const int src = column_shape(c.ncols, c.nz, lanes_per_col, &G, &P);
+  if (src != PM_OK) return src;
   hipStream_t st = resolve_stream(stream);
   switch (G) {
     case 16: return column_steps_g16(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);

@@ -107,7 +107,7 @@ __device__ __forceinline__ void psib_cell_terms(double t, double d, double yk, d
 // top, d = top - bot, y = RN(1/d) or NaN, u.
 // Range test of a pass: every class of the pass lies in [gmin, gmax] (wave-uniform scalars);
 // gbot[g] / gtop[g] hold min(bot) / max(top) of the 8 cells k = 8g .. 8g+7 (-inf / +inf when a
-// cell of the group is degenerate or inverted).  If gmax <= gbot[g] every mask of the group
+// cell of the group is degenerate or inverted, or carries a non-finite u_k).  If gmax <= gbot[g] every mask of the group
 // is exactly 1 for every class of the pass (fl(top-g) >= fl(top-bot) > 0, quotient >= 1), so
 // the terms are the u_k themselves; if gmin >= gtop[g] every mask is exactly 0 and the group
 // only adds zeros.  Both shortcuts leave every partial sum of NumPy's pairwise order
@@ -390,7 +390,11 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
       s_c[k] = u;
       s_y[k] = regular ? 1.0 / d : __builtin_nan("");
       // staged in the psib row (free until the first pass writes it) for the group ranges
-      if (nb >= nz) s_psib[k] = (regular && d > 0.) ? bot : -__builtin_inf();
+      // a non-finite u_k (user-assigned Psi) must reach the products: 0 * NaN and 0 * inf are
+      // NaN in the reference's `mask * udydz` (psi_thermwind.py:183-184), so such a cell bars
+      // its group from both shortcuts like a degenerate cell does
+      const bool ufin = __builtin_fabs(u) <= 1.7976931348623157e308;
+      if (nb >= nz) s_psib[k] = (regular && d > 0. && ufin) ? bot : -__builtin_inf();
     }
   }
   __builtin_amdgcn_wave_barrier();

@@ -121,6 +121,9 @@ class DeviceArray(object):
   def zeros(cls, shape, dtype=np.float64, stream=None):
     d = cls(shape, dtype)
     check(lib.pm_memset(d.ptr, 0, d.nbytes, _sh(stream)))
+    # complete before returning: a fill enqueued on one stream must not be overtaken by a
+    # kernel that a caller launches on another (streams here are non-blocking)
+    check(lib.pm_stream_sync(_sh(stream)))
     return d
 
   def upload(self, arr, stream=None):

@@ -43,13 +43,13 @@ class JN2018Diagnostics(object):
       return
     e, m = self.ens, self.members
     b = e.cols.get_b()
-    self.AMOC[:, :, k] = e.tw.Psi.download()[m]
-    self.AMOC_b[:, :, k] = e.tw.psib.download()[m]
-    self.bgrid[:, :, k] = e.tw.bgrid.download()[m]
+    self.AMOC[:, :, k] = e.tw.Psi.download(stream=e.stream)[m]
+    self.AMOC_b[:, :, k] = e.tw.psib.download(stream=e.stream)[m]
+    self.bgrid[:, :, k] = e.tw.bgrid.download(stream=e.stream)[m]
     self.b_basin[:, :, k] = b[:e.n][m]
     self.b_north[:, :, k] = b[e.n:][m]
-    self.bs_SO[:, :, k] = e.ml.bs.download()[m]
-    self.Psi_SO[:, :, k] = e.so.Psi.download()[m]
+    self.bs_SO[:, :, k] = e.ml.bs.download(stream=e.stream)[m]
+    self.Psi_SO[:, :, k] = e.so.Psi.download(stream=e.stream)[m]
 
   def save_member(self, path, j, tau, kapGM):
     """The reference's diagfile for recorded member j (positional arr_0..arr_10)."""
@@ -68,7 +68,7 @@ def save_pickup(ens, path, member=None):
   """np.savez(path, basin.b, north.b, channel.bs): one member in the reference's layout, or
   the whole ensemble with a leading member axis."""
   b = ens.cols.get_b()
-  bs = ens.ml.bs.download()
+  bs = ens.ml.bs.download(stream=ens.stream)
   if member is None:
     np.savez(path, b[:ens.n], b[ens.n:], bs)
   else:

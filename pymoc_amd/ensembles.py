@@ -18,6 +18,7 @@ from .columns import ColumnBatch
 from .device import DeviceArray, _sh
 from .equilibrium import ColumnEquiBatch
 from .psi_so import PsiSOBatch
+from .sharding import DiagnosticGather
 from .so_ml import SOMLBatch
 from .thermwind import ThermwindBatch
 
@@ -50,13 +51,13 @@ class ColumnThermwindEnsemble(object):
     b0 = np.atleast_2d(cfg['b0'])
     n = b0.shape[0] if n is None else n
     self.n, self.nz, self.dt = n, nz, float(cfg['dt'])
-    self.lanes = lanes_per_col
+    self.lanes, self.stream = lanes_per_col, stream
     self.cols = ColumnBatch(z, _rows(cfg['kappa'], n, nz), _rows(cfg['Area'], n, nz),
                             _rows(b0, n, nz), bs=_vec(cfg['bs'], n), bbot=_vec(cfg['bbot'], n),
                             stream=stream)
     self.tw = ThermwindBatch(z, n, f=cfg['f'], nb=1, stream=stream, z_dev=self.cols.z)
-    self.b2 = DeviceArray.zeros((n, nz))
-    self.wA = DeviceArray.zeros((n, nz))
+    self.b2 = DeviceArray.zeros((n, nz), stream=stream)
+    self.wA = DeviceArray.zeros((n, nz), stream=stream)
     self._solve()
 
   def _solve(self):
@@ -69,7 +70,7 @@ class ColumnThermwindEnsemble(object):
       self._solve()
 
   def state(self):
-    return dict(b=self.cols.get_b(), Psi=self.tw.Psi.download())
+    return dict(b=self.cols.get_b(), Psi=self.tw.Psi.download(stream=self.stream))
 
 
 class EquiIterationEnsemble(object):
@@ -87,9 +88,9 @@ class EquiIterationEnsemble(object):
     self.keep, self.relax = float(cfg['keep']), float(cfg['relax'])
     self.stream = stream
     self.tw = ThermwindBatch(z, n, f=cfg['f'], nb=1, stream=stream)
-    self.b1 = DeviceArray.from_host(_rows(b0, n, nz))
-    self.b2 = DeviceArray.zeros((n, nz))
-    self.wA = DeviceArray.zeros((n, nz))
+    self.b1 = DeviceArray.from_host(_rows(b0, n, nz), stream=stream)
+    self.b2 = DeviceArray.zeros((n, nz), stream=stream)
+    self.wA = DeviceArray.zeros((n, nz), stream=stream)
     self.eq = ColumnEquiBatch.from_profiles(
         z, _rows(cfg['kappa'], n, nz), _rows(cfg['A_basin'], n, nz), _vec(cfg['bs'], n),
         _vec(cfg['bbot'], n), n=n, stream=stream, z_dev=self.tw.z)
@@ -107,15 +108,20 @@ class EquiIterationEnsemble(object):
       self._solve()
 
   def state(self):
-    return dict(b=self.eq.get_b(), bz=self.eq.get_bz(), b1=self.b1.download(),
-                Psi=self.tw.Psi.download())
+    return dict(b=self.eq.get_b(), bz=self.eq.get_bz(), b1=self.b1.download(stream=self.stream),
+                Psi=self.tw.Psi.download(stream=self.stream))
 
 
 class TwoColEnsemble(object):
   """Basin + northern sinking column per member, coupled by the thermal-wind overturning
   mapped to isopycnal space every MOC_up_iters steps."""
 
-  def __init__(self, cfg, stream=None, lanes_per_col=0):
+  def __init__(self, cfg, stream=None, lanes_per_col=0, comm=None, n_total=None,
+               diag_iters=None, keep_history=False):
+    """`comm` (a pymoc_amd.sharding communicator) makes this rank's members one shard of an
+    `n_total`-member ensemble: stepping is unchanged (members never interact) and
+    {b_basin, b_north, Psi, Psi_SO} are all-gathered on device buffers every `diag_iters`
+    steps (default cfg['Diag_iters']) and by `gather_diagnostics()` at the end of a run."""
     z = cfg['z']
     nz = z.size
     n = np.atleast_2d(cfg['b_basin0']).shape[0]
@@ -123,6 +129,12 @@ class TwoColEnsemble(object):
     self.dt, self.M, self.nb = float(cfg['dt']), int(cfg['MOC_up_iters']), int(cfg['nb'])
     self.lanes = lanes_per_col
     self.stream = stream
+    self.diag_iters = cfg.get('Diag_iters') if diag_iters is None else diag_iters
+    self.diag = None
+    if comm is not None or keep_history:
+      self.diag = DiagnosticGather(comm, n, n if n_total is None else n_total,
+                                   [(k, nz) for k in ('b_basin', 'b_north', 'Psi', 'Psi_SO')],
+                                   stream=stream, keep_history=keep_history)
     kap = _rows(cfg['kappa'], n, nz)
     # rows [0, n): basin columns, rows [n, 2n): northern columns
     self.cols = ColumnBatch(
@@ -133,7 +145,7 @@ class TwoColEnsemble(object):
         bbot=np.concatenate([_vec(cfg['bbot'], n), _vec(cfg['bbot'], n)]),
         do_conv=np.concatenate([np.zeros(n, bool), np.ones(n, bool)]), stream=stream)
     self.tw = ThermwindBatch(z, n, f=cfg['f'], nb=self.nb, stream=stream, z_dev=self.cols.z)
-    self.wA = DeviceArray.zeros((2 * n, nz))
+    self.wA = DeviceArray.zeros((2 * n, nz), stream=stream)
     self._off = n * nz * 8
     self.ii = 0
     self.so = None
@@ -144,7 +156,9 @@ class TwoColEnsemble(object):
                            bvp_refine=cfg.get('bvp_refine', 0), stream=stream,
                            z_dev=self.cols.z)
       self.bs_SO = DeviceArray.from_host(_rows(cfg['bs_SO'], n, ny) if np.ndim(cfg['bs_SO']) == 1
-                                         else cfg['bs_SO'])
+                                         else cfg['bs_SO'], stream=stream)
+    self._zero_so = (DeviceArray.zeros((n, nz), stream=stream)
+                     if self.so is None and self.diag is not None else None)
     self._update()  # AMOC.solve(); AMOC.Psibz() [; SO.solve()] on the initial profiles
 
   # device views
@@ -180,14 +194,23 @@ class TwoColEnsemble(object):
       remaining -= n
       if (self.ii - 1) % self.M == 0:
         self._update()
+        if self.diag is not None and self.diag.due(self.ii - 1, self.diag_iters):
+          self.gather_diagnostics(self.ii - 1)
+
+  def gather_diagnostics(self, step=None):
+    """All-gather {b_basin, b_north, Psi_AMOC, Psi_SO} of every rank's members (device
+    buffers, one collective); `self.diag.last()` returns the assembled host arrays."""
+    self.diag.gather(dict(b_basin=self._b_basin, b_north=self._b_north, Psi=self.tw.Psi,
+                          Psi_SO=self.so.Psi if self.so is not None else self._zero_so),
+                     step=self.ii if step is None else step)
 
   def state(self):
     b = self.cols.get_b()
-    out = dict(b_basin=b[:self.n], b_north=b[self.n:], Psi=self.tw.Psi.download(),
-               Psi_iso_b=self.tw.psibz1.download(), Psi_iso_n=self.tw.psibz2.download())
+    out = dict(b_basin=b[:self.n], b_north=b[self.n:], Psi=self.tw.Psi.download(stream=self.stream),
+               Psi_iso_b=self.tw.psibz1.download(stream=self.stream), Psi_iso_n=self.tw.psibz2.download(stream=self.stream))
     if self.so is not None:
-      out.update(Psi_SO=self.so.Psi.download(), Psi_Ek=self.so.Psi_Ek.download(),
-                 Psi_GM=self.so.Psi_GM.download())
+      out.update(Psi_SO=self.so.Psi.download(stream=self.stream), Psi_Ek=self.so.Psi_Ek.download(stream=self.stream),
+                 Psi_GM=self.so.Psi_GM.download(stream=self.stream))
     return out
 
   def nonfinite_members(self):
@@ -204,7 +227,11 @@ class JN2018Ensemble(object):
   MOC_up_iters steps (before the step) the three diagnostics are refreshed.  With
   `use_graph` a whole MOC block is captured once into a hipGraph and replayed."""
 
-  def __init__(self, cfg, stream=None, lanes_per_col=0, use_graph=False, fused=None):
+  def __init__(self, cfg, stream=None, lanes_per_col=0, use_graph=False, fused=None,
+               comm=None, n_total=None, diag_iters=None, keep_history=False):
+    """`comm`, `n_total`, `diag_iters`: as for TwoColEnsemble; the gather happens where the
+    script samples its diagnostics (`if ii % Diag_iters == 0`, right after the MOC update,
+    run_JansenNadeau_2018.py:218-226; default Diag_iters = 10 MOC_up_iters, :99)."""
     import ctypes as C
     from ._lib import pm_jn2018_bc
     z, y = cfg['z'], cfg['y']
@@ -233,7 +260,7 @@ class JN2018Ensemble(object):
                         surflux=cfg['surflux'], rest_mask=cfg['rest_mask'],
                         b_rest=cfg['b_rest'], Ks=cfg['Ks'], h=cfg['h'], L=cfg['L'],
                         v_pist=cfg['v_pist'], stream=stream)
-    self.wA = DeviceArray.zeros((2 * n, nz))
+    self.wA = DeviceArray.zeros((2 * n, nz), stream=stream)
     self._off = n * nz * 8
     self._bc = pm_jn2018_bc()
     d = self._bc
@@ -248,6 +275,24 @@ class JN2018Ensemble(object):
     # fused: one launch per MOC block for the whole [BC switch, 2 columns, mixed layer] loop
     self._fused = (nz <= 256) if fused is None else bool(fused)
     self.recorder = None  # optional diagnostics.JN2018Diagnostics
+    self.diag_iters = (cfg.get('Diag_iters', 10 * self.M) if diag_iters is None
+                       else diag_iters)
+    self.diag = None
+    if comm is not None or keep_history:
+      self.diag = DiagnosticGather(comm, n, n if n_total is None else n_total,
+                                   [(k, nz) for k in ('b_basin', 'b_north', 'Psi', 'Psi_SO')],
+                                   stream=stream, keep_history=keep_history)
+
+  def gather_diagnostics(self, step=None):
+    self.diag.gather(dict(b_basin=self.cols.b.ptr, b_north=self.cols.b.ptr + self._off,
+                          Psi=self.tw.Psi, Psi_SO=self.so.Psi),
+                     step=self.ii if step is None else step)
+
+  def _after_update(self):
+    if self.recorder is not None:
+      self.recorder.maybe_record(self.ii)
+    if self.diag is not None and self.diag.due(self.ii, self.diag_iters):
+      self.gather_diagnostics(self.ii)
 
   def _update(self):
     b_basin, b_north = self.cols.b.ptr, self.cols.b.ptr + self._off
@@ -293,15 +338,14 @@ class JN2018Ensemble(object):
     while remaining > 0 and self._fused:
       if self.ii % self.M == 0:
         self._update()
-        if self.recorder is not None:
-          self.recorder.maybe_record(self.ii)
+        self._after_update()
       n = min(self.M - self.ii % self.M, remaining)
       self._fused_steps(n)
       self.ii += n
       remaining -= n
     while remaining > 0:
-      if (self._use_graph and self.recorder is None and self.ii % self.M == 0 and
-          remaining >= self.M):
+      if (self._use_graph and self.recorder is None and self.diag is None and
+          self.ii % self.M == 0 and remaining >= self.M):
         if self._graph is None:
           with Graph.capture(self.stream) as cap:
             self._block()
@@ -312,18 +356,17 @@ class JN2018Ensemble(object):
         continue
       if self.ii % self.M == 0:
         self._update()
-        if self.recorder is not None:
-          self.recorder.maybe_record(self.ii)
+        self._after_update()
       self._step()
       self.ii += 1
       remaining -= 1
 
   def state(self):
     b = self.cols.get_b()
-    return dict(b_basin=b[:self.n], b_north=b[self.n:], bs_SO=self.ml.bs.download(),
-                Psi=self.tw.Psi.download(), Psi_SO=self.so.Psi.download(),
-                Psi_iso_b=self.tw.psibz1.download(), Psi_iso_n=self.tw.psibz2.download(),
-                Psi_s=self.ml.Psi_s.download())
+    return dict(b_basin=b[:self.n], b_north=b[self.n:], bs_SO=self.ml.bs.download(stream=self.stream),
+                Psi=self.tw.Psi.download(stream=self.stream), Psi_SO=self.so.Psi.download(stream=self.stream),
+                Psi_iso_b=self.tw.psibz1.download(stream=self.stream), Psi_iso_n=self.tw.psibz2.download(stream=self.stream),
+                Psi_s=self.ml.Psi_s.download(stream=self.stream))
 
   def nonfinite_members(self):
     nf = self.cols.get_nonfinite()
@@ -360,12 +403,12 @@ class TwoBasinEnsemble(object):
     self.so_atl = PsiSOBatch(z, y, n, L=cfg['L_Atl'], **so)
     self.so_pac = PsiSOBatch(z, y, n, L=cfg['L_Pac'], **so)
     self.bs_SO = DeviceArray.from_host(_rows(cfg['bs_SO'], n, ny) if np.ndim(cfg['bs_SO']) == 1
-                                       else cfg['bs_SO'])
-    self.wA = DeviceArray.zeros((3 * n, nz))
+                                       else cfg['bs_SO'], stream=stream)
+    self.wA = DeviceArray.zeros((3 * n, nz), stream=stream)
     self._off = n * nz * 8
     self.ii = 0
     # initial diagnostics (:58-79): AMOC against b2 = 0.01*b_Atl, the rest on the initial columns
-    b2 = DeviceArray.from_host(rows(cfg['b2_init']))
+    b2 = DeviceArray.from_host(rows(cfg['b2_init']), stream=stream)
     self._update(b_north=b2.ptr)
 
   def _update(self, b_north=None):
@@ -397,9 +440,9 @@ class TwoBasinEnsemble(object):
 
   def state(self):
     b, n = self.cols.get_b(), self.n
-    return dict(b_Atl=b[:n], b_north=b[n:2 * n], b_Pac=b[2 * n:], Psi_AMOC=self.amoc.Psi.download(),
-                Psi_ZOC=self.zoc.Psi.download(), Psi_SO_Atl=self.so_atl.Psi.download(),
-                Psi_SO_Pac=self.so_pac.Psi.download())
+    return dict(b_Atl=b[:n], b_north=b[n:2 * n], b_Pac=b[2 * n:], Psi_AMOC=self.amoc.Psi.download(stream=self.stream),
+                Psi_ZOC=self.zoc.Psi.download(stream=self.stream), Psi_SO_Atl=self.so_atl.Psi.download(stream=self.stream),
+                Psi_SO_Pac=self.so_pac.Psi.download(stream=self.stream))
 
   def nonfinite_members(self):
     nf, n = self.cols.get_nonfinite(), self.n

@@ -30,8 +30,8 @@ class PsiSOBatch(object):
     self.y_host = np.ascontiguousarray(y, dtype=np.float64)
     self.nz, self.ny, self.n = self.z_host.size, self.y_host.size, int(n)
     self.stream = stream
-    self.z = z_dev if z_dev is not None else DeviceArray.from_host(self.z_host)
-    self.y = DeviceArray.from_host(self.y_host)
+    self.z = z_dev if z_dev is not None else DeviceArray.from_host(self.z_host, stream=stream)
+    self.y = DeviceArray.from_host(self.y_host, stream=stream)
     self.KGM = DeviceArray((self.n,))
     self.tau = None
     self.flags = 0
@@ -40,15 +40,15 @@ class PsiSOBatch(object):
     self.opts = dict(f=f, rho=rho, L=L, c=c, bvp_with_Ek=bvp_with_Ek, Hsill=Hsill, HEk=HEk,
                      Htapertop=Htapertop, Htaperbot=Htaperbot, smax=smax)
     self.bvp_refine = int(bvp_refine)
-    self.Psi = DeviceArray.zeros((self.n, self.nz))
-    self.Psi_Ek = DeviceArray.zeros((self.n, self.nz))
-    self.Psi_GM = DeviceArray.zeros((self.n, self.nz))
-    self.status = DeviceArray.zeros((self.n,), np.int32)
+    self.Psi = DeviceArray.zeros((self.n, self.nz), stream=stream)
+    self.Psi_Ek = DeviceArray.zeros((self.n, self.nz), stream=stream)
+    self.Psi_GM = DeviceArray.zeros((self.n, self.nz), stream=stream)
+    self.status = DeviceArray.zeros((self.n,), np.int32, stream=stream)
     self.Ek_raw = self.GM_raw = self.ys = None
     if diagnostics:
-      self.Ek_raw = DeviceArray.zeros((self.n, self.nz))
-      self.GM_raw = DeviceArray.zeros((self.n, self.nz))
-      self.ys = DeviceArray.zeros((self.n, self.nz))
+      self.Ek_raw = DeviceArray.zeros((self.n, self.nz), stream=stream)
+      self.GM_raw = DeviceArray.zeros((self.n, self.nz), stream=stream)
+      self.ys = DeviceArray.zeros((self.n, self.nz), stream=stream)
 
   def set_tau(self, tau):
     """scalar or (n,): one wind stress per member; (n, ny): a profile on y per member."""

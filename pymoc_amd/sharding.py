@@ -53,12 +53,65 @@ class SingleCommunicator(object):
     pass
 
 
+def rendezvous_path(env=None, rendezvous_dir="/tmp"):
+  """File through which rank 0 hands the RCCL unique id to the other ranks of the node.
+
+  The key is built from launcher-provided values only -- MASTER_ADDR, MASTER_PORT and a run
+  id (torch.distributed.run's TORCHELASTIC_RUN_ID or pymoc_amd.launch's PYMOC_RUN_ID, plus
+  the elastic restart count) -- so that any spawner works, including one wrapper shell per
+  rank.  `PYMOC_RENDEZVOUS` overrides the whole path."""
+  env = os.environ if env is None else env
+  if env.get("PYMOC_RENDEZVOUS"):
+    return env["PYMOC_RENDEZVOUS"]
+  run_id = env.get("PYMOC_RUN_ID") or env.get("TORCHELASTIC_RUN_ID") or "none"
+  key = "pymoc_rccl_%s_%s_%s_%s" % (env.get("MASTER_ADDR", "127.0.0.1"),
+                                    env.get("MASTER_PORT", "0"), run_id,
+                                    env.get("TORCHELASTIC_RESTART_COUNT", "0"))
+  return os.path.join(rendezvous_dir, "".join(c if c.isalnum() or c in "._-" else "_"
+                                               for c in key))
+
+
+def publish_id(path, payload):
+  """Rank 0: replace whatever a crashed earlier run left at `path` with the new id."""
+  try:
+    os.remove(path)
+  except OSError:
+    pass
+  tmp = path + ".tmp%d" % os.getpid()
+  with open(tmp, "wb") as f:
+    f.write(payload)
+  os.replace(tmp, path)
+
+
+def wait_for_id(path, nbytes, started, timeout_s=300.0, stale_slack_s=30.0):
+  """Other ranks: wait for a complete id file that is not a leftover of an earlier run (a
+  file older than this process by more than `stale_slack_s` is stale: ranks of one launch
+  start within seconds of each other, and rank 0 replaces leftovers when it starts)."""
+  t0 = time.time()
+  while True:
+    try:
+      st = os.stat(path)
+      if st.st_size >= nbytes and st.st_mtime >= started - stale_slack_s:
+        with open(path, "rb") as f:
+          data = f.read(nbytes)
+        if len(data) == nbytes:
+          return data
+    except OSError:
+      pass
+    if time.time() - t0 > timeout_s:
+      raise TimeoutError("no RCCL unique id at %s after %.0f s" % (path, timeout_s))
+    time.sleep(0.02)
+
+
+_PROCESS_START = time.time()
+
+
 class RcclCommunicator(object):
   """RCCL through the C-ABI.  The 128-byte unique id travels from rank 0 to the other
-  ranks of the node through a file (single node: shared /tmp)."""
+  ranks of the node through a file (single node: shared /tmp), see `rendezvous_path`."""
 
   def __init__(self, rank=None, world=None, stream=None, rendezvous_dir="/tmp",
-               timeout_s=300.0):
+               timeout_s=300.0, path=None):
     from . import _lib
     from .device import DeviceArray
     self._lib = _lib
@@ -67,25 +120,13 @@ class RcclCommunicator(object):
     self.world = w if world is None else world
     self.stream = stream
     _lib.require_device()
-    key = "pymoc_rccl_%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"),
-                                   os.environ.get("TORCHELASTIC_RUN_ID", "none"),
-                                   os.getppid())
-    path = os.path.join(rendezvous_dir, key)
+    path = path or rendezvous_path(rendezvous_dir=rendezvous_dir)
     buf = C.create_string_buffer(128)
     if self.rank == 0:
       _lib.check(_lib.lib.pm_comm_unique_id(buf))
-      tmp = path + ".tmp%d" % os.getpid()
-      with open(tmp, "wb") as f:
-        f.write(buf.raw)
-      os.replace(tmp, path)
+      publish_id(path, buf.raw)
     else:
-      t0 = time.time()
-      while not os.path.exists(path):
-        if time.time() - t0 > timeout_s:
-          raise TimeoutError("no RCCL unique id at %s after %.0f s" % (path, timeout_s))
-        time.sleep(0.05)
-      with open(path, "rb") as f:
-        buf.raw = f.read(128)
+      buf.raw = wait_for_id(path, 128, _PROCESS_START, timeout_s)
     h = C.c_void_p()
     _lib.check(_lib.lib.pm_comm_init(C.byref(h), self.world, self.rank, buf))
     self.handle = h
@@ -144,6 +185,110 @@ def gather_members(comm, local, n_members):
   padded = np.zeros((pad,) + local.shape[1:])
   padded[:local.shape[0]] = local
   return assemble(comm.allgather_host(padded), counts)
+
+
+class DiagnosticGather(object):
+  """The one exchange step of the path: all-gather of per-member diagnostic fields at the
+  drivers' output cadence (`if ii % Diag_iters == 0`, run_JansenNadeau_2018.py:218-226) and
+  at the end of a run.
+
+  Every rank packs its fields into ONE send buffer laid out [field][pad][nlev] (pad = the
+  largest shard, so ragged shards gather with equal counts) with device-to-device copies and
+  issues ONE collective into recv[world][field][pad][nlev] -- fewer, larger messages suit
+  the per-link-bound xGMI mesh; no host staging.  Communicators without `allgather_device`
+  (the gloo test vehicle, which has no device) go through `allgather_host` on NumPy sources
+  with the same layout, which is what the CPU multi-process tests exercise.
+
+  fields: sequence of (name, nlev)."""
+
+  def __init__(self, comm, n_local, n_total, fields, stream=None, keep_history=False):
+    self.comm = comm if comm is not None else SingleCommunicator()
+    self.fields = [(str(k), int(v)) for k, v in fields]
+    self.n_local, self.n_total = int(n_local), int(n_total)
+    self.stream = stream
+    world, rank = self.comm.world, self.comm.rank
+    self.counts = [hi - lo for lo, hi in (member_range(self.n_total, world, r)
+                                          for r in range(world))]
+    if self.counts[rank] != self.n_local:
+      raise ValueError("rank %d owns %d of %d members, not %d" %
+                       (rank, self.counts[rank], self.n_total, self.n_local))
+    self.pad = max(self.counts) if self.counts else 0
+    self.offsets, off = {}, 0
+    for name, nlev in self.fields:
+      self.offsets[name] = off
+      off += self.pad * nlev
+    self.count = off  # doubles per rank
+    self.keep_history = keep_history
+    self.history = []  # [(step, {field: [n_total, nlev]})] when keep_history
+    self.ngathers = 0
+    self._send = self._recv = None
+    self._host = None  # last gathered [world][count] in host mode
+
+  def due(self, step, diag_iters):
+    return diag_iters is not None and diag_iters > 0 and step % int(diag_iters) == 0
+
+  # ---------------------------------------------------------------- device path
+  def _device_buffers(self):
+    from .device import DeviceArray
+    if self._send is None:
+      self._send = DeviceArray.zeros((self.count,), stream=self.stream)
+      self._recv = (self._send if self.comm.world == 1 else
+                    DeviceArray((self.comm.world, self.count)))
+    return self._send, self._recv
+
+  def _gather_device(self, sources):
+    from ._lib import check, lib
+    from .device import _sh
+    send, recv = self._device_buffers()
+    for name, nlev in self.fields:
+      src = sources[name]
+      ptr = src if isinstance(src, int) else src.ptr
+      check(lib.pm_memcpy_d2d(send.ptr + 8 * self.offsets[name], ptr,
+                              8 * self.n_local * nlev, _sh(self.stream)))
+    if self.comm.world > 1:
+      self.comm.allgather_device(send, recv, self.stream)
+
+  # ------------------------------------------------------------------ host path
+  def _gather_host(self, sources):
+    buf = np.zeros(self.count)
+    for name, nlev in self.fields:
+      a = np.ascontiguousarray(sources[name], dtype=np.float64).reshape(self.n_local, nlev)
+      o = self.offsets[name]
+      buf[o:o + self.n_local * nlev] = a.ravel()
+    self._host = np.asarray(self.comm.allgather_host(buf)).reshape(self.comm.world, self.count)
+
+  def gather(self, sources, step=None):
+    """sources: {field: DeviceArray | device address (int) | ndarray [n_local, nlev]}."""
+    host = any(isinstance(sources[k], np.ndarray) for k, _ in self.fields)
+    if host or (self.comm.world > 1 and not hasattr(self.comm, "allgather_device")):
+      if not host:  # device state but a host-only communicator: stage through the host
+        sources = {k: sources[k].download(stream=self.stream) for k, _ in self.fields}
+      self._gather_host(sources)
+    else:
+      self._host = None
+      self._gather_device(sources)
+    self.ngathers += 1
+    if self.keep_history:
+      self.history.append((step, self.last()))
+
+  def last(self):
+    """{field: [n_total, nlev]} of the most recent gather, shard padding removed."""
+    if self._host is not None:
+      g = self._host
+    elif self._recv is not None:
+      g = self._recv.download(stream=self.stream).reshape(self.comm.world, self.count)
+    else:
+      raise RuntimeError("nothing gathered yet")
+    out = {}
+    for name, nlev in self.fields:
+      o = self.offsets[name]
+      blk = g[:, o:o + self.pad * nlev].reshape(self.comm.world, self.pad, nlev)
+      out[name] = assemble(blk, self.counts)
+    return out
+
+  @property
+  def bytes_per_rank(self):
+    return 8 * self.count
 
 
 def make_communicator(**kw):

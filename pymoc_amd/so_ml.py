@@ -36,13 +36,13 @@ class SOMLBatch(object):
     bs = np.atleast_2d(np.asarray(bs, dtype=np.float64))
     self.n = bs.shape[0]
     self.stream = stream
-    self.y = DeviceArray.from_host(self.y_host)
-    self.bs = DeviceArray.from_host(bs)
-    self.Psi_s = DeviceArray.zeros((self.n, self.ny))
-    self.surflux = DeviceArray.from_host(_rows(surflux, self.n, self.ny))
-    self.rest_mask = DeviceArray.from_host(_rows(rest_mask, self.n, self.ny))
-    self.b_rest = DeviceArray.from_host(_rows(b_rest, self.n, self.ny))
-    self.status = DeviceArray.zeros((self.n,), np.int32)
+    self.y = DeviceArray.from_host(self.y_host, stream=stream)
+    self.bs = DeviceArray.from_host(bs, stream=stream)
+    self.Psi_s = DeviceArray.zeros((self.n, self.ny), stream=stream)
+    self.surflux = DeviceArray.from_host(_rows(surflux, self.n, self.ny), stream=stream)
+    self.rest_mask = DeviceArray.from_host(_rows(rest_mask, self.n, self.ny), stream=stream)
+    self.b_rest = DeviceArray.from_host(_rows(b_rest, self.n, self.ny), stream=stream)
+    self.status = DeviceArray.zeros((self.n,), np.int32, stream=stream)
     self.Ks, self.h, self.L, self.v_pist = float(Ks), float(h), float(L), float(v_pist)
 
   def step(self, b_basin, Psi_b, dt):

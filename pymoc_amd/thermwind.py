@@ -22,14 +22,14 @@ class ThermwindBatch(object):
     self.nz = self.z_host.size
     self.n, self.nb = int(n), int(nb)
     self.stream = stream
-    self.z = z_dev if z_dev is not None else DeviceArray.from_host(self.z_host)
+    self.z = z_dev if z_dev is not None else DeviceArray.from_host(self.z_host, stream=stream)
     fv = np.asarray(f, dtype=np.float64)
-    self.f = DeviceArray.from_host(np.full(self.n, fv) if fv.ndim == 0 else fv)
-    self.Psi = DeviceArray.zeros((self.n, self.nz))
-    self.bgrid = DeviceArray.zeros((self.n, self.nb))
-    self.psib = DeviceArray.zeros((self.n, self.nb))
-    self.psibz1 = DeviceArray.zeros((self.n, self.nz))
-    self.psibz2 = DeviceArray.zeros((self.n, self.nz))
+    self.f = DeviceArray.from_host(np.full(self.n, fv) if fv.ndim == 0 else fv, stream=stream)
+    self.Psi = DeviceArray.zeros((self.n, self.nz), stream=stream)
+    self.bgrid = DeviceArray.zeros((self.n, self.nb), stream=stream)
+    self.psib = DeviceArray.zeros((self.n, self.nb), stream=stream)
+    self.psibz1 = DeviceArray.zeros((self.n, self.nz), stream=stream)
+    self.psibz2 = DeviceArray.zeros((self.n, self.nz), stream=stream)
 
   @staticmethod
   def _ptr(x):

@@ -27,6 +27,7 @@ Sets:
                        the example_iteration loop (solve_equi + thermal wind, 30 iterations)
   G13 equi_column      Equi_Column.solve outputs (z, psi, b, H) for the example scripts' problems
                        and the reference tests' configurations (np.NaN restored for NumPy 2)
+  G16 thermwind_nonfinite Psib / Psibz with a user-assigned Psi holding NaN / inf (finite b1, b2)
   G14 thermwind_callable  Psi_Thermwind.solve with CALLABLE profiles (hazard H7: solve_bvp evaluates
                        them at its collocation midpoints and refines the mesh)
   G15 psi_so_callable  Psi_SO.solve with CALLABLE bs / tau (evaluated between grid points by the
@@ -170,6 +171,40 @@ def g3_thermwind():
                 p + "psibz1": pz[0], p + "psibz2": pz[1]})
   out["ncases"] = np.array(k + 1)
   save("thermwind", **out)
+
+
+# ------------------------------------------------------------------------ G16
+def nonfinite_psi_cases():
+  """(z, b1, b2, Psi) with a USER-ASSIGNED Psi holding NaN / inf under finite b1, b2
+  (`T.Psi = ...` is allowed between solve() and Psib()): `mask * udydz` then carries 0 * NaN
+  and 0 * inf = NaN into every class (psi_thermwind.py:175-184)."""
+  rng = np.random.default_rng(16)
+  cases = []
+  for nz, where, val in ((100, 50, np.nan), (100, 3, np.inf), (100, 97, -np.inf),
+                         (100, 0, np.nan), (200, 150, np.inf), (80, 40, np.nan),
+                         (30, 29, np.nan)):
+    z = np.linspace(-4000, 0, nz)
+    b1 = 0.03 * np.exp(z / 300) - 0.003
+    b2 = 1e-3 * 0.03 * np.exp(z / 300) - 0.0029
+    Psi = 10 * np.sin(np.pi * z / 4000)**2 + 0.1 * rng.standard_normal(nz)
+    Psi[where] = val
+    cases.append((z, b1, b2, Psi))
+  return cases
+
+
+def g16_thermwind_nonfinite():
+  out = {}
+  for k, (z, b1, b2, Psi) in enumerate(nonfinite_psi_cases()):
+    T = Psi_Thermwind(z=z, b1=b1.copy(), b2=b2.copy())
+    T.Psi = Psi.copy()
+    psib = T.Psib()
+    pz = T.Psibz()
+    p = "c%02d_" % k
+    out.update({p + "z": z, p + "b1": b1, p + "b2": b2, p + "Psi": Psi,
+                p + "bgrid": T.bgrid.copy(), p + "psib": psib, p + "psibz1": pz[0],
+                p + "psibz2": pz[1]})
+  out["ncases"] = np.array(k + 1)
+  save("thermwind_nonfinite", **out)
 
 
 # --------------------------------------------------------------------- G4 / G6
@@ -762,10 +797,11 @@ def g9_twobasin():
 
 
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
   table = dict(g1=[g1_column_steps], g2=[g2_config1], g3=[g3_thermwind], g4=[g4_twocol],
                g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
-               g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column], g14=[g14_thermwind_callable], g15=[g15_psi_so_callable])
+               g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column], g14=[g14_thermwind_callable], g15=[g15_psi_so_callable],
+               g16=[g16_thermwind_nonfinite])
   for w in which:
     for fn in table[w]:
       fn()

@@ -316,6 +316,20 @@ def test_thermwind_callable_profiles_golden():
     assert relerr(O.thermwind_solve(z, b1, 0. * z, 1.2e-4), g["nz%d_Psi" % nz]) > 1e-5
 
 
+def test_thermwind_nonfinite_psi_golden():
+  """G16: a user-assigned Psi with NaN / inf under finite b1, b2 poisons every class
+  (0 * NaN, 0 * inf in `mask * udydz`, psi_thermwind.py:183-184)."""
+  g = load_golden("thermwind_nonfinite")
+  for k in range(int(g["ncases"])):
+    p = "c%02d_" % k
+    bgrid, psib, o1, o2 = O.thermwind_psibz(g[p + "b1"], g[p + "b2"], g[p + "Psi"], 500)
+    assert np.array_equal(bgrid, g[p + "bgrid"]), k
+    assert np.array_equal(psib, g[p + "psib"], equal_nan=True), k
+    assert np.array_equal(o1, g[p + "psibz1"], equal_nan=True), k
+    assert np.array_equal(o2, g[p + "psibz2"], equal_nan=True), k
+    assert np.isnan(psib).all()
+
+
 # --------------------------------------------------------------------- G8 sweep members
 def _member(cfg, i, keys):
   m = dict(cfg)

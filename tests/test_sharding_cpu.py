@@ -79,3 +79,121 @@ def test_gloo_sharded_ensemble_matches_single_process(tmp_path, world, N):
   ref = O.column_ensemble_steps(c["z"], c["kappa"], c["Area"], c["b0"], c["wA"], c["dt"],
                                 c["do_conv"], c["bs"], c["bbot"], c["N2min"], 20)
   assert np.array_equal(np.load(out), ref)
+
+
+# ------------------------------------------------- rendezvous, launcher, diagnostic gather
+def test_rendezvous_key_uses_launcher_values_only(monkeypatch):
+  """Ranks started by different parents (any spawner, one wrapper shell per rank) must meet
+  at the same file: the key may depend on MASTER_ADDR/PORT and the run id only."""
+  env = dict(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", TORCHELASTIC_RUN_ID="abc")
+  p0 = sharding.rendezvous_path(env)
+  monkeypatch.setattr(os, "getppid", lambda: 424242)
+  assert sharding.rendezvous_path(env) == p0
+  assert sharding.rendezvous_path(dict(env, MASTER_PORT="29512")) != p0
+  assert sharding.rendezvous_path(dict(env, TORCHELASTIC_RUN_ID="abd")) != p0
+  assert sharding.rendezvous_path(dict(env, PYMOC_RUN_ID="x")) != p0
+  assert sharding.rendezvous_path(dict(env, TORCHELASTIC_RESTART_COUNT="1")) != p0
+  assert sharding.rendezvous_path(dict(env, PYMOC_RENDEZVOUS="/tmp/given")) == "/tmp/given"
+
+
+def test_stale_id_file_is_ignored_and_replaced(tmp_path):
+  import threading
+  import time
+  path = str(tmp_path / "id")
+  with open(path, "wb") as f:
+    f.write(b"S" * 128)
+  old = time.time() - 3600
+  os.utime(path, (old, old))  # leftover of a crashed run, an hour old
+  with pytest.raises(TimeoutError):
+    sharding.wait_for_id(path, 128, time.time(), timeout_s=0.3)
+  t = threading.Timer(0.2, sharding.publish_id, (path, b"N" * 128))
+  t.start()
+  assert sharding.wait_for_id(path, 128, time.time(), timeout_s=10) == b"N" * 128
+  t.join()
+
+
+def test_launcher_environment_and_exit_code(tmp_path):
+  from pymoc_amd import launch
+  script = tmp_path / "child.py"
+  script.write_text(
+      "import os, sys\n"
+      "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+      "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+      "open(os.path.join(sys.argv[1], 'r%d_%s_%s' % (r, os.environ['MASTER_PORT'],\n"
+      "     os.environ['PYMOC_RUN_ID'])), 'w').close()\n"
+      "sys.exit(int(sys.argv[2]) if r == w - 1 else 0)\n")
+  out = tmp_path / "out"
+  out.mkdir()
+  assert launch.spawn([sys.executable, str(script), str(out), "0"], 3) == 0
+  names = sorted(os.listdir(out))
+  assert [n.split("_")[0] for n in names] == ["r0", "r1", "r2"]
+  assert len({n.split("_", 1)[1] for n in names}) == 1  # same port and run id for all ranks
+  assert launch.spawn([sys.executable, str(script), str(out), "7"], 2) == 7
+
+
+def test_diagnostic_gather_single_rank_host_path():
+  g = sharding.DiagnosticGather(None, 5, 5, [("a", 3), ("b", 2)], keep_history=True)
+  a, b = np.arange(15.).reshape(5, 3), -np.arange(10.).reshape(5, 2)
+  assert g.due(0, 240) and g.due(480, 240) and not g.due(24, 240) and not g.due(5, None)
+  g.gather(dict(a=a, b=b), step=0)
+  last = g.last()
+  assert np.array_equal(last["a"], a) and np.array_equal(last["b"], b)
+  assert g.history[0][0] == 0 and g.ngathers == 1 and g.bytes_per_rank == 8 * 25
+  with pytest.raises(ValueError):
+    sharding.DiagnosticGather(None, 4, 5, [("a", 3)])
+
+
+DIAG_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["PM_ROOT"]); sys.path.insert(0, os.path.join(os.environ["PM_ROOT"], "tests"))
+from oracle import drivers
+from gloo_comm import GlooCommunicator
+from pymoc_amd import configs, sharding
+N, steps, D = int(os.environ["PM_N"]), 73, 24
+comm = GlooCommunicator()
+lo, hi = sharding.member_range(N, comm.world, comm.rank)
+cfg = configs.config3(N=N, members=(lo, hi))
+nz = cfg["z"].size
+diag = sharding.DiagnosticGather(comm, hi - lo, N, [(k, nz) for k in ("b_basin", "b_north", "Psi", "Psi_SO")],
+                                 keep_history=True)
+# the coupled loop of TwoColEnsemble with the ORACLE as the stepper (no GPU here): gather after
+# the update of every step ii with ii % D == 0, and once more at the end
+snaps = [ii + 1 for ii in range(steps) if ii % D == 0] + [steps]
+runs = [drivers.run_twocol(configs.member(cfg, j, 3), steps, snaps) for j in range(hi - lo)]
+for s in snaps:
+  st = {k: np.stack([r[s][k] for r in runs]) if runs else np.zeros((0, nz))
+        for k in ("b_basin", "b_north", "Psi", "Psi_SO")}
+  diag.gather(st, step=s)
+if comm.rank == 0:
+  np.savez(os.environ["PM_OUT"], steps=np.array([h[0] for h in diag.history]),
+           **{"%s_%d" % (k, i): h[1][k] for i, h in enumerate(diag.history) for k in h[1]})
+comm.close()
+'''
+
+
+@pytest.mark.parametrize("world,N", [(2, 6), (3, 5)])
+def test_gloo_diagnostic_gather_cadence_matches_single_process(tmp_path, world, N):
+  """The coupled drivers' Diag_iters gather across ranks (ragged shards included) must
+  deliver, at every cadence point, exactly the fields of the unsharded ensemble."""
+  from oracle import drivers
+  from pymoc_amd import configs
+  out = str(tmp_path / "diag.npz")
+  port = _free_port()
+  procs = []
+  for r in range(world):
+    env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PM_ROOT=ROOT, PM_OUT=out,
+               PM_N=str(N), OMP_NUM_THREADS="1")
+    procs.append(subprocess.Popen([sys.executable, "-c", DIAG_WORKER], env=env))
+  for p in procs:
+    assert p.wait(timeout=300) == 0
+  got = np.load(out)
+  steps = list(got["steps"])
+  assert steps == [1, 25, 49, 73, 73]
+  cfg = configs.config3(N=N)
+  runs = [drivers.run_twocol(configs.member(cfg, j, 3), 73, steps) for j in range(N)]
+  for i, s in enumerate(steps):
+    for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
+      ref = np.stack([r[s][k] for r in runs])
+      assert np.array_equal(got["%s_%d" % (k, i)], ref), (s, k)

@@ -55,3 +55,87 @@ def test_gloo_sharded_gpu_ensemble_matches_single_process(gpu, tmp_path, world, 
   got = np.load(out)
   for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
     assert np.array_equal(got[k], st[k]), k
+
+
+DIAG_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["PM_ROOT"]); sys.path.insert(0, os.path.join(os.environ["PM_ROOT"], "tests"))
+from gloo_comm import GlooCommunicator
+import pymoc_amd
+from pymoc_amd import configs, sharding
+N, cfgno = int(os.environ["PM_N"]), int(os.environ["PM_CFG"])
+comm = GlooCommunicator()
+lo, hi = sharding.member_range(N, comm.world, comm.rank)
+if cfgno == 4:
+  cfg = dict(configs.config4(N=N, members=(lo, hi)), bvp_refine=8)
+  ens = pymoc_amd.TwoColEnsemble(cfg, comm=comm, n_total=N, diag_iters=48, keep_history=True)
+  ens.run(100)
+else:
+  cfg = configs.config5(N=N, members=(lo, hi))
+  ens = pymoc_amd.JN2018Ensemble(cfg, comm=comm, n_total=N, diag_iters=72, keep_history=True)
+  ens.run(150)
+ens.gather_diagnostics()
+if comm.rank == 0:
+  h = ens.diag.history
+  np.savez(os.environ["PM_OUT"], steps=np.array([s for s, _ in h]),
+           **{"%s_%d" % (k, i): d[k] for i, (s, d) in enumerate(h) for k in d})
+comm.close()
+'''
+
+
+@pytest.mark.parametrize("cfgno,world,N", [(4, 2, 40), (5, 3, 10)])
+def test_sharded_coupled_driver_gathers_at_diag_cadence(gpu, tmp_path, cfgno, world, N):
+  """Coupled drivers with a communicator: the Diag_iters gathers of a sharded run (2-3
+  processes on the one GPU, gloo carrying the collective) equal, gather for gather and bit
+  for bit, those of the unsharded ensemble (which packs on device and needs no collective)."""
+  from pymoc_amd import configs
+  out = str(tmp_path / "diag.npz")
+  port = _free_port()
+  procs = []
+  for r in range(world):
+    env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PM_ROOT=ROOT, PM_OUT=out,
+               PM_N=str(N), PM_CFG=str(cfgno), OMP_NUM_THREADS="1")
+    procs.append(subprocess.Popen([sys.executable, "-c", DIAG_WORKER], env=env))
+  for p in procs:
+    assert p.wait(timeout=300) == 0
+  if cfgno == 4:
+    ens = gpu.TwoColEnsemble(dict(configs.config4(N=N), bvp_refine=8), diag_iters=48,
+                             keep_history=True)
+    ens.run(100)
+    want_steps = [0, 48, 96, 100]
+  else:
+    ens = gpu.JN2018Ensemble(configs.config5(N=N), diag_iters=72, keep_history=True)
+    ens.run(150)
+    want_steps = [0, 72, 144, 150]
+  ens.gather_diagnostics()
+  got = np.load(out)
+  assert list(got["steps"]) == want_steps
+  assert [s for s, _ in ens.diag.history] == want_steps
+  for i, (s, d) in enumerate(ens.diag.history):
+    for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
+      assert np.array_equal(got["%s_%d" % (k, i)], d[k]), (s, k)
+  # the last gather is the state itself
+  st = ens.state()
+  for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
+    assert np.array_equal(ens.diag.history[-1][1][k], st[k]), k
+
+
+def test_explicit_stream_equals_default_stream(gpu):
+  """Every fill, upload, launch and download of a driver must be ordered on the stream the
+  caller passes: a run on an explicit (non-blocking) Stream is bit-identical to the
+  default-stream run (ADVICE r1: zero-fills on a private stream could be overtaken)."""
+  from pymoc_amd import configs
+  s = gpu.Stream()
+  for make, steps in (
+      (lambda st: gpu.TwoColEnsemble(dict(configs.config4(N=32), bvp_refine=8), stream=st), 60),
+      (lambda st: gpu.JN2018Ensemble(configs.config5(N=16), stream=st), 80),
+      (lambda st: gpu.ColumnThermwindEnsemble(configs.config1(), stream=st), 20),
+      (lambda st: gpu.TwoBasinEnsemble(configs.config_twobasin(N=8), stream=st), 50)):
+    a, b = make(None), make(s)
+    a.run(steps)
+    b.run(steps)
+    sa, sb = a.state(), b.state()
+    for k in sa:
+      assert np.array_equal(sa[k], sb[k], equal_nan=True), k

@@ -43,6 +43,32 @@ def test_thermwind_golden(gpu):
     assert np.array_equal(t.psibz2.download()[0], g[p + "psibz2"], equal_nan=True), k
 
 
+def test_psib_nonfinite_psi_golden(gpu):
+  """G16: with a user-assigned Psi holding NaN / inf and finite b1, b2 the
+  reference's `mask * udydz` is NaN even under a zero mask; the group shortcuts of Psib must
+  not hide that.  Also a batch mixing poisoned and clean members."""
+  from pymoc_amd import _lib
+  from pymoc_amd.device import DeviceArray
+  g = load_golden("thermwind_nonfinite")
+  ops = _lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ
+  for k in range(int(g["ncases"])):
+    p = "c%02d_" % k
+    z, b1, b2, Psi = g[p + "z"], g[p + "b1"], g[p + "b2"], g[p + "Psi"]
+    clean = np.where(np.isfinite(Psi), Psi, 0.0)
+    t = gpu.ThermwindBatch(z, 3, nb=500)
+    t.Psi.upload(np.stack([clean, Psi, clean]))
+    t.update(DeviceArray.from_host(np.stack([b1] * 3)), DeviceArray.from_host(np.stack([b2] * 3)),
+             ops=ops)
+    psib, o1, o2 = t.psib.download(), t.psibz1.download(), t.psibz2.download()
+    assert np.array_equal(t.bgrid.download()[1], g[p + "bgrid"]), k
+    assert np.array_equal(psib[1], g[p + "psib"], equal_nan=True), k
+    assert np.array_equal(o1[1], g[p + "psibz1"], equal_nan=True), k
+    assert np.array_equal(o2[1], g[p + "psibz2"], equal_nan=True), k
+    rg, rp, r1, r2 = O.thermwind_psibz(b1, b2, clean, 500)
+    for m in (0, 2):  # neighbours in the batch are untouched
+      assert np.array_equal(psib[m], rp) and np.array_equal(o1[m], r1), (k, m)
+
+
 @pytest.mark.parametrize("nz,nb", [(2, 5), (3, 500), (9, 64), (64, 1), (65, 257), (100, 500),
                                    (129, 500), (130, 100), (200, 500), (513, 300),
                                    (1024, 500)])
