@@ -249,6 +249,15 @@ class DiagnosticGather(object):
       self.comm.allgather_device(send, recv, self.stream)
 
   # ------------------------------------------------------------------ host path
+  def _to_host(self, src, nlev):
+    """[n_local, nlev] host copy of a DeviceArray or of a raw device address."""
+    from ._lib import check, lib
+    from .device import _sh
+    out = np.empty((self.n_local, nlev))
+    ptr = src if isinstance(src, int) else src.ptr
+    check(lib.pm_memcpy_d2h(out.ctypes.data, ptr, out.nbytes, _sh(self.stream)))
+    return out
+
   def _gather_host(self, sources):
     buf = np.zeros(self.count)
     for name, nlev in self.fields:
@@ -262,7 +271,7 @@ class DiagnosticGather(object):
     host = any(isinstance(sources[k], np.ndarray) for k, _ in self.fields)
     if host or (self.comm.world > 1 and not hasattr(self.comm, "allgather_device")):
       if not host:  # device state but a host-only communicator: stage through the host
-        sources = {k: sources[k].download(stream=self.stream) for k, _ in self.fields}
+        sources = {k: self._to_host(sources[k], nlev) for k, nlev in self.fields}
       self._gather_host(sources)
     else:
       self._host = None

@@ -28,6 +28,9 @@ Sets:
   G13 equi_column      Equi_Column.solve outputs (z, psi, b, H) for the example scripts' problems
                        and the reference tests' configurations (np.NaN restored for NumPy 2)
   G16 thermwind_nonfinite Psib / Psibz with a user-assigned Psi holding NaN / inf (finite b1, b2)
+  G17 sweep_full       sweep members over the configured run length of configs 2-5; the two
+                       config-5 members the reference itself blows up on
+  G18 range_evidence   the reference blowing up at the SURVEY 8d sweep values configs.py drops
   G14 thermwind_callable  Psi_Thermwind.solve with CALLABLE profiles (hazard H7: solve_bvp evaluates
                        them at its collocation midpoints and refines the mesh)
   G15 psi_so_callable  Psi_SO.solve with CALLABLE bs / tau (evaluated between grid points by the
@@ -342,7 +345,9 @@ def g7_so_ml():
   save("so_ml", **out)
 
 
-def ref_jn2018(m, nsteps, snaps):
+def ref_jn2018(m, nsteps, snaps, catch=False):
+  """catch=True: a raising reference (NaN reaching brentq -> ValueError) ends the run; the
+  snapshots so far are returned with out['raised'] = (1-based step, exception name)."""
   z, y = m['z'], m['y']
   kappa = m.get('kappa_fn', configs.jn2018_kappa)
   kappaeff = m.get('kappaeff_fn', configs.jn2018_kappaeff)
@@ -363,11 +368,17 @@ def ref_jn2018(m, nsteps, snaps):
   out = {}
   for ii in range(nsteps):
     if ii % m['MOC_up_iters'] == 0:
-      AMOC.update(b1=basin.b, b2=north.b)
-      AMOC.solve()
-      [Psi_res_b, Psi_res_n] = AMOC.Psibz(nb=m['nb'])
-      PsiSO.update(b=basin.b, bs=channel.bs)
-      PsiSO.solve()
+      try:
+        AMOC.update(b1=basin.b, b2=north.b)
+        AMOC.solve()
+        [Psi_res_b, Psi_res_n] = AMOC.Psibz(nb=m['nb'])
+        PsiSO.update(b=basin.b, bs=channel.bs)
+        PsiSO.solve()
+      except Exception as e:  # noqa: BLE001
+        if not catch:
+          raise
+        out['raised'] = (ii + 1, type(e).__name__)
+        return out
     wAb = (Psi_res_b - PsiSO.Psi) * 1e6
     wAN = -Psi_res_n * 1e6
     if PsiSO.Psi[1] < 0:
@@ -653,6 +664,221 @@ def g8_sweep():
   save("sweep", **out)
 
 
+# ------------------------------------------------------------------------ G17
+def _first_bad(snaps):
+  """First snapshot step holding a non-finite value (None if none)."""
+  for step in sorted(snaps):
+    if not all(np.isfinite(v).all() for v in snaps[step].values()):
+      return step
+  return None
+
+
+def g17_sweep_full():
+  """Sweep members followed over the CONFIGURED run length of each BASELINE config
+  (VERDICT r1 items 3, 4): config 2 x 1000 steps, config 3 x 2400, config 4 x 2400,
+  config 5 x 3600 -- for config 5 with a snapshot at every MOC update, so that the test can
+  follow each member up to its first Psib sign flip (hazard H6: the bottom cell's thickness
+  b[1]-b[0] is last-bit noise under the no-flux BC and its SIGN decides whether Psib counts
+  that cell; two exact implementations part there) -- plus the two members of the 4096-member
+  config-5 ensemble that blow up in the reference itself."""
+  out = {}
+  c2 = configs.config2(N=1024)
+  pick = np.arange(0, 1024, 64)
+  res = []
+  for i in pick:
+    col = Column(z=c2['z'], kappa=c2['kappa'][i].copy(), Area=c2['Area'][i].copy(),
+                 b=c2['b0'][i].copy(), bs=float(c2['bs'][i]), bbot=float(c2['bbot'][i]),
+                 N2min=float(c2['N2min'][i]))
+    for _ in range(1000):
+      col.timestep(wA=c2['wA'][i], dt=c2['dt'], do_conv=bool(c2['do_conv'][i]))
+    res.append(col.b.copy())
+  out.update(c2_members=pick, c2_nsteps=np.array(1000), c2_b=np.array(res))
+  print("config 2 done", flush=True)
+
+  c3 = configs.config3(N=4096)
+  pick = np.arange(0, 4096, 512)
+  keys = ('b_basin', 'b_north', 'Psi')
+  acc = {k: [] for k in keys}
+  for i in pick:
+    s = ref_twocol(configs.member(c3, i, 3), 2400, {2400})[2400]
+    for k in keys:
+      acc[k].append(s[k])
+  out.update(c3_members=pick, c3_nsteps=np.array(2400))
+  out.update({"c3_" + k: np.array(v) for k, v in acc.items()})
+  print("config 3 done", flush=True)
+
+  c4 = configs.config4(N=8192)
+  pick = np.arange(0, 8192, 1024)
+  keys = ('b_basin', 'b_north', 'Psi', 'Psi_SO')
+  acc = {k: [] for k in keys}
+  for i in pick:
+    s = ref_twocol(configs.member(c4, i, 4), 2400, {2400}, so=True)[2400]
+    for k in keys:
+      acc[k].append(s[k])
+  out.update(c4_members=pick, c4_nsteps=np.array(2400))
+  out.update({"c4_" + k: np.array(v) for k, v in acc.items()})
+  print("config 4 done", flush=True)
+
+  c5 = configs.config5(N=4096)
+  pick = np.arange(0, 4096, 512)
+  M = int(c5['MOC_up_iters'])
+  every = list(range(M, 3600 + 1, M))        # what the reference and the oracle are compared on
+  stored = list(range(2 * M, 3600 + 1, 2 * M))  # what the fixture keeps (every 72 steps)
+  keys = ('b_basin', 'b_north', 'bs_SO', 'Psi_SO')
+  traj = {k: [] for k in keys}
+  clean_until = []
+  from oracle import drivers as orc  # the CPU restatement: locates each member's first flip
+  for i in pick:
+    m = configs.member(c5, i, 5)
+    s = ref_jn2018(m, 3600, set(every))
+    o = orc.run_jn2018(m, 3600, every)
+    ok = 0
+    for t in every:
+      e = max(np.abs(o[t][k] - s[t][k]).max() / np.abs(s[t][k]).max() for k in keys)
+      if e > 1e-10:
+        break
+      ok = t
+    clean_until.append(ok - ok % (2 * M))
+    for k in keys:
+      traj[k].append(np.array([s[t][k] for t in stored]))
+    print("config 5 member", i, "oracle tracks the reference up to step", ok, flush=True)
+  out.update(c5_members=pick, c5_steps=np.array(stored), c5_clean_until=np.array(clean_until))
+  out.update({"c5_" + k: np.array(v) for k, v in traj.items()})  # [member][snapshot][level]
+
+  # the members that go non-finite within the bench's 72 + 3600 steps (db ~ 6.019e-4)
+  bad = np.array([2, 1268])
+  first, raised, last_ok = [], [], []
+  for i in bad:
+    s = ref_jn2018(configs.member(c5, i, 5), 3672, set(range(1, 3672 + 1)), catch=True)
+    r = s.pop('raised', (0, ''))
+    fb = _first_bad(s)
+    first.append(fb or 0)
+    raised.append(r[0])
+    ok = max(t for t in s if fb is None or t < fb)
+    last_ok.append(ok)
+    out["c5_blowup_%d_step" % i] = np.array(ok)
+    for k in ('b_basin', 'b_north', 'bs_SO'):
+      out["c5_blowup_%d_%s" % (i, k)] = s[ok][k]
+    print("config 5 bad member", i, "first non-finite step", fb, "raised", r, flush=True)
+  out.update(c5_blowup_members=bad, c5_blowup_first_bad_step=np.array(first),
+             c5_blowup_raised_step=np.array(raised), c5_blowup_last_finite_step=np.array(last_ok),
+             c5_blowup_db=c5['scalars']['db'][bad], c5_blowup_nsteps=np.array(3672))
+  save("sweep_full", **out)
+
+
+# ------------------------------------------------------------------------ G18
+def _ref_blowup_step(run, nsteps, probe):
+  """First 1-based step after which `probe()` is non-finite when `run(ii)` is stepped, or the
+  step at which the reference raised (NaNs reaching brentq / solve_bvp raise ValueError)."""
+  for ii in range(nsteps):
+    try:
+      run(ii)
+    except Exception as e:  # noqa: BLE001
+      return ii + 1, type(e).__name__
+    if not np.isfinite(probe()).all():
+      return ii + 1, "nonfinite"
+  return 0, "finite"
+
+
+def g18_range_evidence():
+  """Why pymoc_amd/configs.py narrows three sweep ranges of SURVEY 8d and config 1's dt: at
+  the dropped values the REFERENCE's explicit column scheme (column.py:245-249) blows up.
+  For each probe: its parameters, the step at which the reference goes non-finite (or
+  raises), and the same for a value inside the narrowed range (stays finite)."""
+  out = {}
+
+  def twocol(m, so, nsteps):
+    st = {}
+
+    def start():
+      z = m['z']
+      st['AMOC'] = Psi_Thermwind(z=z, b1=m['b_basin0'].copy(), b2=m['b_north0'].copy(), f=m['f'])
+      st['AMOC'].solve()
+      st['pib'], st['pin'] = st['AMOC'].Psibz()
+      if so:
+        st['SO'] = Psi_SO(z=z, y=m['y'], b=m['b_basin0'].copy(), bs=m['bs_SO'].copy(),
+                          tau=float(m['tau']), f=m['f'], L=m['L'], KGM=float(m['KGM']),
+                          c=m['c'], bvp_with_Ek=m['bvp_with_Ek'])
+        st['SO'].solve()
+      kap = m['kappa'] + 0 * z
+      st['basin'] = Column(z=z, kappa=kap.copy(), Area=float(m['A_basin']),
+                           b=m['b_basin0'].copy(), bs=float(m['bs']), bbot=float(m['bbot']))
+      st['north'] = Column(z=z, kappa=kap.copy(), Area=float(m['A_north']),
+                           b=m['b_north0'].copy(), bs=float(m['bs_north']),
+                           bbot=float(m['bbot']))
+
+    def run(ii):
+      wAb = (st['pib'] - st['SO'].Psi) * 1e6 if so else st['pib'] * 1e6
+      st['basin'].timestep(wA=wAb, dt=m['dt'])
+      st['north'].timestep(wA=-st['pin'] * 1e6, dt=m['dt'], do_conv=True)
+      if ii % m['MOC_up_iters'] == 0:
+        st['AMOC'].update(b1=st['basin'].b, b2=st['north'].b)
+        st['AMOC'].solve()
+        st['pib'], st['pin'] = st['AMOC'].Psibz()
+        if so:
+          st['SO'].update(b=st['basin'].b)
+          st['SO'].solve()
+
+    start()
+    return _ref_blowup_step(run, nsteps, lambda: np.concatenate([st['basin'].b, st['north'].b]))
+
+  # config 3: kappa_4k (SURVEY: up to 1e-3; configs.config3: up to 2.5e-4)
+  probes = []
+  for k4 in (2.5e-4, 4e-4, 1e-3):
+    step, how = twocol(configs.twocol_member(nz=100, kappa_4k=k4, kappa_back=5e-5), False, 2400)
+    probes.append((k4, step, how))
+    print("config3 kappa_4k", k4, step, how, flush=True)
+  out.update(c3_kappa_4k=np.array([p[0] for p in probes]),
+             c3_blowup_step=np.array([p[1] for p in probes]),
+             c3_how=np.array([p[2] for p in probes]))
+  # config 4: A_basin (SURVEY: down to 3e13; configs.config4: from 4.5e13)
+  probes = []
+  for A in (4.5e13, 3.6e13, 3e13):
+    m = configs.twocol_so_member(nz=100, ny=40, A_basin=A, kappa=5e-5, tau=0.2, KGM=500.)
+    step, how = twocol(m, True, 2400)
+    probes.append((A, step, how))
+    print("config4 A_basin", A, step, how, flush=True)
+  out.update(c4_A_basin=np.array([p[0] for p in probes]),
+             c4_blowup_step=np.array([p[1] for p in probes]),
+             c4_how=np.array([p[2] for p in probes]))
+  # config 5: db (SURVEY: up to 4e-3; configs.config5: up to 8e-4)
+  probes = []
+  for db in (4e-4, 1e-3, 4e-3):
+    m = configs.jn2018_member(nz=200, dt_days=10., db=db)
+    try:
+      s = ref_jn2018(m, 3600, set(range(36, 3601, 36)))
+      bad = _first_bad(s)
+      probes.append((db, bad or 0, "nonfinite" if bad else "finite"))
+    except Exception as e:  # noqa: BLE001
+      probes.append((db, -1, type(e).__name__))
+    print("config5 db", probes[-1], flush=True)
+  out.update(c5_db=np.array([p[0] for p in probes]),
+             c5_blowup_step=np.array([p[1] for p in probes]),
+             c5_how=np.array([p[2] for p in probes]))
+  # config 1: dt (the script's 60 d is for its nz=70 grid; configs.config1 uses 30 d at nz=100)
+  probes = []
+  for dt_days in (30., 60.):
+    cfg = configs.config1(nz=100)
+    z = cfg['z']
+    basin = Column(z=z, kappa=cfg['kappa'].copy(), Area=cfg['Area'], b=cfg['b0'].copy(),
+                   bs=cfg['bs'], bbot=cfg['bbot'])
+    AMOC = Psi_Thermwind(z=z, b1=cfg['b0'].copy(), f=cfg['f'])
+    AMOC.solve()
+
+    def run(ii):
+      basin.timestep(wA=AMOC.Psi * 1e6, dt=dt_days * 86400.)
+      AMOC.update(b1=basin.b)
+      AMOC.solve()
+
+    step, how = _ref_blowup_step(run, 1000, lambda: basin.b)
+    probes.append((dt_days, step, how))
+    print("config1 dt", dt_days, step, how, flush=True)
+  out.update(c1_dt_days=np.array([p[0] for p in probes]),
+             c1_blowup_step=np.array([p[1] for p in probes]),
+             c1_how=np.array([p[2] for p in probes]))
+  save("range_evidence", **out)
+
+
 # ------------------------------------------------- G10 diagnostics + pickup wire format
 def g10_jn2018_files():
   """What `run_JansenNadeau_2018.py --diagfile d.npz --pickup_save_file p.npz` writes
@@ -797,11 +1023,11 @@ def g9_twobasin():
 
 
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
   table = dict(g1=[g1_column_steps], g2=[g2_config1], g3=[g3_thermwind], g4=[g4_twocol],
                g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
                g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column], g14=[g14_thermwind_callable], g15=[g15_psi_so_callable],
-               g16=[g16_thermwind_nonfinite])
+               g16=[g16_thermwind_nonfinite], g17=[g17_sweep_full], g18=[g18_range_evidence])
   for w in which:
     for fn in table[w]:
       fn()

@@ -179,3 +179,15 @@ def test_convective_pattern_churn_vs_oracle(gpu, nz, G):
     batch2.steps(wA, dt, 50, lanes_per_col=G)
   assert np.array_equal(batch2.get_b(), ref, equal_nan=True)
   assert np.isfinite(ref).all()
+
+
+def test_config2_members_full_length_vs_reference(gpu):
+  """G17: the 16 reference-run members over config 2's whole 1000 steps, one fused launch."""
+  g = load_golden("sweep_full")
+  c = configs.config2(N=1024)
+  batch = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"], bs=c["bs"],
+                          bbot=c["bbot"], N2min=c["N2min"], do_conv=c["do_conv"])
+  batch.steps(c["wA"], c["dt"], int(g["c2_nsteps"]))
+  assert int(g["c2_nsteps"]) == c["nsteps"] == 1000
+  assert np.array_equal(batch.get_b()[g["c2_members"]], g["c2_b"])
+  assert batch.get_nonfinite().sum() == 0

@@ -402,3 +402,123 @@ def test_twobasin_trajectory_golden():
     s = drivers.run_twobasin(_member(c, i, ("tau", "K", "A_Pac", "A_Atl", "A_north")), n, {n})[n]
     for k in ("b_Atl", "b_north", "b_Pac", "Psi_AMOC", "Psi_ZOC", "Psi_SO_Atl"):
       assert relerr(s[k], g["sweep_" + k][j]) <= TOL_TRAJ, (i, k)
+
+
+# ---------------------------------------------- G17 sweep members over the configured length
+def test_sweep_full_config2_bitwise():
+  g = load_golden("sweep_full")
+  c = configs.config2(N=1024)
+  idx = g["c2_members"]
+  b = O.column_ensemble_steps(c["z"], c["kappa"][idx], c["Area"][idx], c["b0"][idx],
+                              c["wA"][idx], c["dt"], c["do_conv"][idx], c["bs"][idx],
+                              c["bbot"][idx], c["N2min"][idx], int(g["c2_nsteps"]))
+  assert int(g["c2_nsteps"]) == 1000
+  assert np.array_equal(b, g["c2_b"])
+
+
+def test_sweep_full_config3_2400_steps():
+  g = load_golden("sweep_full")
+  c = configs.config3(N=4096)
+  n = int(g["c3_nsteps"])
+  assert n == c["nsteps"] == 2400
+  for j, i in enumerate(g["c3_members"]):
+    s = drivers.run_twocol(configs.member(c, i, 3), n, {n})[n]
+    for k in ("b_basin", "b_north", "Psi"):
+      assert relerr(s[k], g["c3_" + k][j]) <= TOL_TRAJ, (i, k)
+
+
+def test_sweep_full_config4_2400_steps():
+  g = load_golden("sweep_full")
+  c = configs.config4(N=8192)
+  n = int(g["c4_nsteps"])
+  assert n == c["nsteps"] == 2400
+  for j, i in enumerate(g["c4_members"]):
+    s = drivers.run_twocol(configs.member(c, i, 4), n, {n}, so=True)[n]
+    for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
+      assert relerr(s[k], g["c4_" + k][j]) <= TOL_BVP, (i, k)
+
+
+C5_KEYS = ("b_basin", "b_north", "bs_SO", "Psi_SO")
+C5_FLIP_BOUND, C5_FLIP_END = 5e-3, 1e-4
+
+
+def check_config5_full(traj, g, j, clean_until):
+  """traj: {step: {field: array}} of member j on the fixture's snapshot steps.  Up to
+  `clean_until` (no Psib flip yet, hazard H6) the reference is followed to 1e-10; a flip
+  perturbs Psi_iso by ~1 % for one update and the trajectories close again: never more than
+  5e-3 apart, 1e-4 at the end of the 3600 steps."""
+  steps = [int(t) for t in g["c5_steps"]]
+  worst = 0.
+  for ti, t in enumerate(steps):
+    e = max(relerr(traj[t][k], g["c5_" + k][j][ti]) for k in C5_KEYS)
+    if t <= clean_until:
+      assert e <= 1e-10, (j, t, e)
+    worst = max(worst, e)
+  assert worst <= C5_FLIP_BOUND, (j, worst)
+  assert e <= C5_FLIP_END, (j, e)
+  return worst
+
+
+def test_sweep_full_config5_3600_steps():
+  g = load_golden("sweep_full")
+  c = configs.config5(N=4096)
+  steps = [int(t) for t in g["c5_steps"]]
+  assert steps[-1] == c["nsteps"] == 3600
+  clean = g["c5_clean_until"]
+  assert (clean == 3600).sum() >= 4  # at least half of the members never flip
+  for j, i in enumerate(g["c5_members"]):
+    s = drivers.run_jn2018(configs.member(c, i, 5), 3600, steps)
+    check_config5_full(s, g, j, int(clean[j]))
+
+
+def test_config5_blowup_members_are_the_references():
+  """Members 2 and 1268 of the 4096-member config-5 ensemble (db = 6.0187e-4 / 6.0192e-4): the
+  REFERENCE goes non-finite at step 37 (the step after the second MOC update) and raises
+  ValueError from brentq at step 73.  The oracle loses the same members at the same step;
+  the state one step earlier agrees."""
+  g = load_golden("sweep_full")
+  c = configs.config5(N=4096)
+  assert list(g["c5_blowup_members"]) == [2, 1268]
+  assert list(g["c5_blowup_first_bad_step"]) == [37, 37]
+  assert list(g["c5_blowup_raised_step"]) == [73, 73]
+  for i in (2, 1268):
+    s = drivers.run_jn2018(configs.member(c, i, 5), 37, {36, 37})
+    assert int(g["c5_blowup_%d_step" % i]) == 36
+    for k in ("b_basin", "b_north", "bs_SO"):
+      assert np.isfinite(s[36][k]).all()
+      assert relerr(s[36][k], g["c5_blowup_%d_%s" % (i, k)]) <= 1e-10, (i, k)
+    assert not np.isfinite(s[37]["b_basin"]).all()
+
+
+# ------------------------------- G18 the reference blows up at the sweep values configs.py drops
+def test_range_evidence_reference_blows_up_outside_narrowed_ranges():
+  g = load_golden("range_evidence")
+  # what the reference did
+  assert list(g["c3_how"]) == ["finite", "nonfinite", "nonfinite"] and g["c3_kappa_4k"][0] == 2.5e-4
+  assert list(g["c4_how"]) == ["finite", "nonfinite", "nonfinite"] and g["c4_A_basin"][0] == 4.5e13
+  assert list(g["c5_how"]) == ["finite", "ValueError", "ValueError"]
+  assert list(g["c1_how"]) == ["finite", "nonfinite"] and list(g["c1_dt_days"]) == [30., 60.]
+  # the sweeps stay inside the finite side
+  assert configs.config3(N=4096)["scalars"]["kappa_4k"].max() <= 2.5e-4
+  assert configs.config4(N=8192)["A_basin"].min() >= 4.5e13
+  assert configs.config5(N=64)["scalars"]["db"].max() <= 8e-4
+  assert configs.config1()["dt"] == 30 * 86400.
+  # the oracle goes the same way at the same step
+  for k4, step in zip(g["c3_kappa_4k"], g["c3_blowup_step"]):
+    m = configs.twocol_member(nz=100, kappa_4k=float(k4), kappa_back=5e-5)
+    n = int(step) if step else 2400
+    s = drivers.run_twocol(m, n, {n - 1, n})
+    assert np.isfinite(s[n]["b_north"]).all() == (step == 0), k4
+    if step:
+      assert np.isfinite(s[n - 1]["b_north"]).all() and np.isfinite(s[n - 1]["b_basin"]).all()
+  for A, step in zip(g["c4_A_basin"], g["c4_blowup_step"]):
+    m = configs.twocol_so_member(nz=100, ny=40, A_basin=float(A), kappa=5e-5, tau=0.2, KGM=500.)
+    n = int(step) if step else 2400
+    s = drivers.run_twocol(m, n, {n - 1, n}, so=True)
+    ok = np.isfinite(s[n]["b_north"]).all() and np.isfinite(s[n]["b_basin"]).all()
+    assert ok == (step == 0), A
+  cfg = configs.config1(nz=100)
+  bad = drivers.run_config1(dict(cfg, dt=60 * 86400.), int(g["c1_blowup_step"][1]),
+                            {int(g["c1_blowup_step"][1]) - 1, int(g["c1_blowup_step"][1])})
+  n = int(g["c1_blowup_step"][1])
+  assert np.isfinite(bad[n - 1]["b"]).all() and not np.isfinite(bad[n]["b"]).all()

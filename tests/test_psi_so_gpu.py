@@ -211,3 +211,36 @@ def test_psi_so_callable_surface_profiles(gpu):
   so.update(bs=configs.so_bs_callable(m["y"]))
   so.solve()
   assert so._ny == m["y"].size or so._tau_callable
+
+
+def test_config4_full_length_sweep_vs_reference(gpu):
+  """G17: BASELINE config 4 at its configured length (8192 members x 2400 steps = 100 GM
+  boundary-value solves per member) against the 8 members run through the reference."""
+  g = load_golden("sweep_full")
+  c = dict(configs.config4(N=8192), bvp_refine=8)
+  n = int(g["c4_nsteps"])
+  assert n == c["nsteps"] == 2400
+  ens = gpu.TwoColEnsemble(c)
+  ens.run(n)
+  st = ens.state()
+  idx = g["c4_members"]
+  for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
+    assert relerr(st[k][idx], g["c4_" + k]) <= TOL_BVP_REF, k
+  assert ens.nonfinite_members().size == 0
+
+
+def test_config4_whole_baseline_ensemble_on_one_gpu(gpu):
+  """BASELINE config 4's whole 65536-member ensemble on ONE GPU for its 2400 steps: no
+  member goes non-finite, and two 8192-member shards run on their own (what each GPU of the
+  8-GPU job holds) are bit-identical to their members in the full run."""
+  N = 65536
+  ens = gpu.TwoColEnsemble(dict(configs.config4(N=N), bvp_refine=8))
+  ens.run(2400)
+  assert ens.nonfinite_members().size == 0
+  st = ens.state()
+  for lo in (0, 5 * 8192):
+    part = gpu.TwoColEnsemble(dict(configs.config4(N=N, members=(lo, lo + 8192)), bvp_refine=8))
+    part.run(2400)
+    sp = part.state()
+    for k in ("b_basin", "b_north", "Psi", "Psi_SO", "Psi_iso_b"):
+      assert np.array_equal(sp[k], st[k][lo:lo + 8192]), (lo, k)

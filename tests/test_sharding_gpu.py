@@ -119,7 +119,7 @@ def test_sharded_coupled_driver_gathers_at_diag_cadence(gpu, tmp_path, cfgno, wo
   # the last gather is the state itself
   st = ens.state()
   for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
-    assert np.array_equal(ens.diag.history[-1][1][k], st[k]), k
+    assert np.array_equal(ens.diag.history[-1][1][k], st[k], equal_nan=True), k
 
 
 def test_explicit_stream_equals_default_stream(gpu):

@@ -172,3 +172,66 @@ def test_config5_sweep_members_vs_reference(gpu, fused):
   idx = g["c5_long_members"]
   for k in ("b_basin", "b_north", "bs_SO", "Psi_SO"):
     assert relerr(st[k][idx], g["c5_long_" + k]) <= 1e-9, k
+
+
+def test_config5_full_length_sweep_vs_reference(gpu):
+  """G17: BASELINE config 5 (4096 members, nz=200) over its configured 3600 steps, sampled
+  every 72 steps against the 8 members run through the reference: 1e-10 up to each member's
+  first Psib flip (fixture `c5_clean_until`; four members never flip), bounded after it.
+  The members the run loses are exactly the two the REFERENCE loses (2 and 1268, non-finite
+  from step 37 on; pinned in the fixture and in test_oracle_golden)."""
+  from test_oracle_golden import check_config5_full
+  g = load_golden("sweep_full")
+  c = configs.config5(N=4096)
+  c["rest_mask"] = np.repeat(c["rest_mask"][None], 4096, axis=0)
+  ens = gpu.JN2018Ensemble(c)
+  idx = g["c5_members"]
+  steps = [int(t) for t in g["c5_steps"]]
+  traj = [dict() for _ in idx]
+  done = 0
+  for t in steps:
+    ens.run(t - done)
+    done = t
+    st = ens.state()
+    for j, i in enumerate(idx):
+      traj[j][t] = {k: st[k][i] for k in ("b_basin", "b_north", "bs_SO", "Psi_SO")}
+  for j in range(len(idx)):
+    check_config5_full(traj[j], g, j, int(g["c5_clean_until"][j]))
+  assert list(ens.nonfinite_members()) == list(g["c5_blowup_members"]) == [2, 1268]
+  ens.run(72)  # the bench's 72 warm-up + 3600 steps
+  assert list(ens.nonfinite_members()) == [2, 1268]
+
+
+def test_config5_blowup_members_go_at_the_references_step(gpu):
+  g = load_golden("sweep_full")
+  c = configs.config5(N=4096, members=(0, 1280))
+  ens = gpu.JN2018Ensemble(c)
+  ens.run(36)
+  assert ens.nonfinite_members().size == 0
+  st = ens.state()
+  for i in (2, 1268):
+    for k in ("b_basin", "b_north", "bs_SO"):
+      assert relerr(st[k][i], g["c5_blowup_%d_%s" % (i, k)]) <= 1e-10, (i, k)
+  ens.run(1)
+  assert list(ens.nonfinite_members()) == [2, 1268]
+
+
+def test_config5_whole_baseline_ensemble_on_one_gpu(gpu):
+  """BASELINE config 5's whole 32768-member ensemble on ONE GPU for 3600 steps: a
+  4096-member shard run on its own is bit-identical to its members of the full run, and
+  the members lost are the degenerate-db ones (db within 1e-6 of 6.019e-4, like members 2
+  and 1268 of the 4096-member draw, which the reference itself loses)."""
+  N = 32768
+  ens = gpu.JN2018Ensemble(configs.config5(N=N))
+  ens.run(3600)
+  bad = ens.nonfinite_members()
+  db = configs.config5(N=N)["scalars"]["db"]
+  assert bad.size <= N // 1000
+  assert np.all(np.abs(db[bad] - 6.019e-4) < 1e-6), db[bad]
+  st = ens.state()
+  lo = 3 * 4096
+  part = gpu.JN2018Ensemble(configs.config5(N=N, members=(lo, lo + 4096)))
+  part.run(3600)
+  sp = part.state()
+  for k in ("b_basin", "b_north", "bs_SO", "Psi_SO"):
+    assert np.array_equal(sp[k], st[k][lo:lo + 4096], equal_nan=True), k

@@ -203,3 +203,25 @@ def test_psi_thermwind_callable_profiles(gpu):
     B.update(b1=b1)  # arrays from now on: back to the level-interpolated path
     B.solve()
     assert B._b1_callable is False and B._b2_callable is True
+
+
+def test_config3_full_length_sweep_vs_reference(gpu):
+  """G17: BASELINE config 3 at its configured length (4096 members x 2400 steps); the 8
+  members the reference was run on agree to 1e-12, nothing goes non-finite, and a shard
+  of the ensemble run on its own is bit-identical to the same members of the full run."""
+  g = load_golden("sweep_full")
+  c = configs.config3(N=4096)
+  n = int(g["c3_nsteps"])
+  assert n == c["nsteps"] == 2400
+  ens = gpu.TwoColEnsemble(c)
+  ens.run(n)
+  st = ens.state()
+  idx = g["c3_members"]
+  for k in ("b_basin", "b_north", "Psi"):
+    assert relerr(st[k][idx], g["c3_" + k]) <= 1e-12, k
+  assert ens.nonfinite_members().size == 0
+  part = gpu.TwoColEnsemble(configs.config3(N=4096, members=(1024, 1536)))
+  part.run(n)
+  sp = part.state()
+  for k in sp:
+    assert np.array_equal(sp[k], st[k][1024:1536]), k
