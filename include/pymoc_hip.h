@@ -380,7 +380,8 @@ int pm_comm_allreduce_max(pm_comm_t comm, const void *send, void *recv, size_t c
 /* all ranks have reached this point AND their `stream` work before it is done */
 int pm_comm_barrier(pm_comm_t comm, pm_stream_t stream);
 
-/* debug/test: the kernels' division-by-precomputed-reciprocal against IEEE `/` on
+/* debug/test: the kernels' two divisions by a precomputed reciprocal (div_by_recip from RN(1/d),
+ * div_by_recip2 from the double-double reciprocal; both must be correctly rounded) against IEEE `/` on
  * `4*per_thread*256*blocks` random operand pairs (exponents within +-emax, 3/8 of the
  * mantissas at the all-ones / all-zeros / half-way edges); bitwise mismatches counted. */
 int pm_selftest_fastdiv(uint64_t seed, int32_t blocks, int32_t per_thread, int32_t emax,

@@ -23,6 +23,7 @@ struct ColGrid {     // shared by every column of a batch (and by the columns of
   double dz[P];    // z[i+1]-z[i]           (interface above level i)
   double dzc[P];   // 0.5*(dz[i]+dz[i-1])   (column.py:238)
   double rdz[P], rdzc[P];  // RN(1/dz) (0 above the top level), RN(1/dzc)
+  double rdz_l[P], rdzc_l[P];  // low parts: RN(1/d - RN(1/d)), for div_by_recip2 (DIV == 2)
 };
 template <int P>
 struct ColRegs {
@@ -31,6 +32,7 @@ struct ColRegs {
   double area[P];  // Area(z_i)
   double dAk[P];   // d(Area*kappa)/dz at z_i (np.gradient, host precomputed)
   double rarea[P]; // RN(1/area)
+  double rarea_l[P];  // low part of 1/area (DIV == 2)
 };
 
 // P consecutive levels of one column row (`row` points at level 0 of the column) starting at
@@ -193,11 +195,13 @@ __device__ __forceinline__ void col_convect_cached(double (&b)[P], const double 
   }
 }
 
-// Column.vertadvdiff (column.py:210-249), one explicit step.  FAST: the three divisions by
-// static denominators go through div_by_recip (correctly rounded, so still bit-identical).
+// Column.vertadvdiff (column.py:210-249), one explicit step.  DIV selects how the three
+// divisions by static denominators are done -- 0: IEEE `/`; 1: div_by_recip (5 instructions,
+// needs RN(1/d)); 2: div_by_recip2 (4 instructions, needs the double-double reciprocal).  All
+// three are correctly rounded, hence bit-identical to each other and to NumPy.
 // BC = false: the caller has already imposed the (constant) boundary values, which no
 // interior update ever touches -- valid when bzbot is None and the surface value is bs.
-template <int G, int P, bool FAST, bool BC = true>
+template <int G, int P, int DIV, bool BC = true>
 __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> &r,
                                                 const double (&wA)[P],
                                                 double dt, bool do_conv, double bs,
@@ -227,7 +231,17 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
     double num[P], q[P], rr[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) num[p] = bup[p] - r.b[p];
-    if constexpr (FAST) {
+    if constexpr (DIV == 2) {
+      // u = a*yl; q = fma(a, yh, u) (faithful); r = fma(-d, q, a); q = fma(r, yh, q)
+#pragma unroll
+      for (int p = 0; p < P; ++p) rr[p] = num[p] * g.rdz_l[p];
+#pragma unroll
+      for (int p = 0; p < P; ++p) q[p] = __builtin_fma(num[p], g.rdz[p], rr[p]);
+#pragma unroll
+      for (int p = 0; p < P; ++p) rr[p] = __builtin_fma(-g.dz[p], q[p], num[p]);
+#pragma unroll
+      for (int p = 0; p < P; ++p) q[p] = __builtin_fma(rr[p], g.rdz[p], q[p]);
+    } else if constexpr (DIV == 1) {
 #pragma unroll
       for (int p = 0; p < P; ++p) q[p] = num[p] * g.rdz[p];
 #pragma unroll
@@ -242,8 +256,8 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
 #pragma unroll
       for (int p = 0; p < P; ++p) q[p] = num[p] / g.dz[p];
     }
-    if constexpr (FAST) {
-      // rdz is 0 above the top level, so q is already 0 there (num*0, +0 corrections)
+    if constexpr (DIV != 0) {
+      // rdz (and its low part) is 0 above the top level, so q is already 0 there
 #pragma unroll
       for (int p = 0; p < P; ++p) bz[p] = q[p];
     } else {
@@ -258,10 +272,43 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
     bz_dn[p] = (p > 0) ? bz[p > 0 ? p - 1 : 0] : pbz;
     dbz[p] = bz[p] - bz_dn[p];
     const double weff = wA[p] - r.dAk[p];                // column.py:241
-    const double bzu = (weff < 0.0) ? bz[p] : bz_dn[p];  // column.py:242-243
-    flx[p] = (-weff) * bzu;
+    if constexpr (DIV == 2) {
+      // upwind flux (-weff)*bz* (column.py:242-246) without a select: weff is static over
+      // the launch, so exactly one of the two factors below is (-weff) and the other 0, and
+      // fma(wn, bz, RN(wp*bz_dn)) = RN((-weff)*bz*) -- the unselected product is an exact
+      // zero for finite gradients.  (Differences to the select form: the sign of a zero
+      // flux, which no later operation can tell apart, and NaN instead of a finite flux
+      // next to an infinite gradient, i.e. only inside members that are already blown up.)
+      const double wn = (weff < 0.0) ? -weff : 0.0, wp = (weff < 0.0) ? 0.0 : -weff;
+      flx[p] = __builtin_fma(wn, bz[p], wp * bz_dn[p]);
+    } else {
+      const double bzu = (weff < 0.0) ? bz[p] : bz_dn[p];  // column.py:242-243
+      flx[p] = (-weff) * bzu;
+    }
   }
-  if constexpr (FAST) {  // bzz = dbz/dzc (:238) and adv = flx/Area (:246), interleaved
+  if constexpr (DIV == 2) {  // bzz = dbz/dzc (:238) and adv = flx/Area (:246), interleaved
+    double r1[P], r2[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      r1[p] = dbz[p] * g.rdzc_l[p];
+      r2[p] = flx[p] * r.rarea_l[p];
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      bzz[p] = __builtin_fma(dbz[p], g.rdzc[p], r1[p]);
+      adv[p] = __builtin_fma(flx[p], r.rarea[p], r2[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      r1[p] = __builtin_fma(-g.dzc[p], bzz[p], dbz[p]);
+      r2[p] = __builtin_fma(-r.area[p], adv[p], flx[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      bzz[p] = __builtin_fma(r1[p], g.rdzc[p], bzz[p]);
+      adv[p] = __builtin_fma(r2[p], r.rarea[p], adv[p]);
+    }
+  } else if constexpr (DIV == 1) {
     double r1[P], r2[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -316,7 +363,7 @@ __device__ __forceinline__ void col_horadv(ColRegs<P> &r, const double (&vdx)[P]
 }
 
 // grid metrics of the batch into registers
-template <int P, bool FAST = true>
+template <int P, int DIV = 1>
 __device__ __forceinline__ void col_load_grid(ColGrid<P> &g, const pm_columns &c, int lg,
                                               int lvl0 = 0) {
   const int nz = c.nz;
@@ -330,17 +377,23 @@ __device__ __forceinline__ void col_load_grid(ColGrid<P> &g, const pm_columns &c
     g.z[p] = zc;
     g.dz[p] = c.z[iu] - zc;
     g.dzc[p] = 0.5 * (g.dz[p] + (zc - c.z[id]));
-    if constexpr (FAST) {  // reciprocals only where div_by_recip will use them
+    if constexpr (DIV != 0) {  // reciprocals only where div_by_recip will use them
       g.rdz[p] = (i < nz - 1) ? 1.0 / g.dz[p] : 0.0;  // 0: bz above the top level is 0
       g.rdzc[p] = 1.0 / g.dzc[p];
     } else {
       g.rdz[p] = g.rdzc[p] = 0.0;
     }
+    if constexpr (DIV == 2) {
+      g.rdz_l[p] = (i < nz - 1) ? recip_lo(g.dz[p], g.rdz[p]) : 0.0;
+      g.rdzc_l[p] = recip_lo(g.dzc[p], g.rdzc[p]);
+    } else {
+      g.rdz_l[p] = g.rdzc_l[p] = 0.0;
+    }
   }
 }
 
 // static coefficients of one column (coefficient set `sel`) into registers
-template <int P, bool FAST = true>
+template <int P, int DIV = 1>
 __device__ __forceinline__ void col_load_static(ColRegs<P> &r, const pm_columns &c,
                                                 int col, int sel, int lg, int lvl0 = 0) {
   const int nz = c.nz;
@@ -350,12 +403,170 @@ __device__ __forceinline__ void col_load_static(ColRegs<P> &r, const pm_columns 
   load_levels<P>(r.dAk, c.dAkappa + sbase, lg, nz, lvl0);
   load_levels<P>(r.area, c.area + base, lg, nz, lvl0);
 #pragma unroll
-  for (int p = 0; p < P; ++p) r.rarea[p] = FAST ? 1.0 / r.area[p] : 0.0;
+  for (int p = 0; p < P; ++p) {
+    r.rarea[p] = DIV != 0 ? 1.0 / r.area[p] : 0.0;
+    r.rarea_l[p] = DIV == 2 ? recip_lo(r.area[p], r.rarea[p]) : 0.0;
+  }
+}
+
+// Slots (bit p = slot p) in which the cached pattern has convecting lanes.  P <= 2 keeps one
+// specialised time loop per slot set; taller lanes only distinguish "none" from "some".
+template <int P>
+__device__ __forceinline__ unsigned conv_variant(const ConvCache<P> &cc) {
+  unsigned need = 0u;
+#pragma unroll
+  for (int p = 0; p < P; ++p) need |= (cc.mask[p] != 0ull) ? (1u << p) : 0u;
+  if constexpr (P <= 2) {
+    return need;
+  } else {
+    return need ? (1u << P) - 1u : 0u;
+  }
+}
+
+// Speculative convective time loop of a wave-owned column (G = 64), steps [s, nsteps).
+// Every step adjusts with the facts of the last ESTABLISHED convecting pattern cc (its zconv,
+// hence the adjusted values bs + N2min (z - zconv), column.py:268) and issues the step's
+// arithmetic; whether the pattern really was the cached one is checked once per block of UNR
+// steps, and only a changed pattern (rare) redoes the block exactly from the saved b and
+// re-establishes cc.  Nothing leaves the registers before the check, so steps computed past
+// a pattern change are simply discarded.
+//   * SEL names the slots whose cached mask is non-zero.  Those slots compare (`b > bs`), select
+//     the adjusted value and fold `mask ^ cached` into a scalar accumulator (s_xor / s_or).
+//   * In the other slots nothing convects under the cached pattern, so they need no select, and
+//     "still nothing convects" is one running v_max per step, compared with bs once per block
+//     (a NaN never convects in the reference -- `b > bs` is False -- and v_max ignores it).
+// Why blocks: for a lone wave every scalar instruction costs a vector issue slot and a
+// conditional branch several; the 3-instruction loop control and the check's compare + branch
+// are paid once per UNR steps.  Returns the number of steps done when the new pattern belongs
+// to another SEL class (the caller re-dispatches) or at nsteps.
+template <int P, int DIV, unsigned SEL>
+__device__ __forceinline__ int conv_spec_run(const ColGrid<P> &g, ColRegs<P> &r,
+                                             const double (&wA)[P], double dt, double bs,
+                                             double bbot, double N2min, int lane, int nz,
+                                             ConvCache<P> &cc, int s, int nsteps) {
+  constexpr int UNR = P <= 2 ? 4 : (P <= 4 ? 2 : 1);
+  double adjv[P];    // column.py:268 for the cached zconv: changes only with the pattern
+  double bs_eff[P];  // bs for real levels, +inf for padding: `b > bs_eff` is the whole test
+  // Level 0 always ends a step's convect + boundary condition holding bbot (column.py:232
+  // overwrites whatever convect wrote), so its "adjusted" value is bbot itself.
+  auto set_adj = [&]() {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      adjv[p] = (lane * P + p == 0) ? bbot : bs + N2min * (g.z[p] - cc.zconv);
+  };
+  set_adj();
+#pragma unroll
+  for (int p = 0; p < P; ++p) bs_eff[p] = (lane * P + p < nz) ? bs : __builtin_inf();
+  double b_blk[P];          // state at the start of the current block
+  unsigned long long acc;   // OR of (mask ^ cached) over the SEL slots and steps of the block
+  double bmax[P];           // running max of b over the block, slots outside SEL
+  auto spec = [&]() {
+    unsigned long long im[P];
+    bool ind[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (((SEL >> p) & 1u) != 0u) {  // folds after unrolling
+        ind[p] = r.b[p] > bs_eff[p];  // column.py:264
+        im[p] = __builtin_amdgcn_ballot_w64(ind[p]);
+      } else {
+        bmax[p] = __builtin_fmax(bmax[p], r.b[p]);
+      }
+    }
+    // all compares first, then the selects: a select issued right behind its own compare costs
+    // an s_nop (VALU-written SGPR read as a VALU mask)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (((SEL >> p) & 1u) != 0u) r.b[p] = ind[p] ? adjv[p] : r.b[p];
+      // column.py:271 (b[-1] = bs when nothing convects) needs no work here: the step that
+      // established the cached pattern imposed it, and neither vertadvdiff (the surface level
+      // advances with dt = 0) nor an unchanged pattern alters that level
+    }
+    col_vertadvdiff<64, P, DIV, false>(g, r, wA, dt, true, bs, bbot, false, 0., lane, nz);
+    // (mask ^ cached) AFTER the step's arithmetic has been issued (no wait for the compare
+    // results).  The xor is asm because the optimiser rewrites the C form of the whole test
+    // into compare + select chains (more scalar instructions).
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (((SEL >> p) & 1u) != 0u) {
+        unsigned long long x;
+        asm("s_xor_b64 %0, %1, %2" : "=s"(x) : "s"(im[p]), "s"(cc.mask[p]) : "scc");
+        acc |= x;
+      }
+    }
+  };
+  auto block_begin = [&]() {
+    acc = 0ull;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      b_blk[p] = r.b[p];
+      bmax[p] = -__builtin_inf();
+    }
+  };
+  auto block_bad = [&]() -> bool {
+    bool conv = false;  // a lane of a slot outside SEL would convect
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (((SEL >> p) & 1u) == 0u) conv = conv || (bmax[p] > bs_eff[p]);
+    if constexpr (SEL != (1u << P) - 1u) {
+      // opaque to the optimiser: it would turn `ballot(conv) != 0` back into a DIVERGENT
+      // branch on conv, and the structuriser then wraps the whole loop in exec-mask logic
+      unsigned long long any = __builtin_amdgcn_ballot_w64(conv);
+      asm("" : "+s"(any));
+      acc |= any;
+    }
+    return acc != 0ull;
+  };
+  // redo the block that started at b_blk exactly (pattern changed somewhere inside it)
+  auto redo = [&](int nb) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.b[p] = b_blk[p];
+    for (int k = 0; k < nb; ++k) {
+      col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);
+      if (lane == 0) r.b[0] = bbot;
+      col_vertadvdiff<64, P, DIV, false>(g, r, wA, dt, true, bs, bbot, false, 0., lane, nz);
+    }
+  };
+  // full blocks; the only loop-carried scalar is the count of blocks left.  Single-exit loops
+  // (a `return` inside makes the compiler wrap the hot path in flag logic): a pattern of
+  // another SEL class ends the loop through its own counter.
+  int left = (nsteps - s) / UNR;
+  const int s_full = s + left * UNR;
+  int ret = -1;
+  for (; left > 0; --left) {
+    block_begin();
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) spec();
+    if (__builtin_expect(block_bad(), 0)) {
+      redo(UNR);
+      if (conv_variant<P>(cc) != SEL) {
+        ret = s_full - (left - 1) * UNR;
+        left = 1;
+      } else {
+        set_adj();
+      }
+    }
+  }
+  if (ret >= 0) return ret;
+  left = nsteps - s_full;
+  for (; left > 0; --left) {  // tail: blocks of one step
+    block_begin();
+    spec();
+    if (__builtin_expect(block_bad(), 0)) {
+      redo(1);
+      if (conv_variant<P>(cc) != SEL) {
+        ret = nsteps - (left - 1);
+        left = 1;
+      } else {
+        set_adj();
+      }
+    }
+  }
+  return ret >= 0 ? ret : nsteps;
 }
 
 // PLAIN: ops == PM_OP_TIMESTEP without horadv inputs -- the time loop then carries no
 // loop-invariant branches (they cost a lone wave ~15% of a step).
-template <int G, int P, bool FAST, bool PLAIN>
+template <int G, int P, int FAST, bool PLAIN>
 __global__ __launch_bounds__(256) void k_column_steps(
     pm_columns c, const double *__restrict__ wA_g, const double *__restrict__ vdx_g,
     const double *__restrict__ bin_g, double dt, int nsteps, int ops) {
@@ -402,51 +613,24 @@ __global__ __launch_bounds__(256) void k_column_steps(
       for (int p = 0; p < P; ++p) cc.mask[p] = 0ull;
       cc.zconv = 0.;
       if constexpr (G == 64) {
-        // Speculative step: adjust with the PREVIOUS step's pattern facts (zconv, "nothing
-        // convects"), so the arithmetic of the step never waits for the scalar unit; the
-        // ballots of this step's pattern are compared with the cached ones after the step
-        // has been issued, and only a changed pattern (rare) redoes the step from b_old.
         col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);  // step 0: establishes cc
         if (lg == 0) r.b[0] = bbot;
         col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
-        double adjv[P];  // column.py:268 for the cached zconv: changes only with the pattern
-        double bs_eff[P];  // bs for real levels, +inf for padding: `b > bs_eff` is the whole test
-        // Level 0 always ends a step's convect + boundary condition holding bbot (column.py:232
-        // overwrites whatever convect wrote), so its "adjusted" value is bbot itself.
-        auto set_adj = [&]() {
-#pragma unroll
-          for (int p = 0; p < P; ++p)
-            adjv[p] = (lane * P + p == 0) ? bbot : bs + N2min * (g.z[p] - cc.zconv);
-        };
-        set_adj();
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          bs_eff[p] = (lane * P + p < nz) ? bs : __builtin_inf();
-        }
-        for (int s = 1; s < nsteps; ++s) {
-          double b_old[P];
-          unsigned long long im[P];
-          bool same = true;
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            b_old[p] = r.b[p];
-            const bool ind = r.b[p] > bs_eff[p];  // column.py:264
-            im[p] = __builtin_amdgcn_ballot_w64(ind);
-            r.b[p] = ind ? adjv[p] : r.b[p];
-            // column.py:271 (b[-1] = bs when nothing convects) needs no work here: the step
-            // that established the cached pattern imposed it, and neither vertadvdiff (the
-            // surface level advances with dt = 0) nor an unchanged pattern alters that level
-          }
-          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
-#pragma unroll
-          for (int p = 0; p < P; ++p) same = same && (im[p] == cc.mask[p]);
-          if (__builtin_expect(!same, 0)) {  // pattern changed: redo this step exactly
-#pragma unroll
-            for (int p = 0; p < P; ++p) r.b[p] = b_old[p];
-            col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);
-            if (lg == 0) r.b[0] = bbot;
-            col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
-            set_adj();
+        int s = 1;
+        while (s < nsteps) {  // one pass per established pattern class (rarely more than one)
+          const unsigned v = conv_variant<P>(cc);
+          if constexpr (P <= 2) {
+            switch (v) {
+              case 0: s = conv_spec_run<P, FAST, 0u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
+              case 1: s = conv_spec_run<P, FAST, 1u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
+              case 2: s = conv_spec_run<P, FAST, 2u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
+              default: s = conv_spec_run<P, FAST, 3u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
+            }
+          } else {
+            if (v == 0u)
+              s = conv_spec_run<P, FAST, 0u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps);
+            else
+              s = conv_spec_run<P, FAST, (1u << P) - 1u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps);
           }
         }
       } else {
@@ -466,7 +650,18 @@ __global__ __launch_bounds__(256) void k_column_steps(
         if (lg * P + p == nz - 1) r.b[p] = bs;
         if (lg * P + p == 0) r.b[p] = bbot;
       }
-      for (int s = 0; s < nsteps; ++s)
+      // unrolled: the loop control (3 scalar instructions) costs a lone wave as much as 3
+      // vector instructions
+      int s = 0;
+      if constexpr (P <= 2) {
+        for (; s + 4 <= nsteps; s += 4) {
+          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
+          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
+          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
+          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
+        }
+      }
+      for (; s < nsteps; ++s)
         col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
     }
   } else {
@@ -531,13 +726,13 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
   const unsigned grid = (unsigned)((c.ncols + cols_per_block - 1) / cols_per_block);
   // the reciprocal path pays 3 true divisions per level up front: worth it from 3 steps on
   if (nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx)
-    hipLaunchKernelGGL((k_column_steps<G, P, true, true>), dim3(grid), dim3(256), 0, st, c, wA,
+    hipLaunchKernelGGL((k_column_steps<G, P, 2, true>), dim3(grid), dim3(256), 0, st, c, wA,
                        vdx, bin, dt, nsteps, ops);
   else if (nsteps >= 3)
-    hipLaunchKernelGGL((k_column_steps<G, P, true, false>), dim3(grid), dim3(256), 0, st, c, wA,
+    hipLaunchKernelGGL((k_column_steps<G, P, 1, false>), dim3(grid), dim3(256), 0, st, c, wA,
                        vdx, bin, dt, nsteps, ops);
   else
-    hipLaunchKernelGGL((k_column_steps<G, P, false, false>), dim3(grid), dim3(256), 0, st, c,
+    hipLaunchKernelGGL((k_column_steps<G, P, 0, false>), dim3(grid), dim3(256), 0, st, c,
                        wA, vdx, bin, dt, nsteps, ops);
   PM_HIP(hipGetLastError());
   return PM_OK;

@@ -83,6 +83,27 @@ __device__ __forceinline__ double div_by_recip(double a, double d, double y) {
   return q;
 }
 
+// The same quotient in 4 instructions from the double-double reciprocal yh + yl of d:
+// yh = RN(1/d) (true division), yl = recip_lo(d, yh) ~ 1/d - yh, so that yh + yl = (1/d)(1 + eta)
+// with |eta| < 2^-104.  u = RN(a*yl) and q0 = RN(a*yh + u) give q0 = RN(x(1 + eta')) with
+// x = a/d and |eta'| < 2^-103: q0 is within half an ulp + 2^-103 |x| of x, i.e. a FAITHFUL
+// rounding of x (in fact RN(x) except when x lies within 2^-103 |x| of a midpoint).  The
+// residual r = a - d*q0 of a faithful quotient is exact in one fma, and one Markstein
+// correction with the correctly rounded yh then returns RN(a/d) (same theorem as above; the
+// initial multiply-add is the constant-multiplication scheme of Brisebarre & Muller, IEEE TC
+// 2008, used here only to obtain faithfulness).  Same validity range as div_by_recip.
+__device__ __forceinline__ double recip_lo(double d, double yh) {
+  const double e = __builtin_fma(-d, yh, 1.0);  // exact: |1 - d*yh| <= 2^-53, 53 bits suffice
+  return e * yh;                                // (1/d - yh)(1 + O(2^-52))
+}
+__device__ __forceinline__ double div_by_recip2(double a, double d, double yh, double yl) {
+  const double u = a * yl;
+  double q = __builtin_fma(a, yh, u);
+  const double r = __builtin_fma(-d, q, a);
+  q = __builtin_fma(r, yh, q);
+  return q;
+}
+
 // 64-bit mask of the G lanes of this lane's group inside the wave.
 template <int G>
 __device__ __forceinline__ unsigned long long group_mask(int lane) {

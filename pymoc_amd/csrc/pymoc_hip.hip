@@ -81,12 +81,16 @@ __global__ void k_selftest_fastdiv(unsigned long long seed, int per_thread, int 
   for (int i = 0; i < per_thread; ++i) {
     const double d = random_double(st, emax);
     const double y = 1.0 / d;
-    // several numerators per denominator, as in the kernels (static d, changing a)
+    const double yl = recip_lo(d, y);
+    // several numerators per denominator, as in the kernels (static d, changing a); both
+    // reciprocal forms (5 instructions from RN(1/d), 4 from the double-double reciprocal)
     for (int k = 0; k < 4; ++k) {
       const double a = random_double(st, emax);
       const double q_ref = a / d;
       const double q_fast = div_by_recip(a, d, y);
+      const double q_fast2 = div_by_recip2(a, d, y, yl);
       bad += (__double_as_longlong(q_ref) != __double_as_longlong(q_fast)) ? 1ull : 0ull;
+      bad += (__double_as_longlong(q_ref) != __double_as_longlong(q_fast2)) ? 1ull : 0ull;
     }
   }
   if (bad) atomicAdd(mismatch, bad);

@@ -115,7 +115,8 @@ def test_sharded_coupled_driver_gathers_at_diag_cadence(gpu, tmp_path, cfgno, wo
   assert [s for s, _ in ens.diag.history] == want_steps
   for i, (s, d) in enumerate(ens.diag.history):
     for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
-      assert np.array_equal(got["%s_%d" % (k, i)], d[k]), (s, k)
+      # config 5 (N = 10) contains member 2, which the reference itself loses at step 37
+      assert np.array_equal(got["%s_%d" % (k, i)], d[k], equal_nan=True), (s, k)
   # the last gather is the state itself
   st = ens.state()
   for k in ("b_basin", "b_north", "Psi", "Psi_SO"):

@@ -218,17 +218,24 @@ def test_config5_blowup_members_go_at_the_references_step(gpu):
 
 def test_config5_whole_baseline_ensemble_on_one_gpu(gpu):
   """BASELINE config 5's whole 32768-member ensemble on ONE GPU for 3600 steps: a
-  4096-member shard run on its own is bit-identical to its members of the full run, and
-  the members lost are the degenerate-db ones (db within 1e-6 of 6.019e-4, like members 2
-  and 1268 of the 4096-member draw, which the reference itself loses)."""
+  4096-member shard run on its own is bit-identical to its members of the full run.  A few
+  dozen members (mostly db within 1e-6 of 6.019e-4, like members 2 and 1268 of the
+  4096-member draw, which the reference itself loses at step 37) go non-finite; every one of
+  them also goes non-finite in the oracle, and oracle-finite neighbours stay finite here."""
   N = 32768
-  ens = gpu.JN2018Ensemble(configs.config5(N=N))
+  cfg = configs.config5(N=N)
+  ens = gpu.JN2018Ensemble(cfg)
   ens.run(3600)
   bad = ens.nonfinite_members()
-  db = configs.config5(N=N)["scalars"]["db"]
-  assert bad.size <= N // 1000
-  assert np.all(np.abs(db[bad] - 6.019e-4) < 1e-6), db[bad]
+  assert 0 < bad.size <= N // 500
+  for i in bad:
+    s = drivers.run_jn2018(configs.member(cfg, int(i), 5), 3600, {3600})[3600]
+    assert not np.isfinite(s["b_basin"]).all() or not np.isfinite(s["b_north"]).all(), i
   st = ens.state()
+  for i in (0, 4097, 20000, N - 1):
+    assert i not in bad
+    s = drivers.run_jn2018(configs.member(cfg, i, 5), 3600, {3600})[3600]
+    assert np.isfinite(s["b_basin"]).all() and np.isfinite(st["b_basin"][i]).all(), i
   lo = 3 * 4096
   part = gpu.JN2018Ensemble(configs.config5(N=N, members=(lo, lo + 4096)))
   part.run(3600)
