@@ -23,3 +23,42 @@ for name, fn in (("SO_ML.timestep", lambda: ch.timestep(b_basin=j["b_basin0"], P
   t0 = time.perf_counter()
   for _ in range(200): fn()
   print("%-22s %.1f us per call" % (name, (time.perf_counter() - t0) / 200 * 1e6))
+
+# ---- the reference's two-column user loop (examples/example_twocol.py:85-96) with ONLY the
+# import changed, lazy stepping (default) vs a launch per call; the reference itself runs this
+# loop at 2 880 coupled steps/s at nz = 100 (BASELINE.md, 1 core Xeon 2.1 GHz, measured with
+# the reference imported in the build container)
+from pymoc_amd.modules import column as colmod
+
+
+def twocol_loop(nsteps, nz=100):
+  mm = configs.twocol_member(nz=nz, kappa_4k=2.5e-4)
+  zz = mm["z"]
+  A = pymoc_amd.Psi_Thermwind(z=zz, b1=mm["b_basin0"].copy(), b2=mm["b_north0"].copy())
+  A.solve()
+  [pib, pin] = A.Psibz()
+  ba = pymoc_amd.Column(z=zz, kappa=mm["kappa"].copy(), Area=mm["A_basin"], b=mm["b_basin0"].copy(),
+                        bs=mm["bs"], bbot=mm["bbot"])
+  no = pymoc_amd.Column(z=zz, kappa=mm["kappa"].copy(), Area=mm["A_north"], b=mm["b_north0"].copy(),
+                        bs=mm["bs_north"], bbot=mm["bbot"])
+  t0 = time.perf_counter()
+  for ii in range(nsteps):
+    wAb = pib * 1e6
+    wAN = -pin * 1e6
+    ba.timestep(wA=wAb, dt=mm["dt"])
+    no.timestep(wA=wAN, dt=mm["dt"], do_conv=True)
+    if ii % mm["MOC_up_iters"] == 0:
+      A.update(b1=ba.b, b2=no.b)
+      A.solve()
+      [pib, pin] = A.Psibz()
+  el = time.perf_counter() - t0
+  return nsteps / el, ba.b.copy()
+
+
+for lazy in (True, False):
+  colmod.LAZY = lazy
+  twocol_loop(48)
+  rate, b = twocol_loop(4800)
+  print("example_twocol loop, nz=100, %s: %.0f coupled steps/s (reference 2880/s -> x%.1f)" % (
+      "lazy (default)" if lazy else "a launch per call", rate, rate / 2880.))
+colmod.LAZY = True

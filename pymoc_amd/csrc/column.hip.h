@@ -58,6 +58,31 @@ __device__ __forceinline__ void load_levels(double (&out)[P], const double *__re
   }
 }
 
+// Value held for level j (wave-uniform index) of a wave-owned column: v_readlane of every slot
+// of the owning lane, then a scalar select.  (Selecting the slot per lane first makes the
+// compiler index the register array dynamically, i.e. spill the whole grid to scratch.)
+template <int P>
+__device__ __forceinline__ double level_value(const double (&x)[P], int j) {
+  const int jl = __builtin_amdgcn_readfirstlane(j / P);
+  const int jp = __builtin_amdgcn_readfirstlane(j % P);
+  double out = 0.;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x[p]), jl);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x[p]), jl);
+    const double v = __hiloint2double(hi, lo);
+    out = (p == 0 || jp == p) ? v : out;
+  }
+  return out;
+}
+
+// a lane's value as a wave-uniform scalar (two v_readlane)
+__device__ __forceinline__ double lane_value(double x, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // Convecting-level pattern of the previous step and its zconv: persistent convection keeps
 // the same levels convecting for many steps, so the find-last-bit / readlane chain that
 // locates zconv is skipped while the pattern is unchanged (G = 64 only).
@@ -115,14 +140,7 @@ __device__ __forceinline__ bool col_convect(double (&b)[P], const double (&z)[P]
       if constexpr (G == 64) {
         // the wave owns the whole column: fetch z[jmax] from the owning lane's registers
         // (two v_readlane) instead of a scalar memory load in the middle of the time loop
-        const int jl = __builtin_amdgcn_readfirstlane(jmax / P);
-        const int jp = __builtin_amdgcn_readfirstlane(jmax % P);
-        double zsel = z[0];
-#pragma unroll
-        for (int p = 1; p < P; ++p) zsel = (jp == p) ? z[p] : zsel;
-        const int lo = __builtin_amdgcn_readlane(__double2loint(zsel), jl);
-        const int hi = __builtin_amdgcn_readlane(__double2hiint(zsel), jl);
-        zconv = __hiloint2double(hi, lo);
+        zconv = level_value<P>(z, jmax);
         if (cache != nullptr) {
 #pragma unroll
           for (int p = 0; p < P; ++p) cache->mask[p] = im[p];
@@ -174,14 +192,7 @@ __device__ __forceinline__ void col_convect_cached(double (&b)[P], const double 
         jmax = j > jmax ? j : jmax;
       }
     }
-    const int jl = __builtin_amdgcn_readfirstlane(jmax / P);
-    const int jp = __builtin_amdgcn_readfirstlane(jmax % P);
-    double zsel = z[0];
-#pragma unroll
-    for (int p = 1; p < P; ++p) zsel = (jp == p) ? z[p] : zsel;
-    const int lo = __builtin_amdgcn_readlane(__double2loint(zsel), jl);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(zsel), jl);
-    cc.zconv = __hiloint2double(hi, lo);
+    cc.zconv = level_value<P>(z, jmax);
 #pragma unroll
     for (int p = 0; p < P; ++p) cc.mask[p] = im[p];
     cc.valid = true;
@@ -201,7 +212,8 @@ __device__ __forceinline__ void col_convect_cached(double (&b)[P], const double 
 // three are correctly rounded, hence bit-identical to each other and to NumPy.
 // BC = false: the caller has already imposed the (constant) boundary values, which no
 // interior update ever touches -- valid when bzbot is None and the surface value is bs.
-template <int G, int P, int DIV, bool BC = true>
+// WEFF: `wA` already holds weff = wA - d(A kappa)/dz (callers that keep it across steps).
+template <int G, int P, int DIV, bool BC = true, bool WEFF = false>
 __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> &r,
                                                 const double (&wA)[P],
                                                 double dt, bool do_conv, double bs,
@@ -271,7 +283,7 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
   for (int p = 0; p < P; ++p) {
     bz_dn[p] = (p > 0) ? bz[p > 0 ? p - 1 : 0] : pbz;
     dbz[p] = bz[p] - bz_dn[p];
-    const double weff = wA[p] - r.dAk[p];                // column.py:241
+    const double weff = WEFF ? wA[p] : wA[p] - r.dAk[p];  // column.py:241
     if constexpr (DIV == 2) {
       // upwind flux (-weff)*bz* (column.py:242-246) without a select: weff is static over
       // the launch, so exactly one of the two factors below is (-weff) and the other 0, and

@@ -460,16 +460,30 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
   col_load_grid<P>(g, c, lane);
   col_load_static<P>(rb, c, colb, st.ksel_b, lane);
   col_load_static<P>(rn, c, coln, st.ksel_n, lane);
-  double wAb[P], wAn[P];
+  // weff = wA - d(A kappa)/dz (column.py:241) is static between coefficient-set switches:
+  // kept instead of wA and dAkappa (16 registers less for the two columns, 2P subtractions
+  // less per step) and rebuilt when the BC switch changes a column's set
+  double weff_b[P], weff_n[P];
+  // kappa and weff of coefficient set `sel` (d(A kappa)/dz itself is not kept)
+  auto load_coef = [&](ColRegs<P> &r, double (&weff)[P], int col, int sel) {
+    const size_t sbase = ((size_t)sel * c.ncols + col) * nz;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      const int ic = i < nz ? i : nz - 1;
+      r.kap[p] = c.kappa[sbase + ic];
+      weff[p] = a.wA[(size_t)col * nz + ic] - c.dAkappa[sbase + ic];
+    }
+  };
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int i = lane * P + p;
     const int ic = i < nz ? i : nz - 1;
     rb.b[p] = c.b[(size_t)colb * nz + ic];
     rn.b[p] = c.b[(size_t)coln * nz + ic];
-    wAb[p] = a.wA[(size_t)colb * nz + ic];
-    wAn[p] = a.wA[(size_t)coln * nz + ic];
   }
+  load_coef(rb, weff_b, colb, st.ksel_b);
+  load_coef(rn, weff_n, coln, st.ksel_n);
   const double bs_b = c.bs[colb], bs_n = c.bs[coln];
   const double N2_b = c.N2min[colb], N2_n = c.N2min[coln];
   const double PsiSO1 = a.Psi_SO[bz + 1], Pb1 = a.Psi_res_b[bz + 1], Pn1 = a.Psi_res_n[bz + 1];
@@ -489,9 +503,9 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
   int first_pos;
   bool ml_ok = ml_prepare(w, nz, lane, first_pos);
   ml_tables(w, ny, mc.s);
-  double *M = nullptr;
-  if (ny <= 64) {  // block-uniform
-    M = lds_all + (size_t)(blockDim.x >> 6) * MlLds::doubles(nz, ny);
+  const bool Mprop = ny <= 64;  // block-uniform
+  if (Mprop) {
+    double *M = lds_all + (size_t)(blockDim.x >> 6) * MlLds::doubles(nz, ny);
     if (wave == 0) ml_build_propagator(M, w, ny, mc.s, lane);
     __syncthreads();
   }
@@ -506,19 +520,32 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
   constexpr int L1 = 1 / P, S1 = 1 % P;
   for (int s = 0; s < nsteps; ++s) {
     // ---- bottom-BC switch (run_JansenNadeau_2018.py:233-254)
-    const double bb0 = __shfl(rb.b[0], 0, 64), bb1 = __shfl(rb.b[S1], L1, 64);
-    const double bn0 = __shfl(rn.b[0], 0, 64), bn1 = __shfl(rn.b[S1], L1, 64);
+    // levels 0 and 1 of both columns by v_readlane (scalar registers, no LDS round trip)
+    const double bb0 = lane_value(rb.b[0], 0), bb1 = lane_value(rb.b[S1], L1);
+    const double bn0 = lane_value(rn.b[0], 0), bn1 = lane_value(rn.b[S1], L1);
     const int kb = st.ksel_b, kn = st.ksel_n;
     jn2018_bc(st, PsiSO1, Pb1, Pn1, bb0, bb1, bn0, bn1, w.bs[0]);
-    if (st.ksel_b != kb) col_load_coef<P>(rb, c, colb, st.ksel_b, lane);
-    if (st.ksel_n != kn) col_load_coef<P>(rn, c, coln, st.ksel_n, lane);
+    if (st.ksel_b != kb) load_coef(rb, weff_b, colb, st.ksel_b);
+    if (st.ksel_n != kn) load_coef(rn, weff_n, coln, st.ksel_n);
     // ---- basin.timestep / north.timestep, do_conv=True (:257-258)
     col_convect_cached<P>(rb.b, g.z, bs_b, N2_b, lane, nz, ccb);
-    col_vertadvdiff<64, P, true>(g, rb, wAb, dt, true, bs_b, st.bbot_b, false, 0., lane, nz);
+    col_vertadvdiff<64, P, 1, true, true>(g, rb, weff_b, dt, true, bs_b, st.bbot_b, false, 0.,
+                                          lane, nz);
     col_convect_cached<P>(rn.b, g.z, bs_n, N2_n, lane, nz, ccn);
-    col_vertadvdiff<64, P, true>(g, rn, wAn, dt, true, bs_n, st.bbot_n, false, 0., lane, nz);
+    col_vertadvdiff<64, P, 1, true, true>(g, rn, weff_n, dt, true, bs_n, st.bbot_n, false, 0.,
+                                          lane, nz);
     // ---- channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi) (:261)
     if (ml_ok) {
+      // The workspace pointers are re-derived from an offset the optimiser cannot see through:
+      // otherwise it hoists every LDS address of the mixed-layer step (one per array and
+      // access pattern, ~60 vector registers) out of the time loop and keeps them live across
+      // the column steps, which is what pushed this kernel into scratch spills.
+      int woff = __builtin_amdgcn_readfirstlane(wave) * MlLds::doubles(nz, ny);
+      int moff = (blockDim.x >> 6) * MlLds::doubles(nz, ny);
+      asm volatile("" : "+s"(woff), "+s"(moff));
+      MlLds w;
+      w.carve(lds_all + woff, nz, ny);
+      const double *M = Mprop ? lds_all + moff : nullptr;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int i = lane * P + p;

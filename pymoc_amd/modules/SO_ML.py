@@ -45,6 +45,8 @@ class SO_ML(object):
   def advdiff(self, b_basin, Psi_b, dt):
     import ctypes as C
     from .. import _lib
+    from .column import flush_all
+    flush_all()  # b_basin may alias the array of a Column with queued steps
     ny, nz = np.size(self.y), np.size(b_basin)
     if self._batch is None or self._shape != (ny, nz):
       self._shape = (ny, nz)

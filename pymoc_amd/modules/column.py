@@ -3,16 +3,57 @@
 Same constructor, attributes, method names, argument meaning and error text as
 `pymoc.modules.Column` (src/pymoc/modules/column.py:6-348); the arithmetic of
 convect / vertadvdiff / horadv / timestep runs in the HIP kernel `pm_column_steps`
-on a one-column batch.  `self.b` stays a host NumPy array that is updated IN PLACE
-after every call (the reference's aliasing behaviour, column.py:249), so user loops
-that read `basin.b` or poke `basin.bbot` / `basin.kappa` between steps run unchanged.
-For throughput use `pymoc_amd.ColumnBatch` / the ensemble drivers instead: this
-wrapper pays two small PCIe copies per call.
+on a one-column batch.  `self.b` is the caller's NumPy array, updated IN PLACE (the
+reference's aliasing behaviour, column.py:249), so user loops that read `basin.b` or poke
+`basin.bbot` / `basin.kappa` between steps run unchanged.
+
+Lazy stepping.  A user loop calls `timestep` many times with the same forcing between two
+overturning updates (examples/example_twocol.py:85-96: 24 steps per update).  Such calls are
+QUEUED and executed as one fused launch (one H2D, one `pm_column_steps(nsteps=k)`, one D2H)
+the moment the state is needed:
+  * `col.b` is read (the attribute is a property) or assigned;
+  * the next call differs in anything -- wA values, dt, do_conv, horadv inputs, bs / bbot /
+    bzbot / N2min, a re-assigned (or, for arrays, edited) kappa / Area;
+  * any other pymoc_amd module object computes (`flush_all()`: they may read the array
+    through an alias such as `AMOC.update(b1=basin.b)`);
+  * `vertadvdiff` / `convect` / `horadv` / `solve_equi` are called, the queue is
+    `MAX_QUEUE` steps long, or the object is deleted.
+The queued steps are bit-identical to stepping one by one (the kernel's step-splitting
+invariance, tests/test_column_gpu.py).  The one observable difference to write-through:
+a variable that ALIASES the array and is read directly (not through `col.b` or another
+pymoc_amd object) between steps shows the last flushed state.  `LAZY = False` (or the
+environment variable PYMOC_EAGER=1) restores a launch per call.
+For throughput use `pymoc_amd.ColumnBatch` / the ensemble drivers: state stays in HBM there.
 """
+import os
+import weakref
+
 import numpy as np
 
 from .. import _lib
 from ..utils import make_func, make_array
+
+LAZY = os.environ.get("PYMOC_EAGER", "0") != "1"
+MAX_QUEUE = 1 << 16
+_pending = weakref.WeakSet()  # Columns with queued steps
+
+
+def flush_all():
+  """Execute the queued steps of every Column (called by the other module classes before
+  they read user arrays)."""
+  if _pending:
+    for col in list(_pending):
+      col._flush()
+
+
+def _static_token(fn):
+  """Cheap change detector for a kappa / Area callable: identity for user callables, the
+  VALUES for make_func closures over an array or a float (the reference re-evaluates them
+  every step, so an in-place edit of the aliased array counts)."""
+  src = getattr(fn, "_pm_source", None)
+  if isinstance(src, np.ndarray):
+    return (id(fn), src.tobytes())
+  return (id(fn), src)
 
 
 class Column(object):
@@ -37,11 +78,31 @@ class Column(object):
     self.bbot = bbot
     self.bzbot = bzbot
     self.N2min = N2min
-    self.b = make_array(b, self.z, 'b')
-    self.bz = np.gradient(self.b, z)
     self._arena = None
-    self._kap_cached = None
-    self._area_cached = None
+    self._static_tok = None
+    self._q = None  # queued identical timesteps: [count, wA, dt, do_conv, params]
+    self._b = make_array(b, self.z, 'b')
+    self.bz = np.gradient(self._b, z)
+
+  # ---- state: the caller's array, synchronised on access
+  @property
+  def b(self):
+    if self._q is not None:
+      self._flush()
+    return self._b
+
+  @b.setter
+  def b(self, value):
+    if self._q is not None:
+      self._flush()
+    self._b = value
+
+  def __del__(self):
+    try:
+      if self._q is not None:
+        self._flush()
+    except Exception:
+      pass
 
   # ---- host-side helpers of the reference API (column.py:74-122)
   def Akappa(self, z):
@@ -69,6 +130,7 @@ class Column(object):
     run on the GPU (`pm_column_equi_pass`) inside the same mesh-refinement loop, the
     coefficient functions being sampled wherever that loop asks, as SciPy would."""
     from ..equilibrium import ColumnEquiBatch
+    self._flush()
     self.wA = make_func(wA, self.z, 'w')
     eq = ColumnEquiBatch(
         self.z, 1, lambda i, x: self.Akappa(x), lambda i, x: self.dAkappa_dz(x), self.bs,
@@ -88,6 +150,7 @@ class Column(object):
     nz = self.z.size
     self._nz = nz
     self._host = np.zeros(4 * nz + 5)
+    self._out = np.empty(nz)
     self._arena = DeviceArray((4 * nz + 5,))
     self._zd = DeviceArray.from_host(np.ascontiguousarray(self.z, dtype=np.float64))
     self._kap = DeviceArray((nz,))
@@ -104,50 +167,78 @@ class Column(object):
     self._wA_ptr, self._vdx_ptr, self._bin_ptr = p + nz * 8, p + 2 * nz * 8, p + 3 * nz * 8
     self._C = C
 
-  def _run(self, ops, do_conv, wA=None, dt=1., vdx_in=None, b_in=None):
+  def _sync_statics(self, params):
+    """Evaluate kappa(z), Area(z) and upload them with d(A kappa)/dz when they changed (first
+    call, or the user re-assigned / edited kappa or Area).  Only called with no step queued."""
     if getattr(self, "_arena", None) is None or self._nz != self.z.size:
       self._alloc()
-      self._kap_cached = None
-    z, nz, h = self.z, self._nz, self._host
-    kap = np.asarray(self.kappa(z), dtype=np.float64) + 0 * z
-    area = np.asarray(self.Area(z), dtype=np.float64) + 0 * z
-    if (self._kap_cached is None or not np.array_equal(kap, self._kap_cached) or
-        not np.array_equal(area, self._area_cached)):
-      # static coefficients changed (first call, or the user re-assigned kappa / Area)
+      self._static_tok = None
+    if self._static_tok != params[4:]:
+      z = self.z
+      kap = np.asarray(self.kappa(z), dtype=np.float64) + 0 * z
+      area = np.asarray(self.Area(z), dtype=np.float64) + 0 * z
       self._kap.upload(kap)
       self._area.upload(area)
       self._dAk.upload(np.gradient(area * kap, z))  # dAkappa_dz, column.py:96-122
-      self._kap_cached, self._area_cached = kap.copy(), area.copy()
-    h[0:nz] = self.b
+      self._static_tok = params[4:]
+
+  def _params(self):
+    return (self.bs, self.bbot, self.bzbot, self.N2min, _static_token(self.kappa),
+            _static_token(self.Area))
+
+  def _run(self, ops, do_conv, wA=None, dt=1., vdx_in=None, b_in=None, nsteps=1, params=None):
+    z, nz, h = self.z, self.z.size, None
+    if params is None:  # immediate call: the coefficients as they are now
+      params = self._params()
+      self._sync_statics(params)
+    # (queued calls uploaded theirs when the queue was opened: kappa / Area may have been
+    # re-assigned since)
+    bs, bbot, bzbot, N2min = params[:4]
+    h = self._host
+    h[0:nz] = self._b
     h[nz:2 * nz] = 0. if wA is None else wA
     if vdx_in is not None:
       h[2 * nz:3 * nz] = vdx_in
       h[3 * nz:4 * nz] = b_in
-    h[4 * nz:4 * nz + 4] = (self.bs, self.bbot, 0. if self.bzbot is None else self.bzbot,
-                            self.N2min)
+    h[4 * nz:4 * nz + 4] = (bs, bbot, 0. if bzbot is None else bzbot, N2min)
     flags = (_lib.PM_COL_DO_CONV if do_conv else 0) | (
-        _lib.PM_COL_BZBOT if self.bzbot is not None else 0)
+        _lib.PM_COL_BZBOT if bzbot is not None else 0)
     h[4 * nz + 4:].view(np.int32)[0] = flags
     self._arena.upload(h)
     _lib.check(_lib.lib.pm_column_steps(
         self._C.byref(self._desc), self._wA_ptr,
         self._vdx_ptr if vdx_in is not None else None,
-        self._bin_ptr if vdx_in is not None else None, float(dt), 1, int(ops), 0, None))
-    out = np.empty(nz)
-    _lib.check(_lib.lib.pm_memcpy_d2h(out.ctypes.data, self._arena.ptr, nz * 8, None))
-    self.b[...] = out
+        self._bin_ptr if vdx_in is not None else None, float(dt), int(nsteps), int(ops), 0,
+        None))
+    _lib.check(_lib.lib.pm_memcpy_d2h(self._b.ctypes.data if self._b.flags.c_contiguous and
+                                      self._b.dtype == np.float64 else self._out.ctypes.data,
+                                      self._arena.ptr, nz * 8, None))
+    if not (self._b.flags.c_contiguous and self._b.dtype == np.float64):
+      self._b[...] = self._out
+
+  def _flush(self):
+    """Run the queued timesteps as one fused launch."""
+    q, self._q = self._q, None
+    _pending.discard(self)
+    if q is not None:
+      count, wA, dt, do_conv, params = q
+      # PM_OP_TIMESTEP without horadv inputs = convect + vertadvdiff on the fused fast path
+      self._run(_lib.PM_OP_TIMESTEP, do_conv, wA=wA, dt=dt, nsteps=count, params=params)
 
   # ---- the time-stepping API (column.py:210-348)
   def vertadvdiff(self, wA, dt, do_conv=False):
     wA = make_array(wA, self.z, 'wA')
+    self._flush()
     self._run(_lib.PM_OP_VERTADVDIFF, do_conv, wA=wA, dt=dt)
 
   def convect(self):
+    self._flush()
     self._run(_lib.PM_OP_CONVECT, True)
 
   def horadv(self, vdx_in, b_in, dt):
     vdx_in = make_array(vdx_in, self.z, 'vdx_in')
     b_in = make_array(b_in, self.z, 'b_in')
+    self._flush()
     self._run(_lib.PM_OP_HORADV, False, dt=dt, vdx_in=vdx_in, b_in=b_in)
 
   def timestep(self, wA=0., dt=1., do_conv=False, vdx_in=None, b_in=None):
@@ -155,10 +246,29 @@ class Column(object):
     ops = _lib.PM_OP_CONVECT | _lib.PM_OP_VERTADVDIFF
     if vdx_in is not None and b_in is None:
       # the reference has already convected and stepped when it raises (column.py:336-348)
+      self._flush()
       self._run(ops, do_conv, wA=wA, dt=dt)
       raise TypeError('b_in is needed if vdx_in is provided')
     if vdx_in is not None:
       vdx_in = make_array(vdx_in, self.z, 'vdx_in')
       b_in = make_array(b_in, self.z, 'b_in')
-      ops |= _lib.PM_OP_HORADV
-    self._run(ops, do_conv, wA=wA, dt=dt, vdx_in=vdx_in, b_in=b_in)
+      self._flush()
+      self._run(ops | _lib.PM_OP_HORADV, do_conv, wA=wA, dt=dt, vdx_in=vdx_in, b_in=b_in)
+      return
+    if not LAZY:
+      self._run(ops, do_conv, wA=wA, dt=dt)
+      return
+    # queue: identical consecutive steps fuse into one launch
+    params = self._params()
+    q = self._q
+    if q is not None:
+      if (q[0] < MAX_QUEUE and q[2] == dt and q[3] == do_conv and q[4] == params and
+          (q[1] is wA or np.array_equal(q[1], wA))):
+        q[0] += 1
+        return
+      self._flush()
+    # a new queue: coefficients are evaluated and uploaded now (the device is idle), wA is
+    # snapshotted (the caller may reuse its buffer; the reference reads it during the call)
+    self._sync_statics(params)
+    self._q = [1, np.array(wA, dtype=np.float64, copy=True), dt, bool(do_conv), params]
+    _pending.add(self)

@@ -102,6 +102,8 @@ class Psi_SO(object):
 
   def _run(self, ops, b=None):
     import ctypes as C
+    from .column import flush_all
+    flush_all()  # self.b may alias the array of a Column with queued steps
     if getattr(self, "_arena", None) is None or self._nz != np.size(self.z) or \
         self._ny != np.size(self._kernel_y()):
       self._alloc()
@@ -141,6 +143,8 @@ class Psi_SO(object):
     return self._run(_lib.PM_SO_OP_EKMAN, b=float(b) + 0 * self.z)[5, 0]
 
   def calc_N2(self):
+    from .column import flush_all
+    flush_all()
     dz = self.z[1:] - self.z[:-1]
     N2 = np.zeros(np.size(self.z))
     b = self.b(self.z)

@@ -44,6 +44,8 @@ class Psi_Thermwind(object):
   def _run(self, ops, nb, need_psi):
     import ctypes as C
     from .. import _lib
+    from .column import flush_all
+    flush_all()  # b1 / b2 may alias the array of a Column with queued steps
     nz = np.size(self.z)
     if self._batch is None or self._nb < nb or self._nz != nz:
       self._nb, self._nz = max(int(nb), 1), nz

@@ -16,9 +16,13 @@ def make_func(myst, axis, name):
   if callable(myst):
     return myst
   if isinstance(myst, np.ndarray):
-    return lambda x: np.interp(x, axis, myst)
+    fn = lambda x: np.interp(x, axis, myst)
+    fn._pm_source = myst  # the aliased array (lets callers detect in-place edits cheaply)
+    return fn
   if isinstance(myst, float):
-    return lambda x: myst + 0 * x
+    fn = lambda x: myst + 0 * x
+    fn._pm_source = myst
+    return fn
   raise TypeError(name, _MSG)
 
 

@@ -98,7 +98,74 @@ def test_column_updates_users_array_in_place_and_tracks_attribute_pokes(gpu):
   col.kappa = lambda zz: 5e-5 + 0 * zz       # (run_JansenNadeau_2018.py:233-254)
   ref = O.column_timestep(z, 5e-5 + 0 * z, 8e13 + 0 * z, b, 0 * z, 86400., bs=0.03, bbot=-0.001)
   col.timestep(wA=0., dt=86400.)
-  assert np.array_equal(b, ref)
+  assert np.array_equal(col.b, ref) and col.b is b  # reading col.b runs the queued step
+  assert np.array_equal(b, ref)                     # ... into the caller's array
+
+
+def test_column_lazy_queue_is_bitwise_the_eager_sequence(gpu):
+  """Lazy stepping: identical consecutive timestep() calls are queued and
+  run as ONE fused launch when the state is needed; every way of needing it must give exactly
+  the step-by-step result -- reading .b, a changed wA / dt / do_conv, attribute pokes
+  (run_JansenNadeau_2018.py:233-254 style), an in-place edit of an aliased kappa array,
+  another module object reading through an alias, horadv inputs, and the eager mode."""
+  from pymoc_amd.modules import column as colmod
+  z = np.linspace(-4000., 0., 80)
+  kap0 = 2e-5 + 2e-4 * np.exp(-z / 1000 - 4)
+  kapeff = lambda zz: 6e-5 + 0 * zz  # noqa: E731
+  b0 = 0.03 * np.exp(z / 300.) - 0.001
+  wA1 = 8e13 * 2e-8 * np.sin(np.pi * z / 4000.)
+  wA2 = -0.5 * wA1
+
+  def script(col, tw):
+    """A user loop with every kind of event; returns what the user would have seen."""
+    seen = []
+    for ii in range(40):
+      wA = wA1 if (ii // 7) % 2 == 0 else wA2   # forcing changes every 7 steps
+      if ii == 11:
+        col.bbot = -0.002                      # attribute poke
+      if ii == 17:
+        col.kappa = kapeff                     # coefficient set switch
+      if ii == 23:
+        col.kappa = colmod.make_func(kap0, z, 'kappa')
+      if ii == 29:
+        kap0[:10] *= 1.5                       # in-place edit of the aliased kappa array
+      col.timestep(wA=wA, dt=86400. * 30, do_conv=(ii >= 20))
+      if ii == 5:
+        seen.append(col.b.copy())              # plain read
+      if ii == 14:
+        tw.update(b1=col.b)                    # alias handed to another module object ...
+      if ii in (15, 16, 33):
+        tw.solve()                             # ... which reads it later
+        seen.append(tw.Psi.copy())
+      if ii == 36:
+        col.timestep(wA=wA, dt=86400. * 30, vdx_in=1e3 + 0 * z, b_in=b0)  # horadv: immediate
+    seen.append(col.b.copy())
+    return seen
+
+  def run(lazy):
+    colmod.LAZY = lazy
+    kap0[:] = 2e-5 + 2e-4 * np.exp(-z / 1000 - 4)
+    col = gpu.Column(z=z, kappa=kap0, Area=8e13, b=b0.copy(), bs=0.03, bbot=-0.001)
+    tw = gpu.Psi_Thermwind(z=z, b1=b0.copy(), b2=0.)
+    try:
+      return script(col, tw)
+    finally:
+      colmod.LAZY = True
+
+  eager, lazy = run(False), run(True)
+  assert len(eager) == len(lazy) == 5
+  for a, b in zip(eager, lazy):
+    assert np.array_equal(a, b)
+  # and the queue really fuses: 24 identical steps = 1 launch's worth of work, flushed by .b
+  col = gpu.Column(z=z, kappa=2e-5, Area=8e13, b=b0.copy(), bs=0.03, bbot=-0.001)
+  for _ in range(24):
+    col.timestep(wA=wA1, dt=86400. * 30)
+  assert col._q is not None and col._q[0] == 24
+  ref = b0.copy()
+  for _ in range(24):
+    ref = O.column_timestep(z, 2e-5 + 0 * z, 8e13 + 0 * z, ref, wA1, 86400. * 30, bs=0.03,
+                            bbot=-0.001)
+  assert np.array_equal(col.b, ref) and col._q is None
 
 
 def test_user_loop_like_example_twocol(gpu):
