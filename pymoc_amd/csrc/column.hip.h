@@ -208,8 +208,10 @@ __device__ __forceinline__ void col_convect_cached(double (&b)[P], const double 
 
 // Column.vertadvdiff (column.py:210-249), one explicit step.  DIV selects how the three
 // divisions by static denominators are done -- 0: IEEE `/`; 1: div_by_recip (5 instructions,
-// needs RN(1/d)); 2: div_by_recip2 (4 instructions, needs the double-double reciprocal).  All
-// three are correctly rounded, hence bit-identical to each other and to NumPy.
+// needs RN(1/d)); 2: div_by_recip2 (4 instructions, needs the double-double reciprocal); 3: the
+// two divisions by grid metrics as in 1, the division by Area as in 0 (streaming kernel: the
+// grid is shared by the columns a wave walks through, the areas are not).  All are correctly
+// rounded, hence bit-identical to each other and to NumPy.
 // BC = false: the caller has already imposed the (constant) boundary values, which no
 // interior update ever touches -- valid when bzbot is None and the surface value is bs.
 // WEFF: `wA` already holds weff = wA - d(A kappa)/dz (callers that keep it across steps).
@@ -253,7 +255,7 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
       for (int p = 0; p < P; ++p) rr[p] = __builtin_fma(-g.dz[p], q[p], num[p]);
 #pragma unroll
       for (int p = 0; p < P; ++p) q[p] = __builtin_fma(rr[p], g.rdz[p], q[p]);
-    } else if constexpr (DIV == 1) {
+    } else if constexpr (DIV == 1 || DIV == 3) {
 #pragma unroll
       for (int p = 0; p < P; ++p) q[p] = num[p] * g.rdz[p];
 #pragma unroll
@@ -319,6 +321,20 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
     for (int p = 0; p < P; ++p) {
       bzz[p] = __builtin_fma(r1[p], g.rdzc[p], bzz[p]);
       adv[p] = __builtin_fma(r2[p], r.rarea[p], adv[p]);
+    }
+  } else if constexpr (DIV == 3) {  // grid division by reciprocal, area by IEEE division
+    double r1[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      bzz[p] = dbz[p] * g.rdzc[p];
+      adv[p] = flx[p] / r.area[p];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) r1[p] = __builtin_fma(-g.dzc[p], bzz[p], dbz[p]);
+#pragma unroll
+      for (int p = 0; p < P; ++p) bzz[p] = __builtin_fma(r1[p], g.rdzc[p], bzz[p]);
     }
   } else if constexpr (DIV == 1) {
     double r1[P], r2[P];
@@ -713,6 +729,114 @@ __global__ __launch_bounds__(256) void k_column_steps(
   }
 }
 
+// ------------------------------------------------------------------ streaming kernel
+// One or two steps per launch on a large ensemble (config 1 style loops, Psi refreshed every
+// step): the state cannot stay in registers across launches, every launch streams b, wA and
+// the three coefficient arrays in and b out -- 48 nz B per column-step, HBM is the roof.
+// k_column_steps pays per column what only depends on the shared grid (loading z, forming
+// dz / dzc, three IEEE divisions per level ~ 40 quarter-rate instructions); here a wave walks
+// through `cpw` consecutive columns, forms the grid metrics and their reciprocals ONCE, and
+// has the next column's loads in flight while it computes the current one.
+template <int P>
+struct ColStage {
+  double b[P], wA[P], kap[P], area[P], dAk[P];
+};
+
+template <int P>
+__device__ __forceinline__ void col_stage_load(ColStage<P> &s, const pm_columns &c,
+                                               const double *__restrict__ wA_g, int col,
+                                               int lane) {
+  const int nz = c.nz;
+  const int sel = c.ksel ? c.ksel[col] : 0;
+  const size_t base = (size_t)col * nz;
+  const size_t sbase = ((size_t)sel * c.ncols + col) * nz;
+  load_levels<P>(s.b, c.b + base, lane, nz);
+  load_levels<P>(s.wA, wA_g + base, lane, nz);
+  load_levels<P>(s.kap, c.kappa + sbase, lane, nz);
+  load_levels<P>(s.area, c.area + base, lane, nz);
+  load_levels<P>(s.dAk, c.dAkappa + sbase, lane, nz);
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_column_stream(pm_columns c,
+                                                       const double *__restrict__ wA_g,
+                                                       double dt, int nsteps, int cpw) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+  const int col0 = __builtin_amdgcn_readfirstlane(wave * cpw);
+  const int nz = c.nz;
+  if (col0 >= c.ncols) return;  // wave-uniform
+  const int cend = col0 + cpw < c.ncols ? col0 + cpw : c.ncols;
+
+  ColGrid<P> g;
+  col_load_grid<P, 1>(g, c, lane);
+  ColStage<P> nxt;
+  col_stage_load<P>(nxt, c, wA_g, col0, lane);
+  for (int col = col0; col < cend; ++col) {
+    ColRegs<P> r;
+    double wA[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      r.b[p] = nxt.b[p];
+      wA[p] = nxt.wA[p];
+      r.kap[p] = nxt.kap[p];
+      r.area[p] = nxt.area[p];
+      r.dAk[p] = nxt.dAk[p];
+      r.rarea[p] = r.rarea_l[p] = 0.;
+    }
+    if (col + 1 < cend) col_stage_load<P>(nxt, c, wA_g, col + 1, lane);  // prefetch
+    // the column's scalars: scalar loads (vector loads of a uniform address were tried -- the
+    // flags then sit in vector registers, the branches on them become divergent: 5 % slower)
+    const int flags = c.flags ? c.flags[col] : 0;
+    const bool do_conv = (flags & PM_COL_DO_CONV) != 0;
+    const bool use_bzbot = (flags & PM_COL_BZBOT) != 0 && c.bzbot != nullptr;
+    const double bs = c.bs[col], bbot = c.bbot[col], N2min = c.N2min[col];
+    const double bzbot = use_bzbot ? c.bzbot[col] : 0.0;
+    for (int s = 0; s < nsteps; ++s) {
+      if (do_conv) col_convect<64, P>(r.b, g.z, bs, N2min, lane, lane, nz, c.z);
+      col_vertadvdiff<64, P, 3>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lane, nz);
+    }
+    const size_t base = (size_t)col * nz;
+    bool bad = false;
+    bool stored = false;
+    if constexpr (P == 2) {
+      if ((nz & 1) == 0 && (((unsigned long long)(c.b + base)) & 15ull) == 0ull) {
+        if (lane * 2 < nz) {
+          *reinterpret_cast<double2 *>(c.b + base + lane * 2) = make_double2(r.b[0], r.b[1]);
+          bad = !isfinite(r.b[0]) || !isfinite(r.b[1]);
+        }
+        stored = true;
+      }
+    }
+    if (!stored) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = lane * P + p;
+        if (i < nz) {
+          c.b[base + i] = r.b[p];
+          bad |= !isfinite(r.b[p]);
+        }
+      }
+    }
+    if (c.nonfinite) {
+      const unsigned long long m = __ballot(bad);
+      if (lane == 0) c.nonfinite[col] = (m != 0ull) ? 1 : 0;
+    }
+  }
+}
+
+// columns per wave of the streaming kernel: enough waves to fill the chip several times over
+inline int stream_cols_per_wave(int ncols) {
+  static const int forced = []() {
+    const char *e = getenv("PYMOC_STREAM_CPW");  // experiments (profiles/): 0 = automatic
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0) return forced;
+  const int waves_wanted = 1024 * 8 * 4;  // SIMDs x resident waves x rounds
+  int cpw = ncols / waves_wanted;
+  return cpw < 1 ? 1 : (cpw > 8 ? 8 : cpw);
+}
+
 // ------------------------------------------------------------------ dispatch
 // The <G,P,FAST> instantiations are compiled in three translation units (column_g16.hip,
 // column_g32.hip, column_g64.hip) so that the build parallelises.
@@ -736,6 +860,16 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
                         hipStream_t st) {
   const int cols_per_block = 256 / G;
   const unsigned grid = (unsigned)((c.ncols + cols_per_block - 1) / cols_per_block);
+  if constexpr (G == 64 && P <= 4) {
+    const int cpw = stream_cols_per_wave(c.ncols);
+    if (nsteps < 3 && ops == PM_OP_TIMESTEP && !vdx && cpw >= 2) {
+      const unsigned waves = (unsigned)((c.ncols + cpw - 1) / cpw);
+      hipLaunchKernelGGL((k_column_stream<P>), dim3((waves + 3) / 4), dim3(256), 0, st, c, wA, dt,
+                         nsteps, cpw);
+      PM_HIP(hipGetLastError());
+      return PM_OK;
+    }
+  }
   // the reciprocal path pays 3 true divisions per level up front: worth it from 3 steps on
   if (nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx)
     hipLaunchKernelGGL((k_column_steps<G, P, 2, true>), dim3(grid), dim3(256), 0, st, c, wA,

@@ -191,3 +191,45 @@ def test_config2_members_full_length_vs_reference(gpu):
   assert int(g["c2_nsteps"]) == c["nsteps"] == 1000
   assert np.array_equal(batch.get_b()[g["c2_members"]], g["c2_b"])
   assert batch.get_nonfinite().sum() == 0
+
+
+@pytest.mark.parametrize("nz,nsteps", [(100, 1), (100, 2), (37, 1), (200, 1)])
+def test_streaming_kernel_large_ensemble_bitwise(gpu, nz, nsteps):
+  """One / two steps per launch on an ensemble far beyond the caches take the streaming
+  kernel (k_column_stream: several columns per wave, grid metrics formed once per wave, next
+  column prefetched).  It must be bit-identical to k_column_steps (the same ensemble stepped in
+  chunks small enough to take that kernel) and to the oracle, ragged tail included; flags mix
+  convective adjustment and the bottom-stratification BC."""
+  N = 70001
+  c = configs.config2(N=N, nz=nz)
+  rng = np.random.default_rng(nz)
+  bzbot = np.where(rng.random(N) < 0.3, 1e-7, np.nan)
+  def make(sl):
+    bz = bzbot[sl]
+    batch = gpu.ColumnBatch(c["z"], c["kappa"][sl], c["Area"][sl], c["b0"][sl], bs=c["bs"][sl],
+                            bbot=c["bbot"][sl], N2min=c["N2min"][sl], do_conv=c["do_conv"][sl])
+    # per-column bzbot flag: columns with NaN keep the bbot condition
+    batch.bzbot.upload(np.where(np.isnan(bz), 0., bz))
+    batch._flags_host |= np.where(np.isnan(bz), 0, 2).astype(np.int32)
+    batch.flags.upload(batch._flags_host)
+    return batch
+  big = make(slice(0, N))
+  big.steps(c["wA"], c["dt"], nsteps)
+  b = big.get_b()
+  assert big.get_nonfinite().sum() == 0
+  for lo in (0, 33000, N - 4097):
+    sl = slice(lo, lo + 4097)
+    small = make(sl)
+    small.steps(c["wA"][sl], c["dt"], nsteps)
+    assert np.array_equal(small.get_b(), b[sl]), lo
+  for lo in (0, N - 32):
+    sl = slice(lo, lo + 32)
+    ref = c["b0"][sl].copy()
+    for j in range(32):
+      for _ in range(nsteps):
+        ref[j] = O.column_timestep(c["z"], c["kappa"][sl][j], c["Area"][sl][j], ref[j],
+                                   c["wA"][sl][j], c["dt"], do_conv=bool(c["do_conv"][sl][j]),
+                                   bs=c["bs"][sl][j], bbot=c["bbot"][sl][j],
+                                   bzbot=None if np.isnan(bzbot[sl][j]) else bzbot[sl][j],
+                                   N2min=c["N2min"][sl][j])
+    assert np.array_equal(b[sl], ref), lo
