@@ -265,7 +265,7 @@ def bench_config2(args, env):
       "roofline": {
           "bound": "fp64-valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
           "frac": tf / FP64_PEAK_TFLOPS,
-          "kernel": "k_column_steps<%d,%d,true,true>" % (G, P),
+          "kernel": batch.kernel_name(F, args.lanes),
           "kernel_ms_per_launch": launch_s * 1e3, "launches": launches,
           "flop_model": "14*(nz-2) = %d flop per column-step (SURVEY 8d), x %d columns x %d "
                         "fused steps per launch; the peak counts an FMA as 2 flop, this "
@@ -308,6 +308,7 @@ def bench_config2(args, env):
     msb = time_calls(lambda: big.steps(wAb, dt, 1, lanes_per_col=args.lanes), 20, stream,
                      Event, warm=3)
     real = 48.0 * nz * Cb  # b, wA, kappa, Area, dAkappa in; b out (coefficients streamed)
+    mix = load_json(os.path.join(ROOT, "profiles", "hbm_mix.json"))
     gbps = real / (msb * 1e-3) / 1e9
     out["roofline_hbm_regime"] = {
         "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -316,7 +317,13 @@ def bench_config2(args, env):
         "bytes_model": "48*nz B per column-step: b, wA and the three static coefficient "
                        "arrays in, b out (SURVEY 8d: a build that streams coefficients "
                        "adds 24*nz)",
-        "kernel": "k_column_steps<%d,%d,false,false>" % (G, P), "kernel_ms_per_launch": msb,
+        "kernel": big.kernel_name(1, args.lanes), "kernel_ms_per_launch": msb,
+        "achievable": mix.get("five_reads_one_write_GBps"),
+        "frac_of_achievable": (gbps / mix["five_reads_one_write_GBps"]
+                               if mix.get("five_reads_one_write_GBps") else None),
+        "achievable_source": "plain 5-reads + 1-write streaming kernel of the same footprint "
+                             "(profiles/ubench/stream5.hip), replayed from "
+                             "profiles/hbm_mix.json, not measured in this run",
         "column_timesteps_per_s": Cb / (msb * 1e-3)}
     del big, wAb
   return out

@@ -123,6 +123,11 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
  * per lane; reporting only (bench.py names the kernel instantiation with it).            */
 int pm_column_kernel_shape(int32_t ncols, int32_t nz, int32_t lanes_per_col,
                            int32_t *lanes, int32_t *levels_per_lane);
+/* Name of the kernel instantiation a pm_column_steps call of this shape launches (reporting
+ * only): "k_column_steps<G,P,DIV,PLAIN>" or, for 1-2 steps on a large ensemble,
+ * "k_column_stream<P>".  has_horadv: vdx_in given.                                       */
+int pm_column_kernel_name(int32_t ncols, int32_t nz, int32_t lanes_per_col, int32_t nsteps,
+                          int32_t ops, int32_t has_horadv, char *name, size_t name_len);
 
 /* ------------------------------------------------------------------ Psi_Thermwind
  * Replaces pymoc.modules.Psi_Thermwind for n independent members on one grid z[nz]:

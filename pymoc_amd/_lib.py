@@ -157,6 +157,8 @@ SIGNATURES = {
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "pm_column_kernel_shape": (C.c_int, [C.c_int32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "pm_column_kernel_name": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_char_p, C.c_size_t]),
     "pm_thermwind_update": (C.c_int, [C.POINTER(pm_thermwind), C.c_int32, C.c_void_p]),
     "pm_psi_so_update": (C.c_int, [C.POINTER(pm_psi_so), C.c_int32, C.c_void_p]),
     "pm_so_ml_step": (C.c_int, [C.POINTER(pm_so_ml), C.c_double, C.c_void_p]),

@@ -160,6 +160,13 @@ class ColumnBatch(object):
                                      C.byref(p)))
     return g.value, p.value
 
+  def kernel_name(self, nsteps, lanes_per_col=0, ops=_lib.PM_OP_TIMESTEP, horadv=False):
+    """The kernel instantiation `steps(...)` of this shape launches (reporting only)."""
+    buf = C.create_string_buffer(96)
+    check(lib.pm_column_kernel_name(self.ncols, self.nz, int(lanes_per_col), int(nsteps),
+                                    int(ops), int(bool(horadv)), buf, 96))
+    return buf.value.decode()
+
   def steps(self, wA, dt, nsteps=1, ops=_lib.PM_OP_TIMESTEP, vdx_in=None, b_in=None,
             lanes_per_col=0):
     """nsteps x (convect -> vertadvdiff -> horadv) with wA held fixed, one launch."""

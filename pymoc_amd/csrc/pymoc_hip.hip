@@ -283,6 +283,22 @@ int pm_column_kernel_shape(int32_t ncols, int32_t nz, int32_t lanes_per_col, int
   return PM_OK;
 }
 
+int pm_column_kernel_name(int32_t ncols, int32_t nz, int32_t lanes_per_col, int32_t nsteps,
+                          int32_t ops, int32_t has_horadv, char *name, size_t name_len) {
+  PM_REQUIRE(name && name_len > 0, "NULL output");
+  PM_REQUIRE(nz >= 2 && nz <= 1024, "nz must be in [2,1024]");
+  int G = 0, P = 0;
+  const int rc = column_shape(ncols, nz, lanes_per_col, &G, &P);
+  if (rc != PM_OK) return rc;
+  const bool plain = ops == PM_OP_TIMESTEP && !has_horadv;
+  if (G == 64 && P <= 4 && nsteps < 3 && plain && stream_cols_per_wave(ncols) >= 2)
+    snprintf(name, name_len, "k_column_stream<%d>", P);
+  else  // mirrors launch_column_steps (column.hip.h)
+    snprintf(name, name_len, "k_column_steps<%d,%d,%d,%s>", G, P,
+             nsteps >= 3 ? (plain ? 2 : 1) : 0, (nsteps >= 3 && plain) ? "true" : "false");
+  return PM_OK;
+}
+
 int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_in,
                     const double *b_in, double dt, int32_t nsteps, int32_t ops,
                     int32_t lanes_per_col, pm_stream_t stream) {
