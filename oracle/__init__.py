@@ -228,12 +228,13 @@ def psi_so_solve(z, y, b, bs, tau, **kw):
 # ----------------------------------------------------------------------- SO_ML
 def so_ml_advdiff(y, surflux, rest_mask, b_rest, bs, b_basin, Psi_b, dt, Ks=0., h=50.,
                   L=4e6, v_pist=1.5 / 86400., dense_inverse=False, diffusion=None):
-  """diffusion: 'thomas', 'dense' (the reference's inv(U) @ V @ bs) or 'apply' (propagator
-  U^-1 V built by Thomas, applied by fma accumulation); default: 'dense' when dense_inverse,
-  else what the HIP kernel uses -- 'apply' for ny <= 64, 'thomas' beyond."""
+  """diffusion: 'thomas', 'dense' (the reference's inv(U) @ V @ bs), 'apply' (propagator
+  U^-1 V built by Thomas, applied by fma accumulation) or 'pcr' (parallel cyclic reduction);
+  default: 'dense' when dense_inverse, else what the HIP kernel uses -- 'pcr' for ny <= 64,
+  'thomas' beyond."""
   if diffusion is None:
-    diffusion = 'dense' if dense_inverse else ('apply' if np.size(y) <= 64 else 'thomas')
-  mode = dict(thomas=0, dense=1, apply=2)[diffusion]
+    diffusion = 'dense' if dense_inverse else ('pcr' if np.size(y) <= 64 else 'thomas')
+  mode = dict(thomas=0, dense=1, apply=2, pcr=3)[diffusion]
   y, surflux, rest_mask, b_rest = _a(y), _a(surflux), _a(rest_mask), _a(b_rest)
   bs, b_basin, Psi_b = _a(bs).copy(), _a(b_basin), _a(Psi_b)
   par = SOMLPar(float(Ks), float(h), float(L), float(v_pist))

@@ -637,15 +637,79 @@ static void so_ml_propagator(double *M, int ny, int ld, double s) {
   free(cp);
 }
 
+/* Parallel cyclic reduction of U x = r (U = tridiag(-s/2, 1+s, -s/2) with identity boundary
+ * rows, SO_ML.py:155-165) on 64 rows, rows >= ny being identity rows with r = 0: level l (stride
+ * k = 2^l) eliminates x[i-k] and x[i+k] from row i.  Written row-parallel exactly like the HIP
+ * kernel (one row per lane, every level reads the previous level's values), same expressions,
+ * same fma's: the two are bit-identical.  Multipliers first (they depend only on s, ny): */
+#define PCR_LEVELS 6
+static void so_ml_pcr_tables(int ny, double s, double alpha[PCR_LEVELS][64],
+                             double gamma[PCR_LEVELS][64], double bfin[64]) {
+  double a[64], b[64], c[64], an[64], bn[64], cn[64];
+  for (int i = 0; i < 64; ++i) {
+    const int interior = i >= 1 && i <= ny - 2;
+    a[i] = interior ? -s / 2. : 0.;
+    b[i] = interior ? 1 + s : 1.;
+    c[i] = a[i];
+  }
+  for (int l = 0; l < PCR_LEVELS; ++l) {
+    const int k = 1 << l;
+    for (int i = 0; i < 64; ++i) {
+      const int lo = i >= k ? i - k : i, hi = i + k <= 63 ? i + k : i;
+      const double al = (i >= k) ? -a[i] / b[lo] : 0.;
+      const double ga = (i + k <= 63) ? -c[i] / b[hi] : 0.;
+      alpha[l][i] = al;
+      gamma[l][i] = ga;
+      bn[i] = fma(ga, a[hi], fma(al, c[lo], b[i]));
+      an[i] = al * a[lo];
+      cn[i] = ga * c[hi];
+    }
+    memcpy(a, an, sizeof(a));
+    memcpy(b, bn, sizeof(b));
+    memcpy(c, cn, sizeof(c));
+  }
+  memcpy(bfin, b, sizeof(b));
+}
+
+static void so_ml_pcr_solve(double *bs, int ny, double s) {
+  double alpha[PCR_LEVELS][64], gamma[PCR_LEVELS][64], bfin[64], r[64], rn[64];
+  so_ml_pcr_tables(ny, s, alpha, gamma, bfin);
+  const double sh = s / 2.;
+  for (int i = 0; i < 64; ++i) {
+    if (i >= ny)
+      r[i] = 0.;
+    else if (i >= 1 && i <= ny - 2)
+      r[i] = sh * bs[i - 1] + (1 - s) * bs[i] + sh * bs[i + 1]; /* V bs, interior rows */
+    else
+      r[i] = bs[i];
+  }
+  for (int l = 0; l < PCR_LEVELS; ++l) {
+    const int k = 1 << l;
+    for (int i = 0; i < 64; ++i) {
+      const int lo = i >= k ? i - k : i, hi = i + k <= 63 ? i + k : i;
+      rn[i] = fma(gamma[l][i], r[hi], fma(alpha[l][i], r[lo], r[i]));
+    }
+    memcpy(r, rn, sizeof(r));
+  }
+  for (int i = 0; i < ny; ++i) bs[i] = r[i] / bfin[i];
+}
+
 /* calc_implicit_diffusion, SO_ML.py:136-196.
  *   mode 0: Thomas sweep on U x = V bs;
  *   mode 1: invert U by Gauss-Jordan with partial pivoting and form (Uinv V) bs like the
  *           reference's np.dot(np.dot(np.linalg.inv(U), V), bs);
  *   mode 2: the propagator M = U^-1 V built once (so_ml_propagator), then bs <- M bs with
  *           four interleaved fma accumulators -- what the HIP kernel does for ny <= 64 (U, V
- *           depend only on s = Ks dt / dy^2, i.e. they are static between time steps). */
+ *           depend only on s = Ks dt / dy^2, i.e. they are static between time steps);
+ *           (what the HIP kernel did in round 1)
+ *   mode 3: parallel cyclic reduction (so_ml_pcr_solve) -- what the HIP kernel does for
+ *           ny <= 64 now. */
 static void so_ml_implicit_diffusion(double *bs, int ny, double s, int mode) {
   const int dense = mode == 1;
+  if (mode == 3) {
+    so_ml_pcr_solve(bs, ny, s);
+    return;
+  }
   double *rhs = (double *)malloc(sizeof(double) * ny);
   if (mode == 2) {
     const int ld = ny | 1;

@@ -114,45 +114,65 @@ __device__ __forceinline__ void ml_tables(const MlLds &w, int ny, double s) {
   __builtin_amdgcn_wave_barrier();
 }
 
-// The Crank-Nicolson matrices U, V (:155-190) depend only on s = Ks dt / dy^2: they are the
-// same for every member and every step of a launch.  For ny <= 64 the launch therefore builds
-// the propagator M = U^-1 V ONCE per block (lane j solves U x = V e_j by the Thomas algorithm
-// with the tabulated factors; V e_j has at most three entries) and a step applies it as one
-// dense mat-vec, lane i accumulating row i with four interleaved fma chains -- the
-// reference's own formulation, np.dot(np.dot(inv(U), V), bs) (:196), instead of ~100 serial
-// Thomas steps per member and step.  Rows have an odd leading dimension (conflict-free).
-__device__ __forceinline__ int ml_prop_ld(int ny) { return ny | 1; }
+// The Crank-Nicolson system U x = V bs (:155-196; U = tridiag(-s/2, 1+s, -s/2) with identity
+// boundary rows) depends only on s = Ks dt / dy^2: it is the same for every member and every
+// step of a launch.  For ny <= 64 it is solved by PARALLEL CYCLIC REDUCTION with one row per
+// lane: level l (stride k = 2^l) eliminates x[i-k] and x[i+k] from row i,
+//     alpha = -a[i] / b[i-k],  gamma = -c[i] / b[i+k],
+//     a'[i] = alpha a[i-k],  c'[i] = gamma c[i+k],  b'[i] = fma(gamma, a[i+k], fma(alpha, c[i-k], b[i])),
+//     r'[i] = fma(gamma, r[i+k], fma(alpha, r[i-k], r[i])),
+// and after 6 levels every row is decoupled: x[i] = r[i] / b[i].  The multipliers alpha, gamma
+// and the final diagonal are tabulated once per block (PCR_ROWS x 64 doubles in LDS); a step is
+// then 6 x (two lane shuffles of r + two fma) and one exact division -- no 51 x 51 propagator
+// to stream through the CU's one LDS pipe (the dense form read 52 KB of LDS per wave and step
+// and was bound by that pipe), no serial sweep.  Rows at and beyond ny are identity rows with
+// r = 0; a missing neighbour has a zero multiplier.  The oracle runs the same recurrences in
+// the same order (orc: so_ml_pcr_*), so the two stay bit-identical; against the reference's
+// LAPACK inverse the step agrees to ~1e-15 like before.
+constexpr int PCR_LEVELS = 6;
+constexpr int PCR_ROWS = 2 * PCR_LEVELS + 2;  // alpha[6], gamma[6], b_final, RN(1/b_final)
 
-__device__ __forceinline__ void ml_build_propagator(double *M, const MlLds &w, int ny, double s,
-                                                    int lane) {
-  const int ld = ml_prop_ld(ny), j = lane;
-  if (j >= ny) return;
-  const double ta = -s / 2.;
-  double dp = 0.;
-  for (int i = 0; i < ny; ++i) {
-    double r = 0.;  // V[i][j]: rows 0 and ny-1 identity, interior (s/2, 1-s, s/2)
-    if (i == 0 || i == ny - 1)
-      r = (i == j) ? 1. : 0.;
-    else if (j == i - 1 || j == i + 1)
-      r = s / 2.;
-    else if (j == i)
-      r = 1 - s;
-    dp = (i == 0 || i == ny - 1) ? r : (r - ta * dp) / w.den[i];
-    M[i * ld + j] = dp;
+__device__ __forceinline__ void ml_build_pcr(double *T, int ny, double s, int lane) {
+  const bool interior = lane >= 1 && lane <= ny - 2;
+  double a = interior ? -s / 2. : 0., b = interior ? 1 + s : 1., c = a;
+#pragma unroll
+  for (int l = 0; l < PCR_LEVELS; ++l) {
+    const int k = 1 << l;
+    const double a_lo = __shfl_up(a, k, 64), b_lo = __shfl_up(b, k, 64), c_lo = __shfl_up(c, k, 64);
+    const double a_hi = __shfl_down(a, k, 64), b_hi = __shfl_down(b, k, 64),
+                 c_hi = __shfl_down(c, k, 64);
+    // no neighbour (lane - k < 0 / lane + k > 63): the shuffle returns the lane's own row, whose
+    // b is non-zero, and the coupling a / c towards it is 0 by construction
+    const double alpha = (lane >= k) ? -a / b_lo : 0.;
+    const double gamma = (lane + k <= 63) ? -c / b_hi : 0.;
+    T[l * 64 + lane] = alpha;
+    T[(PCR_LEVELS + l) * 64 + lane] = gamma;
+    const double bn = __builtin_fma(gamma, a_hi, __builtin_fma(alpha, c_lo, b));
+    a = alpha * a_lo;
+    c = gamma * c_hi;
+    b = bn;
   }
-  double x = M[(ny - 1) * ld + j];
-  for (int i = ny - 2; i >= 0; --i) {
-    x = M[i * ld + j] - w.cp[i] * x;
-    M[i * ld + j] = x;
+  T[2 * PCR_LEVELS * 64 + lane] = b;
+  T[(2 * PCR_LEVELS + 1) * 64 + lane] = 1.0 / b;
+}
+
+// x = U^-1 r for the row held by this lane (r = 0 on lanes >= ny)
+__device__ __forceinline__ double ml_pcr_solve(double r, const double *T, int lane) {
+#pragma unroll
+  for (int l = 0; l < PCR_LEVELS; ++l) {
+    const int k = 1 << l;
+    const double r_lo = __shfl_up(r, k, 64), r_hi = __shfl_down(r, k, 64);
+    r = __builtin_fma(T[(PCR_LEVELS + l) * 64 + lane], r_hi,
+                      __builtin_fma(T[l * 64 + lane], r_lo, r));
   }
+  return div_by_recip(r, T[2 * PCR_LEVELS * 64 + lane], T[(2 * PCR_LEVELS + 1) * 64 + lane]);
 }
 
 // One SO_ML.advdiff step on the member staged in `w` (bs, bb, pm valid; tables valid).
-// M: the block's propagator (ny <= 64) or nullptr (ordered Thomas sweep).
+// Any ny (used for ny > 64; shorter profiles take ml_step_reg): ordered Thomas sweep.
 // Returns false where the reference raises IndexError (state untouched).
 __device__ __forceinline__ bool ml_step(const MlLds &w, const MlStatic &c, int nz, int ny,
-                                        int lane, int first_pos, double dt,
-                                        const double *M = nullptr) {
+                                        int lane, int first_pos, double dt) {
   // Psi_s = np.interp(bs, b_basin, Psi_mod) (:232)
   for (int j = lane; j < ny; j += 64) w.ps[j] = interp_sorted(w.bs[j], w.bb, w.pm, nz);
   // argmin(bs): first minimum, a NaN wins (np.argmin)
@@ -220,32 +240,6 @@ __device__ __forceinline__ bool ml_step(const MlLds &w, const MlStatic &c, int n
   }
   // Crank-Nicolson diffusion (:191-196)
   const double s = c.s;
-  if (M != nullptr) {  // bs <- (U^-1 V) bs
-    double xi = 0.;
-    if (lane < ny) {
-      const double *row = M + lane * ml_prop_ld(ny);
-      double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
-      int j = 0;
-      for (; j + 4 <= ny; j += 4) {
-        a0 = __builtin_fma(row[j], w.bs[j], a0);
-        a1 = __builtin_fma(row[j + 1], w.bs[j + 1], a1);
-        a2 = __builtin_fma(row[j + 2], w.bs[j + 2], a2);
-        a3 = __builtin_fma(row[j + 3], w.bs[j + 3], a3);
-      }
-      if (j < ny) a0 = __builtin_fma(row[j], w.bs[j], a0);
-      if (j + 1 < ny) a1 = __builtin_fma(row[j + 1], w.bs[j + 1], a1);
-      if (j + 2 < ny) a2 = __builtin_fma(row[j + 2], w.bs[j + 2], a2);
-      xi = (a0 + a1) + (a2 + a3);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < ny) w.bs[lane] = xi;
-    __builtin_amdgcn_wave_barrier();
-    const double v = upwell ? bsouth : w.bs[1];  // final BC re-set (:274)
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) w.bs[0] = v;
-    __builtin_amdgcn_wave_barrier();
-    return true;
-  }
   // U x = V bs by the Thomas algorithm
   for (int j = lane; j < ny; j += 64) {
     double r;
@@ -304,6 +298,157 @@ __device__ __forceinline__ bool ml_step(const MlLds &w, const MlStatic &c, int n
   return true;
 }
 
+// ---------------------------------------------------------------------------------------
+// Register-resident mixed-layer step for ny <= 64 (the fused JN2018 loop): lane j holds point j
+// of the meridional profile for the whole launch.  Same arithmetic, operation by operation, as
+// ml_step above (which keeps the profile in LDS and serves any ny) -- the two are bit-identical
+// (tests/test_so_ml_gpu.py: fused == stepwise) -- but a step makes 3-4 dependent LDS round
+// trips instead of ~30: neighbours come by DPP wave shifts, the minimum by a DPP butterfly,
+// scalars by v_readlane, and np.interp starts from the interval the point was in one step
+// earlier (verified with the two table reads the interpolation needs anyway; a lane whose
+// point left its interval searches again).  The wave spent half its life waiting on such round
+// trips (profiles/r02/jn2018_steps_sq_counters.txt).
+struct MlReg {
+  double bs;          // bs[lane]
+  double ps;          // Psi_s[lane] of the last step
+  double f1, f2, br;  // surflux/h, rest_mask*v_pist/h, b_rest  (this lane's point)
+  int jh;             // interval of the last interpolation: bb[jh] <= bs < bb[jh+1]
+};
+
+// minimum over the 64 lanes by DPP (quad swaps, half-row and row mirrors, then the four row
+// results by v_readlane); NaNs are ignored (v_min_f64), every lane gets the result
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_min_f64(double x) {
+  x = __builtin_fmin(x, dpp_move<0xB1>(x));   // quad_perm [1,0,3,2]
+  x = __builtin_fmin(x, dpp_move<0x4E>(x));   // quad_perm [2,3,0,1]
+  x = __builtin_fmin(x, dpp_move<0x141>(x));  // row_half_mirror
+  x = __builtin_fmin(x, dpp_move<0x140>(x));  // row_mirror: every lane holds its row's minimum
+  const double r0 = lane_value(x, 0), r1 = lane_value(x, 16), r2 = lane_value(x, 32),
+               r3 = lane_value(x, 48);
+  return __builtin_fmin(__builtin_fmin(r0, r1), __builtin_fmin(r2, r3));
+}
+
+// tail of np.interp once the interval j is known (same expressions as interp_sorted)
+__device__ __forceinline__ double interp_finish(double x, int j, double x0, double x1, double f0,
+                                                double f1) {
+  if (x0 == x) return f0;
+  const double slope = (f1 - f0) / (x1 - x0);
+  double r = slope * (x - x0) + f0;
+  if (r != r) {
+    r = slope * (x - x1) + f1;
+    if (r != r && f0 == f1) r = f0;
+  }
+  return r;
+}
+
+// np.interp(x, xp, fp) with a hint: *jh is tried first and updated
+__device__ __forceinline__ double interp_hinted(double x, const double *xp, const double *fp,
+                                                int n, int &jh, bool active) {
+  const int j0 = jh < n - 1 ? jh : n - 2;
+  const double x0 = xp[j0], x1 = xp[j0 + 1], f0 = fp[j0], f1 = fp[j0 + 1];
+  const bool hit = (x0 <= x) && (x < x1);  // => x is no NaN, inside the table, j0 = upper_bound-1
+  double r = interp_finish(x, j0, x0, x1, f0, f1);
+  if (__builtin_expect(__ballot(active && !hit) != 0ull, 0)) {
+    if (active && !hit) {  // this lane's point left its interval: np.interp from scratch
+      if (x != x) {
+        r = x;
+      } else if (x > xp[n - 1]) {
+        r = fp[n - 1];
+        jh = n - 2;
+      } else if (x < xp[0]) {
+        r = fp[0];
+        jh = 0;
+      } else {
+        int lo = 0, hi = n;  // upper bound: first index with xp > x
+        while (lo < hi) {
+          const int mid = lo + ((hi - lo) >> 1);
+          if (x >= xp[mid])
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        const int j = lo - 1;
+        if (j == n - 1) {
+          r = fp[j];
+          jh = n - 2;
+        } else {
+          r = interp_finish(x, j, xp[j], xp[j + 1], fp[j], fp[j + 1]);
+          jh = j;
+        }
+      }
+    }
+  }
+  return r;
+}
+
+// One SO_ML.advdiff step, ny <= 64, profile in registers.  w.bb / w.pm hold b_basin / Psi_mod,
+// T the block's PCR tables.  Returns false where the reference raises IndexError (state
+// untouched).
+__device__ __forceinline__ bool ml_step_reg(MlReg &q, const MlLds &w, const MlStatic &c, int nz,
+                                            int ny, int lane, int first_pos, double dt,
+                                            const double *T) {
+  const bool act = lane < ny;
+  // Psi_s = np.interp(bs, b_basin, Psi_mod) (:232)
+  double ps = interp_hinted(q.bs, w.bb, w.pm, nz, q.jh, act);
+  // argmin(bs): first minimum, a NaN wins (np.argmin)
+  const double v = act ? q.bs : __builtin_inf();
+  const double mn = wave_min_f64(v);
+  const unsigned long long at_min = __ballot(act && v == mn);
+  const unsigned long long nanm = __ballot(act && v != v);
+  const int mi = at_min ? (int)__ffsll((long long)at_min) - 1 : 0;
+  const int amin = nanm ? (int)__ffsll((long long)nanm) - 1 : mi;
+  if (lane < amin || lane == 0) ps = 0.;  // :240-243
+  const bool upwell = lane_value(ps, 1) > 0;  // set_boundary_conditions, :93-98
+  if (upwell && first_pos >= nz) return false;
+  const double bsouth = upwell ? w.bb[first_pos] : 0.;
+  double bs = q.bs;
+  {
+    const double v0 = upwell ? bsouth : lane_value(bs, 1);
+    if (lane == 0) bs = v0;
+  }
+  // tendencies from surface flux / restoring and upwind advection (:250-259)
+  const double bs_up = from_next_lane(bs), bs_dn = from_prev_lane(bs);
+  const double flux = q.f1 + q.f2 * (q.br - bs);
+  double adv = 0.;
+  if (lane >= 1 && lane <= ny - 2) {
+    double num = 0.;
+    if (ps < 0.)
+      num = -ps * 1e6 * (bs_up - bs);
+    else if (ps > 0.)
+      num = -ps * 1e6 * (bs - bs_dn);
+    if (ps != 0. && ps == ps)
+      adv = div_by_recip(div_by_recip(div_by_recip(num, c.h, c.rh), c.L, c.rL), c.dy, c.rdy);
+  }
+  bs = bs + dt * (flux + adv);  // every tendency uses the old bs
+  if (!upwell) {  // no-flux BC re-set (:264-266)
+    const double v1 = lane_value(bs, 1);
+    if (lane == 0) bs = v1;
+  }
+  // Crank-Nicolson diffusion (:191-196): U x = V bs by parallel cyclic reduction
+  double xi;
+  {
+    const double bl = from_prev_lane(bs), bu = from_next_lane(bs);
+    const double sh = c.s / 2.;
+    double r = bs;  // rows 0 and ny-1 of V are identity rows
+    if (lane >= 1 && lane <= ny - 2) r = sh * bl + (1 - c.s) * bs + sh * bu;
+    if (!act) r = 0.;
+    xi = ml_pcr_solve(r, T, lane);
+  }
+  bs = xi;
+  {
+    const double v2 = upwell ? bsouth : lane_value(bs, 1);  // final BC re-set (:274)
+    if (lane == 0) bs = v2;
+  }
+  q.bs = bs;
+  q.ps = ps;
+  return true;
+}
+
 __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_so_ml_step(pm_so_ml a, double dt) {
   extern __shared__ double lds_all[];
   const int lane = threadIdx.x & 63;
@@ -335,27 +480,52 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_so_ml_step(pm_so_ml
   c.s = a.Ks * dt / (c.dy * c.dy);  // :191
   bool ok = ml_prepare(w, nz, lane, first_pos);
   ml_tables(w, ny, c.s);
-  double *M = nullptr;
-  if (ny <= 64) {  // block-uniform
-    M = lds_all + (size_t)(blockDim.x >> 6) * MlLds::doubles(nz, ny);
-    if (wave == 0) ml_build_propagator(M, w, ny, c.s, lane);
+  const bool small = ny <= 64;  // block-uniform: register-resident step with PCR diffusion
+  const double *T = nullptr;
+  if (small) {
+    double *Tw = lds_all + (size_t)(blockDim.x >> 6) * MlLds::doubles(nz, ny);
+    if (wave == 0) ml_build_pcr(Tw, ny, c.s, lane);
     __syncthreads();
+    T = Tw;
   }
+  MlReg q;
+  q.bs = q.ps = q.f1 = q.f2 = q.br = 0.;
+  q.jh = 0;
   if (ok) {
     ml_flux_tables(w, c, ny, lane);
-    ok = ml_step(w, c, nz, ny, lane, first_pos, dt, M);
+    if (small) {
+      if (lane < ny) {
+        q.bs = w.bs[lane];
+        q.f1 = w.f1[lane];
+        q.f2 = w.f2[lane];
+        q.br = w.br[lane];
+      }
+      ok = ml_step_reg(q, w, c, nz, ny, lane, first_pos, dt, T);
+    } else {
+      ok = ml_step(w, c, nz, ny, lane, first_pos, dt);
+    }
   }
   if (!ok) {  // IndexError in the reference: leave the state untouched
     if (a.status && lane == 0 && m_ok) a.status[m] = 1;
     return;
   }
   bool bad = false;
-  for (int j = lane; j < ny; j += 64) {
-    const double v = w.bs[j];
-    bad |= !isfinite(v);
-    if (m_ok) {
-      a.bs[by + j] = v;
-      if (a.Psi_s) a.Psi_s[by + j] = w.ps[j];
+  if (small) {
+    if (lane < ny) {
+      bad |= !isfinite(q.bs);
+      if (m_ok) {
+        a.bs[by + lane] = q.bs;
+        if (a.Psi_s) a.Psi_s[by + lane] = q.ps;
+      }
+    }
+  } else {
+    for (int j = lane; j < ny; j += 64) {
+      const double v = w.bs[j];
+      bad |= !isfinite(v);
+      if (m_ok) {
+        a.bs[by + j] = v;
+        if (a.Psi_s) a.Psi_s[by + j] = w.ps[j];
+      }
     }
   }
   if (a.status) {
@@ -433,7 +603,8 @@ __device__ __forceinline__ void col_load_coef(ColRegs<P> &r, const pm_columns &c
   }
 }
 
-template <int P>
+// SMALLNY (ny <= 64): the mixed layer lives in registers (ml_step_reg); otherwise in LDS.
+template <int P, bool SMALLNY>
 __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_jn2018 a,
                                                                           double dt,
                                                                           int nsteps) {
@@ -503,14 +674,27 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
   int first_pos;
   bool ml_ok = ml_prepare(w, nz, lane, first_pos);
   ml_tables(w, ny, mc.s);
-  const bool Mprop = ny <= 64;  // block-uniform
-  if (Mprop) {
-    double *M = lds_all + (size_t)(blockDim.x >> 6) * MlLds::doubles(nz, ny);
-    if (wave == 0) ml_build_propagator(M, w, ny, mc.s, lane);
+  if constexpr (SMALLNY) {  // the block's PCR tables of the Crank-Nicolson system
+    double *Tw = lds_all + (size_t)(blockDim.x >> 6) * MlLds::doubles(nz, ny);
+    if (wave == 0) ml_build_pcr(Tw, ny, mc.s, lane);
     __syncthreads();
   }
   if (ml_ok) ml_flux_tables(w, mc, ny, lane);
   int status = ml_ok ? 0 : 1;
+  MlReg q;
+  q.bs = q.ps = q.f1 = q.f2 = q.br = 0.;
+  q.jh = 0;
+  bool ps_valid = false;
+  if constexpr (SMALLNY) {
+    if (lane < ny) {
+      q.bs = w.bs[lane];
+      if (ml_ok) {
+        q.f1 = w.f1[lane];
+        q.f2 = w.f2[lane];
+        q.br = w.br[lane];
+      }
+    }
+  }
 
   ConvCache<P> ccb, ccn;
 #pragma unroll
@@ -524,7 +708,8 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
     const double bb0 = lane_value(rb.b[0], 0), bb1 = lane_value(rb.b[S1], L1);
     const double bn0 = lane_value(rn.b[0], 0), bn1 = lane_value(rn.b[S1], L1);
     const int kb = st.ksel_b, kn = st.ksel_n;
-    jn2018_bc(st, PsiSO1, Pb1, Pn1, bb0, bb1, bn0, bn1, w.bs[0]);
+    const double bs0 = SMALLNY ? lane_value(q.bs, 0) : w.bs[0];
+    jn2018_bc(st, PsiSO1, Pb1, Pn1, bb0, bb1, bn0, bn1, bs0);
     if (st.ksel_b != kb) load_coef(rb, weff_b, colb, st.ksel_b);
     if (st.ksel_n != kn) load_coef(rn, weff_n, coln, st.ksel_n);
     // ---- basin.timestep / north.timestep, do_conv=True (:257-258)
@@ -545,16 +730,23 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
       asm volatile("" : "+s"(woff), "+s"(moff));
       MlLds w;
       w.carve(lds_all + woff, nz, ny);
-      const double *M = Mprop ? lds_all + moff : nullptr;
+      const double *T = lds_all + moff;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int i = lane * P + p;
         if (i < nz) w.bb[i] = rb.b[p];
       }
       __builtin_amdgcn_wave_barrier();
-      if (!ml_step(w, mc, nz, ny, lane, first_pos, dt, M)) {
+      bool stepped;
+      if constexpr (SMALLNY)
+        stepped = ml_step_reg(q, w, mc, nz, ny, lane, first_pos, dt, T);
+      else
+        stepped = ml_step(w, mc, nz, ny, lane, first_pos, dt);
+      if (!stepped) {
         ml_ok = false;  // IndexError in the reference; the mixed layer stops evolving
         status = 1;
+      } else {
+        ps_valid = true;
       }
     }
   }
@@ -571,12 +763,24 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
       bad |= !isfinite(rb.b[p]) || !isfinite(rn.b[p]);
     }
   }
-  for (int j = lane; j < ny; j += 64) {
-    const double v = w.bs[j];
-    bad |= !isfinite(v);
-    if (m_ok) {
-      a.ml.bs[by + j] = v;
-      if (a.ml.Psi_s) a.ml.Psi_s[by + j] = w.ps[j];
+  if constexpr (SMALLNY) {
+    if (lane < ny) {
+      bad |= !isfinite(q.bs);
+      if (m_ok) {
+        a.ml.bs[by + lane] = q.bs;
+        // Psi_s of the last step that ran (like the stand-alone kernel, which leaves the array
+        // untouched where the reference raises)
+        if (a.ml.Psi_s && ps_valid) a.ml.Psi_s[by + lane] = q.ps;
+      }
+    }
+  } else {
+    for (int j = lane; j < ny; j += 64) {
+      const double v = w.bs[j];
+      bad |= !isfinite(v);
+      if (m_ok) {
+        a.ml.bs[by + j] = v;
+        if (a.ml.Psi_s) a.ml.Psi_s[by + j] = w.ps[j];
+      }
     }
   }
   const bool anybad = __ballot(bad) != 0ull;
@@ -596,9 +800,9 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
 inline size_t ml_lds_bytes(int nz, int ny) {
   return (size_t)(2 * nz + 10 * ny) * sizeof(double);
 }
-// the block-shared propagator of the Crank-Nicolson step (ny <= 64)
+// the block-shared PCR tables of the Crank-Nicolson step (ny <= 64)
 inline size_t ml_prop_bytes(int ny) {
-  return ny <= 64 ? (size_t)ny * (size_t)(ny | 1) * sizeof(double) : 0;
+  return ny <= 64 ? (size_t)PCR_ROWS * 64 * sizeof(double) : 0;
 }
 
 inline int launch_so_ml(const pm_so_ml &a, double dt, hipStream_t st) {
@@ -623,11 +827,20 @@ int launch_jn2018_steps(const pm_jn2018 &a, double dt, int nsteps, hipStream_t s
   while (wpb > 1 && per_wave * wpb + prop > 160 * 1024) wpb >>= 1;
   const size_t lds = per_wave * wpb + prop;
   if (lds > 160 * 1024) return fail(PM_EINVAL, "jn2018 needs %zu B of LDS per member", lds);
-  if (lds > 64 * 1024)
-    PM_HIP(hipFuncSetAttribute((const void *)k_jn2018_steps<P>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = (unsigned)((a.n + wpb - 1) / wpb);
-  hipLaunchKernelGGL((k_jn2018_steps<P>), dim3(grid), dim3(64 * wpb), lds, st, a, dt, nsteps);
+  if (a.ml.ny <= 64) {
+    if (lds > 64 * 1024)
+      PM_HIP(hipFuncSetAttribute((const void *)k_jn2018_steps<P, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_jn2018_steps<P, true>), dim3(grid), dim3(64 * wpb), lds, st, a, dt,
+                       nsteps);
+  } else {
+    if (lds > 64 * 1024)
+      PM_HIP(hipFuncSetAttribute((const void *)k_jn2018_steps<P, false>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_jn2018_steps<P, false>), dim3(grid), dim3(64 * wpb), lds, st, a, dt,
+                       nsteps);
+  }
   PM_HIP(hipGetLastError());
   return PM_OK;
 }

@@ -51,52 +51,58 @@ class Equi_Column(object):
     self.sol_init = self.calc_sol_init(sol_init, nz, b_bot)
 
   # ---- non-dimensional profiles, functions of (z*, H)  (equi_column.py:101-185)
+  # One sampler serves the three profile kinds the constructor accepts: `_dimensional(v)` gives
+  # v at physical depths (callable: called; array: np.interp on self.z; number: itself), and
+  # each init_* divides by its own power of H and f.
+  def _dimensional(self, v):
+    if callable(v):
+      return v
+    if isinstance(v, np.ndarray):
+      return lambda zp: np.interp(zp, self.z, v)
+    return lambda zp: v
+
   def init_kappa(self, kappa):
-    scale = lambda H: H**2 * self.f
-    if callable(kappa):
-      return lambda z, H: kappa(z * H) / scale(H)
-    if isinstance(kappa, np.ndarray):
-      return lambda z, H: np.interp(z * H, self.z, kappa) / scale(H)
-    return lambda z, H: kappa / scale(H)
+    dim = self._dimensional(kappa)
+    return lambda z, H: dim(z * H) / (H**2 * self.f)
 
   def init_dkappa_dz(self, kappa, dkappa_dz=None):
-    if callable(kappa) and callable(dkappa_dz):
-      return lambda z, H: dkappa_dz(z * H) / (H * self.f)
+    if not callable(kappa) and not isinstance(kappa, np.ndarray):
+      return lambda z, H: 0  # a constant diffusivity has no gradient
     if callable(kappa):
-      return lambda z, H: np.gradient(kappa(z * H), z * H) / (H * self.f)
-    if isinstance(kappa, np.ndarray):
-      slope = np.gradient(kappa, self.z)
-      return lambda z, H: np.interp(z * H, self.z, slope) / (H * self.f)
-    return lambda z, H: 0
+      if callable(dkappa_dz):
+        slope = dkappa_dz
+      else:  # differentiate the callable on whatever depths it is asked for
+        slope = lambda zp: np.gradient(kappa(zp), zp)
+    else:
+      slope = self._dimensional(np.gradient(kappa, self.z))
+    return lambda z, H: slope(z * H) / (H * self.f)
 
   def init_psi_so(self, psi_so=None):
-    if callable(psi_so):
-      self.psi_so = lambda z, H: psi_so(z * H) / (self.f * H**3)
-    elif isinstance(psi_so, np.ndarray):
-      self.psi_so = lambda z, H: np.interp(z * H, self.z, psi_so) / (self.f * H**3)
-    else:
+    if not (callable(psi_so) or isinstance(psi_so, np.ndarray)):
       self.psi_so = lambda z, H: 0
+      return
+    dim = self._dimensional(psi_so)
+    self.psi_so = lambda z, H: dim(z * H) / (self.f * H**3)
 
   def calc_sol_init(self, sol_init, nz=None, b_bot=None):
     if sol_init is not None:
       return sol_init
-    if nz is None:
-      nz = len(self.z)
-    guess = np.zeros((4, nz))
-    guess[0, :] = 1.0
-    guess[3, :] = -100.0 if b_bot is not None else -self.bz(1500.)
-    return guess
+    n = len(self.z) if nz is None else nz
+    # rows: psi (1 everywhere), psi', psi'' (0), psi''' (-100 with a bottom buoyancy, else
+    # minus the bottom stratification of a 1500 m deep cell)
+    third = -100.0 if b_bot is not None else -self.bz(1500.)
+    return np.vstack([np.ones(n), np.zeros(n), np.zeros(n), np.full(n, third)])
 
   def init_b_boundaries(self, b_s, b_bot=None, B_int=None):
     if b_bot is None and B_int is None:
       raise Exception(
           'You need to specify either b_bot or B_int for bottom boundary condition'
       )
-    self.bs = -b_s / self.f**2
-    if b_bot is not None:
-      self.b_bot = -b_bot / self.f**2
-    else:
+    self.bs = -b_s / self.f**2  # buoyancies are carried as -b / f^2
+    if b_bot is None:
       self.B_int = B_int
+    else:
+      self.b_bot = -b_bot / self.f**2
 
   def alpha(self, z, H):
     return H**2 / (self.A * self.kappa(z, H))
@@ -105,34 +111,26 @@ class Equi_Column(object):
     return self.B_int / (self.f**3 * H**2 * self.A * self.kappa(-1, H))
 
   # ---- what SciPy would call back into (equi_column.py:286-406)
+  def _depth(self, p):
+    """The cell depth: the fixed H, or the free parameter p[0]; the reference's TypeError
+    when neither exists."""
+    if self.H is not None:
+      return self.H
+    if p is None or len(p) == 0:
+      raise TypeError('Must provide a p array if column does not have an H value')
+    return p[0]
+
   def bc(self, ya, yb, p=None):
-    try:
-      depth = p[0] if self.H is None else self.H
-      res = [ya[0], yb[0]]
-      if self.H is None:
-        res.append(ya[1])
-      if getattr(self, 'b_bot', None) is not None:
-        res.append(ya[2] - self.b_bot / depth)
-      else:
-        res.append(ya[3] + self.bz(depth))
-      res.append(yb[2] - self.bs / depth)
-      return np.array(res)
-    except TypeError:
-      raise TypeError(
-          'Must provide a p array if column does not have an H value'
-      )
+    depth = self._depth(p)
+    bottom = (ya[2] - self.b_bot / depth if getattr(self, 'b_bot', None) is not None
+              else ya[3] + self.bz(depth))
+    free_depth = [ya[1]] if self.H is None else []
+    return np.array([ya[0], yb[0]] + free_depth + [bottom, yb[2] - self.bs / depth])
 
   def ode(self, z, y, p=None):
-    if self.H is None and p is not None and len(p) > 0:
-      H = p[0]
-    elif self.H is not None:
-      H = self.H
-    else:
-      raise TypeError(
-          'Must provide a p array if column does not have an H value'
-      )
-    forcing = y[0] - self.psi_so(z, H) - self.A * self.dkappa_dz(z, H) / (H**2)
-    return np.vstack((y[1], y[2], y[3], self.alpha(z, H) * y[3] * forcing))
+    H = self._depth(p)
+    drive = y[0] - self.psi_so(z, H) - self.A * self.dkappa_dz(z, H) / (H**2)
+    return np.vstack((y[1], y[2], y[3], self.alpha(z, H) * y[3] * drive))
 
   # ---- equi_column.py:408-435
   def solve(self):
