@@ -526,6 +526,174 @@ static void gm_bvp(const double *z, int nz, const double *N2, const double *T, d
   free(x);
 }
 
+/* The same boundary-value problem on the mesh scipy.integrate.solve_bvp itself ends on
+ * (scipy 1.15.3, integrate/_bvp.py:solve_bvp with the defaults the reference uses, tol = 1e-3,
+ * max_nodes = 1000; psi_SO.py:319-321).  The ODE is linear, so solve_newton lands on the exact
+ * solution of the collocation system of the current mesh (verified against SciPy: 6e-16), and
+ * the outer loop is: solve -> rms residual of every interval (estimate_rms_residuals: 5-point
+ * Lobatto rule on the C1 cubic spline create_spline(y, f), relative residuals r / (1 + |f|),
+ * the mid-point residual being zero for a converged collocation solution) -> insert one node
+ * where tol < rms < 100 tol, two where rms >= 100 tol (modify_mesh) -> repeat until no node
+ * is added (status 0) or the mesh would exceed max_nodes (status 1, solution of the current
+ * mesh returned, like SciPy).  Original levels stay in the mesh, and the spline interpolates
+ * its nodes, so res.sol(z) is the nodal solution at the original levels.
+ * Returns the number of mesh nodes at the end; *iters = mesh iterations. */
+int orc_gm_bvp_adaptive(const double *z, int nz, const double *N2, const double *T, double c,
+                        double ua, double ub, double tol, int max_nodes, double *out,
+                        int *iters, int *status, double *mesh_out) {
+  const double c2 = c * c;
+  int m = nz, cap = max_nodes + 2 * nz + 8;
+  double *x = (double *)malloc(sizeof(double) * (size_t)cap * 12);
+  double *q = x + cap, *r = x + 2 * cap, *u = x + 3 * cap, *up_ = x + 4 * cap,
+         *lo = x + 5 * cap, *di = x + 6 * cap, *upd = x + 7 * cap, *rh = x + 8 * cap,
+         *rms = x + 9 * cap, *xn = x + 10 * cap, *tq = x + 11 * cap;
+  int *seg = (int *)malloc(sizeof(int) * (size_t)cap * 2), *segn = seg + cap;
+  double *sA = (double *)malloc(sizeof(double) * (size_t)cap * 6);
+  double *sB = sA + cap, *sC = sA + 2 * cap, *dA = sA + 3 * cap, *dB = sA + 4 * cap,
+         *dC = sA + 5 * cap;
+  for (int k = 0; k < nz; ++k) {
+    x[k] = z[k];
+    seg[k] = k < nz - 1 ? k : nz - 2; /* original interval a node belongs to */
+  }
+  int it = 0, st = 0;
+  (void)tq;
+  for (;;) {
+    /* coefficient functions at the nodes: np.interp closures of N2 and T (:309-316) */
+    for (int i = 0; i < m; ++i) {
+      const int k = seg[i];
+      double n2, tv;
+      if (x[i] == z[k]) {
+        n2 = N2[k];
+        tv = T[k];
+      } else if (x[i] == z[k + 1]) {
+        n2 = N2[k + 1];
+        tv = T[k + 1];
+      } else {
+        const double hz = z[k + 1] - z[k];
+        n2 = (N2[k + 1] - N2[k]) / hz * (x[i] - z[k]) + N2[k];
+        tv = (T[k + 1] - T[k]) / hz * (x[i] - z[k]) + T[k];
+      }
+      q[i] = n2 / c2;
+      r[i] = q[i] * tv;
+    }
+    for (int i = 0; i < m - 1; ++i) {
+      const double h = x[i + 1] - x[i], xm = x[i] + 0.5 * h;
+      const int k = seg[i];
+      const double hz = z[k + 1] - z[k];
+      const double n2m = (N2[k + 1] - N2[k]) / hz * (xm - z[k]) + N2[k];
+      const double tm = (T[k + 1] - T[k]) / hz * (xm - z[k]) + T[k];
+      const double qm = n2m / c2, rm = qm * tm;
+      const double al = 1. + h * h * qm / 12.;
+      sA[i] = -(2. / h) * (1. + h * h * q[i] / 12.);
+      sB[i] = (2. / h) * (1. + h * h * q[i + 1] / 12.);
+      sC[i] = -(h / 6.) * (r[i + 1] - r[i]);
+      dA[i] = (h / 6.) * (q[i] + 2. * qm) / al;
+      dB[i] = (h / 6.) * (q[i + 1] + 2. * qm) / al;
+      dC[i] = -(h / 6.) * (r[i] + r[i + 1] + 4. * rm) / al;
+    }
+    di[0] = 1.;
+    upd[0] = 0.;
+    lo[0] = 0.;
+    rh[0] = ua;
+    for (int i = 1; i < m - 1; ++i) {
+      lo[i] = -(sA[i - 1] + dA[i - 1]);
+      di[i] = (sA[i] - dA[i]) - (sB[i - 1] + dB[i - 1]);
+      upd[i] = sB[i] - dB[i];
+      rh[i] = -(sC[i] - dC[i]) + (sC[i - 1] + dC[i - 1]);
+    }
+    di[m - 1] = 1.;
+    lo[m - 1] = 0.;
+    upd[m - 1] = 0.;
+    rh[m - 1] = ub;
+    for (int i = 1; i < m; ++i) {
+      const double w = lo[i] / di[i - 1];
+      di[i] -= w * upd[i - 1];
+      rh[i] -= w * rh[i - 1];
+    }
+    u[m - 1] = rh[m - 1] / di[m - 1];
+    for (int i = m - 2; i >= 0; --i) u[i] = (rh[i] - upd[i] * u[i + 1]) / di[i];
+    /* nodal derivative u' (continuous across nodes by construction) */
+    for (int i = 0; i < m - 1; ++i) {
+      const double S = sA[i] * u[i] + sB[i] * u[i + 1] + sC[i];
+      const double D = dA[i] * u[i] + dB[i] * u[i + 1] + dC[i];
+      up_[i] = 0.5 * (S - D);
+      if (i == m - 2) up_[m - 1] = 0.5 * (S + D);
+    }
+    ++it;
+    /* estimate_rms_residuals */
+    int added = 0;
+    const double s37 = sqrt(3. / 7.);
+    for (int i = 0; i < m - 1; ++i) {
+      const double h = x[i + 1] - x[i];
+      const int k = seg[i];
+      const double hz = z[k + 1] - z[k];
+      /* spline of component 0 (y = u, yp = u') and component 1 (y = u', yp = q u - r) */
+      const double y0a = u[i], y0b = u[i + 1], p0a = up_[i], p0b = up_[i + 1];
+      const double y1a = up_[i], y1b = up_[i + 1];
+      const double p1a = q[i] * u[i] - r[i], p1b = q[i + 1] * u[i + 1] - r[i + 1];
+      const double sl0 = (y0b - y0a) / h, t0 = (p0a + p0b - 2 * sl0) / h;
+      const double sl1 = (y1b - y1a) / h, t1 = (p1a + p1b - 2 * sl1) / h;
+      const double c00 = t0 / h, c01 = (sl0 - p0a) / h - t0, c02 = p0a, c03 = y0a;
+      const double c10 = t1 / h, c11 = (sl1 - p1a) / h - t1, c12 = p1a, c13 = y1a;
+      const double xmid = x[i] + 0.5 * h, s = 0.5 * h * s37;
+      double acc = 0.;
+      for (int side = 0; side < 2; ++side) {
+        const double xe = side == 0 ? xmid + s : xmid - s;
+        const double dx = xe - x[i];
+        const double Y0 = ((c00 * dx + c01) * dx + c02) * dx + c03;
+        const double Y1 = ((c10 * dx + c11) * dx + c12) * dx + c13;
+        const double Y0p = (3 * c00 * dx + 2 * c01) * dx + c02;
+        const double Y1p = (3 * c10 * dx + 2 * c11) * dx + c12;
+        const double n2e = (N2[k + 1] - N2[k]) / hz * (xe - z[k]) + N2[k];
+        const double te = (T[k + 1] - T[k]) / hz * (xe - z[k]) + T[k];
+        const double F0 = Y1, F1 = n2e / c2 * (Y0 - te);
+        const double r0 = (Y0p - F0) / (1 + fabs(F0)), r1 = (Y1p - F1) / (1 + fabs(F1));
+        acc += r0 * r0 + r1 * r1;
+      }
+      rms[i] = sqrt(0.5 * (49. / 90. * acc));
+      if (rms[i] > tol && rms[i] < 100 * tol)
+        added += 1;
+      else if (rms[i] >= 100 * tol)
+        added += 2;
+    }
+    if (m + added > max_nodes) {
+      st = 1;
+      break;
+    }
+    if (added == 0) break;
+    /* modify_mesh */
+    int mn = 0;
+    for (int i = 0; i < m - 1; ++i) {
+      xn[mn] = x[i];
+      segn[mn++] = seg[i];
+      if (rms[i] > tol && rms[i] < 100 * tol) {
+        xn[mn] = 0.5 * (x[i] + x[i + 1]);
+        segn[mn++] = seg[i];
+      } else if (rms[i] >= 100 * tol) {
+        xn[mn] = (2 * x[i] + x[i + 1]) / 3;
+        segn[mn++] = seg[i];
+        xn[mn] = (x[i] + 2 * x[i + 1]) / 3;
+        segn[mn++] = seg[i];
+      }
+    }
+    xn[mn] = x[m - 1];
+    segn[mn++] = seg[m - 1];
+    memcpy(x, xn, sizeof(double) * mn);
+    memcpy(seg, segn, sizeof(int) * mn);
+    m = mn;
+  }
+  /* the original levels are mesh nodes: pick them out in order */
+  for (int i = 0, k = 0; i < m && k < nz; ++i)
+    if (x[i] == z[k]) out[k++] = u[i];
+  if (mesh_out) memcpy(mesh_out, x, sizeof(double) * m);
+  if (iters) *iters = it;
+  if (status) *status = st;
+  free(sA);
+  free(seg);
+  free(x);
+  return m;
+}
+
 /* Psi_SO.solve, psi_SO.py:333-354 = calc_Ekman (:218-243) + calc_GM (:277-331) */
 void orc_psi_so_solve(const double *z, int nz, const double *y, int ny, const double *b,
                       const double *bs, const double *tau, const orc_psi_so_par *par,
@@ -576,8 +744,15 @@ void orc_psi_so_solve(const double *z, int nz, const double *y, int ny, const do
       ua = -(Psi_Ek[0] * 1e6);
       ub = -(Psi_Ek[nz - 1] * 1e6);
     }
-    gm_bvp(z, nz, N2, temp, par->c, ua, ub, par->bvp_refine > 0 ? par->bvp_refine : 16,
-           temp);
+    if (par->bvp_refine < 0) { /* follow solve_bvp's own adaptive mesh */
+      double *sol = (double *)malloc(sizeof(double) * nz);
+      orc_gm_bvp_adaptive(z, nz, N2, temp, par->c, ua, ub, 1e-3, 1000, sol, NULL, NULL, NULL);
+      memcpy(temp, sol, sizeof(double) * nz);
+      free(sol);
+    } else {
+      gm_bvp(z, nz, N2, temp, par->c, ua, ub, par->bvp_refine > 0 ? par->bvp_refine : 16,
+             temp);
+    }
   } else {
     for (int i = 0; i < nz; ++i) {
       double s = z[i] / dy[i];

@@ -173,6 +173,244 @@ __device__ __forceinline__ SoElem so_shfl_down(const SoElem &e, int d) {
   return o;
 }
 
+// ---------------------------------------------------------------------------------------
+// The GM boundary-value problem on the mesh scipy.integrate.solve_bvp itself ends on
+// (a.bvp_refine < 0; the default of the drop-in class and of the config-4 driver).
+// solve_bvp (scipy 1.15.3 _bvp.py, defaults tol = 1e-3, max_nodes = 1000, as psi_SO.py:319-321
+// calls it) loops: Newton on the collocation system of the current mesh -- the ODE is linear,
+// Newton lands on that system's exact solution (checked against SciPy: 6e-16) -- then the rms
+// residual of every interval (estimate_rms_residuals: 5-point Lobatto rule on the C1 cubic
+// spline of (y, f), residuals relative to 1 + |f|; the mid-point term vanishes for a converged
+// collocation solution), then modify_mesh: one node into intervals with tol < rms < 100 tol,
+// two into those with rms >= 100 tol; until nothing is added.  Original levels stay nodes
+// and the spline interpolates its nodes, so res.sol(z) is the nodal solution there.
+// Following the same decisions gives SciPy's mesh (node for node on every golden case) and
+// 1e-14 agreement with the reference where the fixed 8-fold mesh was 1e-6 away.
+//
+// One wave per member, mesh in LDS.  A mesh pass:
+//   A  every lane condenses its chunk of consecutive intervals into one element (so_merge);
+//   B  prefix / suffix scans of the chunk elements across the wave (as in the fixed-mesh path);
+//   C  the first node of every chunk closes with its own row; D  a Thomas sweep inside each
+//      chunk between the two now-known chunk ends (all chunks in parallel);
+//   E  nodal derivatives, F  residuals and insertion counts per interval, G  the new mesh by
+//      a prefix sum of the counts.
+constexpr int SO_MCAP = 384;  // mesh nodes the device follows SciPy to (status bit 3 beyond)
+// LDS doubles per wave: x[2][MCAP], u[MCAP], up[MCAP], z[nz], sN[nz], sT[nz] + shorts
+// seg[2][MCAP], cnt[MCAP]
+__host__ __device__ inline int so_adaptive_doubles(int nz) {
+  return 4 * SO_MCAP + 3 * nz + (3 * SO_MCAP * 2 + 7) / 8;
+}
+
+struct SoMesh {
+  double *x, *xn, *u, *up;
+  const double *z, *N2, *T, *sN, *sT;  // sN, sT: slopes of the np.interp closures per interval
+  short *seg, *segn, *cnt;
+  int nz;
+  double rc2;
+};
+
+// q = N2(x)/c^2 and r = q T(x) at mesh node i / at a point xe of original interval k
+__device__ __forceinline__ void so_coef_at(const SoMesh &w, int k, double xe, double &q,
+                                           double &r) {
+  // slope * (x - xp[k]) + fp[k] (np.interp); at the upper level the node value itself
+  const double zk = w.z[k];
+  const bool top = xe == w.z[k + 1];
+  const double dx = xe - zk;
+  const double n2 = top ? w.N2[k + 1] : w.sN[k] * dx + w.N2[k];
+  const double tv = top ? w.T[k + 1] : w.sT[k] * dx + w.T[k];
+  q = n2 * w.rc2;
+  r = q * tv;
+}
+
+__device__ __forceinline__ SoElem so_mesh_element(const SoMesh &w, int i) {
+  const int k = w.seg[i];
+  const double x0 = w.x[i], x1 = w.x[i + 1], h = x1 - x0;
+  double q0, r0, q1, r1, qm, rm;
+  so_coef_at(w, k, x0, q0, r0);
+  so_coef_at(w, k, x1, q1, r1);
+  so_coef_at(w, k, x0 + 0.5 * h, qm, rm);
+  return so_sub_element(h, q0, q1, qm, r0, r1, rm);
+}
+
+// returns the final number of mesh nodes; u at the original levels is left in w.u[pos] and
+// copied to out_lds[k] (an LDS array of nz doubles) by the caller-visible tail below
+__device__ __forceinline__ int so_gm_adaptive(SoMesh w, double ua, double ub, int lane,
+                                              double *out_lds, int *status_bits) {
+  const double tol = 1e-3;
+  const int max_nodes = 1000;
+  const int nz = w.nz;
+  int m = nz;
+  for (int i = lane; i < nz; i += 64) {
+    w.x[i] = w.z[i];
+    w.seg[i] = (short)(i < nz - 1 ? i : nz - 2);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int pass = 0; pass < 64; ++pass) {  // SciPy has no cap while nodes are added; 64 >> any run
+    const int ne = m - 1;
+    const int C = (ne + 63) >> 6;
+    const int f = lane * C;                       // first interval / first node of the chunk
+    const int l = f + C < ne ? f + C : ne;        // one past the last interval; node l ends it
+    const bool has = f < ne;
+    // ---- A: chunk element
+    SoElem TL = SoElem{0., 0., 0., 0., 0., 0.};
+    for (int i = f; i < l; ++i) {
+      const SoElem e = so_mesh_element(w, i);
+      TL = (i == f) ? e : so_merge(TL, e);
+    }
+    // ---- B: scans (lanes with an empty chunk carry nothing; non-empty lanes are a prefix)
+    SoElem PL = TL, PR = TL;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const SoElem o = so_shfl_up(PL, d);
+      if (lane >= d && has) PL = so_merge(o, PL);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const SoElem o = so_shfl_down(PR, d);
+      const bool ohas = __shfl_down(has ? 1 : 0, d, 64) != 0 && lane + d < 64;
+      if (has && ohas) PR = so_merge(PR, o);
+    }
+    const SoElem XL = so_shfl_up(PL, 1);  // everything left of this chunk (lane > 0)
+    // PR: everything from this chunk's first node to the end of the mesh
+    // ---- C: first node of the chunk
+    double uf = ua;
+    if (has && lane > 0) uf = (XL.c2 + PR.c1 - XL.a21 * ua - PR.a12 * ub) / (XL.a22 + PR.a11);
+    double ul = __shfl_down(uf, 1, 64);
+    const bool next_has = __shfl_down(has ? 1 : 0, 1, 64) != 0 && lane < 63;
+    if (!next_has) ul = ub;
+    // ---- D: Thomas inside the chunk, Dirichlet ends uf (node f) and ul (node l)
+    if (has) {
+      w.u[f] = uf;
+      if (l == ne) w.u[ne] = ub;
+      // rows j = f+1 .. l-1:  E[j-1].a21 u[j-1] + (E[j-1].a22 + E[j].a11) u[j] + E[j].a12 u[j+1]
+      //                       = E[j-1].c2 + E[j].c1
+      SoElem ep = so_mesh_element(w, f);
+      double dprev = 1., rprev = uf, uprev_c = 0.;  // row of node f: u[f] = uf
+      for (int j = f + 1; j < l; ++j) {
+        const SoElem ej = so_mesh_element(w, j);
+        const double lo = ep.a21, di = ep.a22 + ej.a11, upc = ej.a12, rh = ep.c2 + ej.c1;
+        const double wq = lo / dprev;
+        const double d2 = di - wq * uprev_c, r2 = rh - wq * rprev;
+        w.up[j] = d2;   // scratch: modified diagonal
+        w.u[j] = r2;    // scratch: modified right-hand side
+        w.xn[j] = upc;  // scratch: super-diagonal
+        dprev = d2;
+        rprev = r2;
+        uprev_c = upc;
+        ep = ej;
+      }
+      double unext = ul;
+      for (int j = l - 1; j > f; --j) {
+        const double v = (w.u[j] - w.xn[j] * unext) / w.up[j];
+        w.u[j] = v;
+        unext = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- E: nodal derivative u' (continuous across nodes by construction)
+    for (int i = lane; i < ne; i += 64) {
+      const SoElem e = so_mesh_element(w, i);
+      w.up[i] = 0.5 * (e.a11 * w.u[i] + e.a12 * w.u[i + 1] - e.c1);
+      if (i == ne - 1) w.up[ne] = 0.5 * (-e.a21 * w.u[i] - e.a22 * w.u[i + 1] + e.c2);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- F: rms residual and insertion count of every interval (estimate_rms_residuals)
+    int added = 0;
+    const double s37 = 0.6546536707079771;  // sqrt(3/7)
+    for (int i = lane; i < ne; i += 64) {
+      const int k = w.seg[i];
+      const double x0 = w.x[i], h = w.x[i + 1] - x0;
+      double q0, r0, q1, r1;
+      so_coef_at(w, k, x0, q0, r0);
+      so_coef_at(w, k, w.x[i + 1], q1, r1);
+      const double y0a = w.u[i], y0b = w.u[i + 1], p0a = w.up[i], p0b = w.up[i + 1];
+      const double p1a = q0 * y0a - r0, p1b = q1 * y0b - r1;
+      const double rh = so_rcp(h);
+      const double sl0 = (y0b - y0a) * rh, t0 = (p0a + p0b - 2 * sl0) * rh;
+      const double sl1 = (p0b - p0a) * rh, t1 = (p1a + p1b - 2 * sl1) * rh;
+      const double c00 = t0 * rh, c01 = (sl0 - p0a) * rh - t0;
+      const double c10 = t1 * rh, c11 = (sl1 - p1a) * rh - t1;
+      const double xmid = x0 + 0.5 * h, s = 0.5 * h * s37;
+      double acc = 0.;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const double xe = side == 0 ? xmid + s : xmid - s;
+        const double dx = xe - x0;
+        const double Y0 = ((c00 * dx + c01) * dx + p0a) * dx + y0a;
+        const double Y1 = ((c10 * dx + c11) * dx + p1a) * dx + p0a;
+        const double Y0p = (3 * c00 * dx + 2 * c01) * dx + p0a;
+        const double Y1p = (3 * c10 * dx + 2 * c11) * dx + p1a;
+        double qe, re;
+        so_coef_at(w, k, xe, qe, re);
+        const double F0 = Y1, F1 = qe * Y0 - re;
+        const double e0 = (Y0p - F0) * so_rcp(1 + __builtin_fabs(F0));
+        const double e1 = (Y1p - F1) * so_rcp(1 + __builtin_fabs(F1));
+        acc += e0 * e0 + e1 * e1;
+      }
+      // rms = sqrt(0.5 * 49/90 * acc) compared through its square
+      const double ms = 0.5 * (49. / 90. * acc);
+      const int c = (ms >= (100 * tol) * (100 * tol)) ? 2 : ((ms > tol * tol) ? 1 : 0);
+      w.cnt[i] = (short)c;
+      added += c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) added += __shfl_xor(added, o, 64);
+    if (added == 0) break;                       // status 0
+    if (m + added > max_nodes || m + added > SO_MCAP) {
+      if (m + added <= max_nodes) *status_bits |= 8;  // SciPy would refine further than we follow
+      break;                                     // (beyond max_nodes SciPy stops here too)
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- G: new mesh (modify_mesh); chunk-wise prefix sum of 1 + cnt
+    int mine = 0;
+    for (int i = f; i < l; ++i) mine += 1 + w.cnt[i];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    int pos = incl - mine;
+    for (int i = f; i < l; ++i) {
+      const double xa = w.x[i], xb = w.x[i + 1];
+      const short sg = w.seg[i];
+      const int c = w.cnt[i];
+      w.xn[pos] = xa;
+      w.segn[pos++] = sg;
+      if (c == 1) {
+        w.xn[pos] = 0.5 * (xa + xb);
+        w.segn[pos++] = sg;
+      } else if (c == 2) {
+        w.xn[pos] = (2 * xa + xb) / 3;
+        w.segn[pos++] = sg;
+        w.xn[pos] = (xa + 2 * xb) / 3;
+        w.segn[pos++] = sg;
+      }
+    }
+    if (lane == 0) {
+      w.xn[m + added - 1] = w.x[m - 1];
+      w.segn[m + added - 1] = w.seg[m - 1];
+    }
+    m += added;
+    double *tx = w.x;
+    w.x = w.xn;
+    w.xn = tx;
+    short *ts = w.seg;
+    w.seg = w.segn;
+    w.segn = ts;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __builtin_amdgcn_wave_barrier();
+  // the original levels are mesh nodes: node i starts original interval seg[i] iff x[i] == z[seg[i]]
+  for (int i = lane; i < m; i += 64) {
+    const int k = w.seg[i];
+    if (w.x[i] == w.z[k]) out_lds[k] = w.u[i];
+    if (i == m - 1) out_lds[nz - 1] = w.u[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  return m;
+}
+
 template <int P>
 __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a, int ops) {
   extern __shared__ double lds_all[];
@@ -184,7 +422,8 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   const int nz = a.nz, ny = a.ny;
   const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
   const bool tau_arr = (a.flags & PM_SO_TAU_ARRAY) != 0;
-  const int per_wave = 3 * ny + (has_c ? 2 * nz : 0);
+  const bool adaptive = has_c && a.bvp_refine < 0;
+  const int per_wave = 3 * ny + (has_c ? 2 * nz : 0) + (adaptive ? so_adaptive_doubles(nz) + nz : 0);
   double *s_y = lds_all + (size_t)wave * per_wave;
   double *s_bs = s_y + ny;
   double *s_tau = s_bs + ny;
@@ -346,6 +585,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
       topt[p] = 1 - (mm * mm) / (a.Htapertop * a.Htapertop);
     }
   }
+  int gm_status = 0;
   if (!has_c) {
 #pragma unroll
     for (int p = 0; p < P; ++p)
@@ -371,6 +611,53 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
       }
     }
     __builtin_amdgcn_wave_barrier();
+    // boundary values (bc_GM, :270-275); Psi_Ek[0], Psi_Ek[-1] live in lanes 0 / last
+    double ua0 = 0., ub0 = 0.;
+    if (a.flags & PM_SO_BVP_WITH_EK) {
+      const int last_lane = (nz - 1) / P, last_p = (nz - 1) % P;
+      double v_last = 0.;
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (p == last_p) v_last = ek_sv[p];
+      ua0 = -(__shfl(ek_sv[0], 0, 64) * 1e6);
+      ub0 = -(__shfl(v_last, last_lane, 64) * 1e6);
+    }
+    if (adaptive) {  // wave-uniform: follow solve_bvp's own mesh
+      double *wk = s_w + 2 * nz;
+      SoMesh ms;
+      ms.x = wk;
+      ms.xn = wk + SO_MCAP;
+      ms.u = wk + 2 * SO_MCAP;
+      ms.up = wk + 3 * SO_MCAP;
+      double *zl = wk + 4 * SO_MCAP;
+      double *sNl = zl + nz, *sTl = zl + 2 * nz;
+      ms.seg = reinterpret_cast<short *>(zl + 3 * nz);
+      ms.segn = ms.seg + SO_MCAP;
+      ms.cnt = ms.segn + SO_MCAP;
+      double *outl = wk + so_adaptive_doubles(nz);
+      for (int i = lane; i < nz; i += 64) {
+        zl[i] = a.z[i];
+        if (i < nz - 1) {
+          const double hz = a.z[i + 1] - a.z[i];
+          sNl[i] = (s_N2[i + 1] - s_N2[i]) / hz;
+          sTl[i] = (s_T[i + 1] - s_T[i]) / hz;
+        }
+      }
+      ms.z = zl;
+      ms.sN = sNl;
+      ms.sT = sTl;
+      ms.N2 = s_N2;
+      ms.T = s_T;
+      ms.nz = nz;
+      ms.rc2 = 1. / c2;
+      __builtin_amdgcn_wave_barrier();
+      so_gm_adaptive(ms, ua0, ub0, lane, outl, &gm_status);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = lane * P + p;
+        temp[p] = outl[i < nz ? i : nz - 1];
+      }
+    } else {
     const int R = a.bvp_refine > 0 ? a.bvp_refine : 8;
     const double rc2 = 1. / c2, rR = 1. / (double)R;
     SoElem Ecl[P];  // condensed element of interval [z_k, z_k+1], k = lane*P + p
@@ -408,17 +695,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
         Ecl[p] = E;
       }
     }
-    // boundary values (bc_GM, :270-275); Psi_Ek[0], Psi_Ek[-1] live in lanes 0 / last
-    double ua = 0., ub = 0.;
-    if (a.flags & PM_SO_BVP_WITH_EK) {
-      const int last_lane = (nz - 1) / P, last_p = (nz - 1) % P;
-      double v_last = 0.;
-#pragma unroll
-      for (int p = 0; p < P; ++p)
-        if (p == last_p) v_last = ek_sv[p];
-      ua = -(__shfl(ek_sv[0], 0, 64) * 1e6);
-      ub = -(__shfl(v_last, last_lane, 64) * 1e6);
-    }
+    const double ua = ua0, ub = ub0;
     // The nz-1 condensed elements are combined by the associative node-elimination `so_merge`:
     // a prefix scan gives L_k (the element of [z_0, z_k+1]) and a suffix scan R_k (the element
     // of [z_k, z_nz-1]); interior node i then closes with its own row
@@ -476,6 +753,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
         u = (Lm.c2 + Rm.c1 - Lm.a21 * ua - Rm.a12 * ub) / (Lm.a22 + Rm.a11);
       temp[p] = u;
     }
+    }  // fixed R-fold mesh
   }
   // limit Psi_GM to -Psi_Ek on isopycnals that do not outcrop (:329-330)
   const double width = yN - y0g;
@@ -498,14 +776,16 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   if (a.status) {
     const bool anybad = __ballot(bad) != 0ull;
     if (lane == 0 && m_ok)
-      a.status[m] = (ambiguous ? 1 : 0) | (anybad ? 2 : 0) | (bs_nan ? 4 : 0);
+      a.status[m] = (ambiguous ? 1 : 0) | (anybad ? 2 : 0) | (bs_nan ? 4 : 0) | gm_status;
   }
 }
 
 template <int P>
 int launch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
   const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
-  const size_t per_wave = (size_t)(3 * a.ny + (has_c ? 2 * a.nz : 0)) * sizeof(double);
+  const bool adaptive = has_c && a.bvp_refine < 0;
+  const size_t per_wave = (size_t)(3 * a.ny + (has_c ? 2 * a.nz : 0) +
+                                   (adaptive ? so_adaptive_doubles(a.nz) + a.nz : 0)) * sizeof(double);
   int wpb = SO_WAVES_PER_BLOCK;
   while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
   const size_t lds = per_wave * wpb;

@@ -346,40 +346,40 @@ __device__ __forceinline__ double interp_finish(double x, int j, double x0, doub
   return r;
 }
 
-// np.interp(x, xp, fp) with a hint: *jh is tried first and updated
+// np.interp(x, xp, fp) with a hint: interval jh is tried first and updated.  The common cases --
+// x still in its interval, x beyond either end of the table, x NaN -- are settled with selects
+// from one batch of independent LDS reads; only a lane whose point moved to another interval
+// searches (rare, divergent).
 __device__ __forceinline__ double interp_hinted(double x, const double *xp, const double *fp,
                                                 int n, int &jh, bool active) {
   const int j0 = jh < n - 1 ? jh : n - 2;
   const double x0 = xp[j0], x1 = xp[j0 + 1], f0 = fp[j0], f1 = fp[j0 + 1];
+  const double xlo = xp[0], xhi = xp[n - 1], flo = fp[0], fhi = fp[n - 1];
   const bool hit = (x0 <= x) && (x < x1);  // => x is no NaN, inside the table, j0 = upper_bound-1
   double r = interp_finish(x, j0, x0, x1, f0, f1);
-  if (__builtin_expect(__ballot(active && !hit) != 0ull, 0)) {
-    if (active && !hit) {  // this lane's point left its interval: np.interp from scratch
-      if (x != x) {
-        r = x;
-      } else if (x > xp[n - 1]) {
-        r = fp[n - 1];
+  // np.interp's order of tests: NaN, above the table, below the table
+  const bool isnan_x = x != x, above = x > xhi, below = x < xlo;
+  if (below) r = flo;
+  if (above) r = fhi;
+  if (isnan_x) r = x;
+  const bool search = active && !hit && !isnan_x && !above && !below;
+  if (__builtin_expect(__ballot(search) != 0ull, 0)) {
+    if (search) {  // this lane's point left its interval: upper-bound search from scratch
+      int lo = 0, hi = n;  // first index with xp > x
+      while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (x >= xp[mid])
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      const int j = lo - 1;
+      if (j == n - 1) {
+        r = fp[j];
         jh = n - 2;
-      } else if (x < xp[0]) {
-        r = fp[0];
-        jh = 0;
       } else {
-        int lo = 0, hi = n;  // upper bound: first index with xp > x
-        while (lo < hi) {
-          const int mid = lo + ((hi - lo) >> 1);
-          if (x >= xp[mid])
-            lo = mid + 1;
-          else
-            hi = mid;
-        }
-        const int j = lo - 1;
-        if (j == n - 1) {
-          r = fp[j];
-          jh = n - 2;
-        } else {
-          r = interp_finish(x, j, xp[j], xp[j + 1], fp[j], fp[j + 1]);
-          jh = j;
-        }
+        r = interp_finish(x, j, xp[j], xp[j + 1], fp[j], fp[j + 1]);
+        jh = j;
       }
     }
   }
