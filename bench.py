@@ -58,7 +58,7 @@ WORKLOAD = {
        "physics, nz=%d, MOC_up_iters=24, nb=500; pymoc_amd.configs.config3, seed 20241)",
     4: "BASELINE configs[3]: %d two-column + SO-channel members per GPU (example_twocol_plusSO.py"
        " physics, nz=%d, ny=40, c=0.1 GM boundary-value smoother; pymoc_amd.configs.config4, "
-       "seed 20242)",
+       "seed 20242; GM boundary-value problem on scipy solve_bvp's adaptive mesh)",
     5: "BASELINE configs[4]: %d run_JansenNadeau_2018.py members per GPU (nz=%d, dt=10 d, "
        "ny=51, MOC_up_iters=36, nb=500; pymoc_amd.configs.config5, seed 20243)",
 }
@@ -123,7 +123,7 @@ def _cpu_worker(job):
     if config == 3:
       D.run_twocol(m, nsteps, ())
     elif config == 4:
-      D.run_twocol(m, nsteps, (), so=True, bvp_refine=8)
+      D.run_twocol(m, nsteps, (), so=True)
     else:
       D.run_jn2018(m, nsteps, ())
     units += size["ncol"] * nsteps
@@ -153,7 +153,7 @@ def cpu_baseline(config, nz, budget_1=6.0, budget_all=6.0, max_workers=0):
   rate_all = sum(u / t for u, t in res)
   what = {2: "the config-2 column batch stepped 250 steps at a time",
           3: "full 2400-step example_twocol member runs",
-          4: "full 2400-step example_twocol_plusSO member runs (GM BVP on the 8-fold mesh)",
+          4: "full 2400-step example_twocol_plusSO member runs (GM BVP on solve_bvp's adaptive mesh)",
           5: "full 3600-step run_JansenNadeau_2018 member runs"}[config]
   base = {"value": u1 / t1, "unit": unit, "cores": 1, "kind": "port",
           "sample": "%s, members [0,%d) of the same ensemble, %.1f s on 1 core "
@@ -343,7 +343,7 @@ def make_ensemble(config, env, members, comm=None, n_total=None):
     cfg = configs.config3(N=n_total, members=sl)
     ens = pymoc_amd.TwoColEnsemble(cfg, diag_iters=240, **kw)
   elif config == 4:
-    cfg = dict(configs.config4(N=n_total, members=sl), bvp_refine=8)
+    cfg = dict(configs.config4(N=n_total, members=sl), bvp_refine=env.get("bvp_refine", 0))
     ens = pymoc_amd.TwoColEnsemble(cfg, **kw)
   else:
     cfg = configs.config5(N=n_total, members=sl)
@@ -547,6 +547,14 @@ def main():
         res, ens = bench_coupled(c, args, env, SIZES[c]["members"],
                                  nsteps=SIZES[c]["nsteps"], warm_blocks=10)
         res["workload"] = WORKLOAD[c] % (SIZES[c]["members"], ens.nz)
+        if c == 4:
+          # the GM boundary-value solve follows scipy solve_bvp's adaptive mesh (1e-14 from the
+          # reference); the fixed 8-fold mesh of round 1 (~1e-6 from the reference) for comparison
+          res["gm_bvp"] = "adaptive mesh (scipy solve_bvp's own refinement), parity 1e-11"
+          del ens
+          r8, ens = bench_coupled(4, args, dict(env, bvp_refine=8), SIZES[4]["members"],
+                                  nsteps=SIZES[4]["nsteps"], warm_blocks=10, breakdown=False)
+          res["fixed_mesh_R8_coupled_steps_per_s"] = r8["coupled_steps_per_s"]
         if c in cpu:
           res["cpu_baseline"] = cpu[c]
         out["coupled"]["config%d" % c] = res

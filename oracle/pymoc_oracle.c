@@ -744,14 +744,13 @@ void orc_psi_so_solve(const double *z, int nz, const double *y, int ny, const do
       ua = -(Psi_Ek[0] * 1e6);
       ub = -(Psi_Ek[nz - 1] * 1e6);
     }
-    if (par->bvp_refine < 0) { /* follow solve_bvp's own adaptive mesh */
+    if (par->bvp_refine <= 0) { /* default: follow solve_bvp's own adaptive mesh */
       double *sol = (double *)malloc(sizeof(double) * nz);
       orc_gm_bvp_adaptive(z, nz, N2, temp, par->c, ua, ub, 1e-3, 1000, sol, NULL, NULL, NULL);
       memcpy(temp, sol, sizeof(double) * nz);
       free(sol);
     } else {
-      gm_bvp(z, nz, N2, temp, par->c, ua, ub, par->bvp_refine > 0 ? par->bvp_refine : 16,
-             temp);
+      gm_bvp(z, nz, N2, temp, par->c, ua, ub, par->bvp_refine, temp);
     }
   } else {
     for (int i = 0; i < nz; ++i) {

@@ -175,7 +175,8 @@ __device__ __forceinline__ SoElem so_shfl_down(const SoElem &e, int d) {
 
 // ---------------------------------------------------------------------------------------
 // The GM boundary-value problem on the mesh scipy.integrate.solve_bvp itself ends on
-// (a.bvp_refine < 0; the default of the drop-in class and of the config-4 driver).
+// (a.bvp_refine <= 0, the default; a.bvp_refine = R > 0 selects the fixed R-fold mesh, 2-3x
+// faster and ~1e-6 from the reference).
 // solve_bvp (scipy 1.15.3 _bvp.py, defaults tol = 1e-3, max_nodes = 1000, as psi_SO.py:319-321
 // calls it) loops: Newton on the collocation system of the current mesh -- the ODE is linear,
 // Newton lands on that system's exact solution (checked against SciPy: 6e-16) -- then the rms
@@ -194,7 +195,7 @@ __device__ __forceinline__ SoElem so_shfl_down(const SoElem &e, int d) {
 //      chunk between the two now-known chunk ends (all chunks in parallel);
 //   E  nodal derivatives, F  residuals and insertion counts per interval, G  the new mesh by
 //      a prefix sum of the counts.
-constexpr int SO_MCAP = 384;  // mesh nodes the device follows SciPy to (status bit 3 beyond)
+constexpr int SO_MCAP = 256;  // config 4 and the golden cases end on 85-207 nodes  // mesh nodes the device follows SciPy to (status bit 3 beyond)
 // LDS doubles per wave: x[2][MCAP], u[MCAP], up[MCAP], z[nz], sN[nz], sT[nz] + shorts
 // seg[2][MCAP], cnt[MCAP]
 __host__ __device__ inline int so_adaptive_doubles(int nz) {
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   const int nz = a.nz, ny = a.ny;
   const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
   const bool tau_arr = (a.flags & PM_SO_TAU_ARRAY) != 0;
-  const bool adaptive = has_c && a.bvp_refine < 0;
+  const bool adaptive = has_c && a.bvp_refine <= 0;
   const int per_wave = 3 * ny + (has_c ? 2 * nz : 0) + (adaptive ? so_adaptive_doubles(nz) + nz : 0);
   double *s_y = lds_all + (size_t)wave * per_wave;
   double *s_bs = s_y + ny;
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
 template <int P>
 int launch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
   const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
-  const bool adaptive = has_c && a.bvp_refine < 0;
+  const bool adaptive = has_c && a.bvp_refine <= 0;
   const size_t per_wave = (size_t)(3 * a.ny + (has_c ? 2 * a.nz : 0) +
                                    (adaptive ? so_adaptive_doubles(a.nz) + a.nz : 0)) * sizeof(double);
   int wpb = SO_WAVES_PER_BLOCK;

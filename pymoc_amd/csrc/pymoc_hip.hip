@@ -352,7 +352,7 @@ int pm_psi_so_update(const pm_psi_so *so, int32_t ops, pm_stream_t stream) {
   PM_REQUIRE(a.z && a.y && a.b && a.bs && a.tau && a.KGM && a.Psi_Ek,
              "pm_psi_so has a NULL required pointer");
   PM_REQUIRE(!(ops & PM_SO_OP_GM) || (a.Psi && a.Psi_GM), "Psi / Psi_GM is NULL");
-  PM_REQUIRE(a.bvp_refine >= -1 && a.bvp_refine <= 256, "bad bvp_refine (-1: adaptive)");
+  PM_REQUIRE(a.bvp_refine >= -1 && a.bvp_refine <= 256, "bad bvp_refine (<= 0: adaptive mesh, R > 0: fixed R-fold mesh)");
   if (a.n == 0) return PM_OK;
   return dispatch_psi_so(a, ops, resolve_stream(stream));
 }

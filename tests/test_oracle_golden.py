@@ -13,7 +13,9 @@ from conftest import load_golden, relerr
 TOL_EXACT = 0.0          # elementwise fp64 paths restated operation by operation
 TOL_TW = 1e-13           # thermal wind: closed form vs SciPy collocation + sparse LU
 TOL_TRAJ = 1e-12         # coupled trajectories without the GM boundary-value problem
-TOL_BVP = 1e-5           # anything downstream of SciPy solve_bvp with c != None
+TOL_BVP = 1e-11          # anything downstream of SciPy solve_bvp with c != None: the oracle follows
+                         # solve_bvp's own adaptive mesh (measured 2e-14; 1e-6 on a fixed mesh)
+TOL_BVP_FIXED = 1e-5     # the fixed R-fold mesh option
 
 
 # ------------------------------------------------------------ third-party primitives
@@ -142,6 +144,9 @@ def test_psi_so_golden():
     else:
       assert relerr(GM, g[p + "Psi_GM"]) <= TOL_BVP, k
       assert relerr(Psi, g[p + "Psi"]) <= TOL_BVP, k
+      _, _, GM8, _ = O.psi_so_solve(g[p + "z"], g[p + "y"], g[p + "b"], g[p + "bs"], tau,
+                                    bvp_refine=8, **kw)
+      assert 1e-9 < relerr(GM8, g[p + "Psi_GM"]) <= TOL_BVP_FIXED, k  # the fast option
 
 
 # -------------------------------------------------------------------------- G7 SO_ML

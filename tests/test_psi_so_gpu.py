@@ -244,3 +244,75 @@ def test_config4_whole_baseline_ensemble_on_one_gpu(gpu):
     sp = part.state()
     for k in ("b_basin", "b_north", "Psi", "Psi_SO", "Psi_iso_b"):
       assert np.array_equal(sp[k], st[k][lo:lo + 8192]), (lo, k)
+
+
+# ------------------------------------------------ the default: solve_bvp's own adaptive mesh
+TOL_BVP_ADAPT = 1e-11  # measured 1e-14: SciPy's mesh is reproduced node for node
+
+
+def test_psi_so_golden_adaptive_mesh(gpu):
+  """G5 with the DEFAULT GM solver (bvp_refine <= 0): the device follows scipy solve_bvp's
+  mesh refinement (residual estimate, node insertion) decision for decision, so the BVP cases
+  agree with the reference to 1e-11 (the fixed 8-fold mesh: 1e-6), and with the oracle's
+  adaptive solver to 1e-11."""
+  from pymoc_amd.device import DeviceArray
+  g = load_golden("psi_so")
+  seen = 0
+  for k in range(int(g["ncases"])):
+    p = "c%02d_" % k
+    kw = _kwargs(g, p)
+    if kw["c"] is None:
+      continue
+    seen += 1
+    tau = g[p + "tau"]
+    KGM = kw.pop("KGM")
+    t = gpu.PsiSOBatch(g[p + "z"], g[p + "y"], 3, tau=float(tau) if tau.ndim == 0 else
+                       np.stack([tau] * 3), KGM=KGM, **kw)
+    t.update(DeviceArray.from_host(np.stack([g[p + "b"]] * 3)),
+             DeviceArray.from_host(np.stack([g[p + "bs"]] * 3)))
+    Psi, GM = t.Psi.download(), t.Psi_GM.download()
+    assert np.array_equal(GM[0], GM[1]) and np.array_equal(GM[0], GM[2])
+    assert relerr(GM[0], g[p + "Psi_GM"]) <= TOL_BVP_ADAPT, k
+    assert relerr(Psi[0], g[p + "Psi"]) <= TOL_BVP_ADAPT, k
+    oPsi, oEk, oGM, _ = O.psi_so_solve(g[p + "z"], g[p + "y"], g[p + "b"], g[p + "bs"],
+                                       float(tau) if tau.ndim == 0 else tau, KGM=KGM, **kw)
+    assert relerr(GM[0], oGM) <= TOL_BVP_ADAPT, k
+    assert np.all(t.status.download() & 14 == 0)  # incl. bit 3: mesh cap never reached
+  assert seen >= 12
+
+
+def test_twocol_so_trajectory_golden_adaptive_mesh(gpu):
+  """example_twocol_plusSO physics (BASELINE config 4's member), nz=100, 2400 steps = 100
+  boundary-value solves: 1e-11 from the reference with the default GM solver."""
+  g = load_golden("twocol_so")
+  m = configs.twocol_so_member(nz=100, ny=40)
+  cfg = dict(m, kappa=m["kappa"][None], b_basin0=m["b_basin0"][None],
+             b_north0=m["b_north0"][None], bs_SO=m["bs_SO"][None])
+  ens = gpu.TwoColEnsemble(cfg)
+  done = 0
+  for s in (1, 24, 25, 26, 2400):
+    ens.run(s - done)
+    done = s
+    st = ens.state()
+    for k in ("b_basin", "b_north", "Psi", "Psi_iso_b", "Psi_iso_n", "Psi_SO"):
+      assert relerr(st[k][0], g["s%05d_%s" % (s, k)]) <= TOL_BVP_ADAPT, (s, k)
+
+
+def test_config4_full_length_sweep_adaptive_mesh(gpu):
+  """G17 with the default GM solver: BASELINE config 4 (8192 members x 2400 steps) against the
+  8 members run through the reference at 1e-10, zero non-finite, no member hits the mesh cap;
+  17 more members against the oracle's adaptive solver."""
+  g = load_golden("sweep_full")
+  c = configs.config4(N=8192)
+  ens = gpu.TwoColEnsemble(c)
+  ens.run(2400)
+  st = ens.state()
+  idx = g["c4_members"]
+  for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
+    assert relerr(st[k][idx], g["c4_" + k]) <= 1e-10, k
+  assert ens.nonfinite_members().size == 0
+  assert np.all(ens.so.status.download() & 8 == 0)
+  for i in range(5, 8192, 500):
+    s = drivers.run_twocol(configs.member(c, i, 4), 2400, {2400}, so=True)[2400]
+    for k in ("b_basin", "Psi", "Psi_SO"):
+      assert relerr(st[k][i], s[k]) <= 1e-10, (i, k)
