@@ -401,8 +401,15 @@ def kernel_breakdown(config, cfg, ens, env, reps=20):
     alg = n * M * (2 * 24.0 * nz + 8.0 * (2 * nz + 2 * ny))
     model = ("per coupled step 2 x 14 (nz-2) (columns) + 30 ny (mixed layer) = %d flop, x %d "
              "members x %d fused steps" % (2 * flops_column_step(nz) + flops_so_ml_step(ny), n, M))
-  else:
-    flop, alg, model = float("nan"), float("nan"), "n/a"
+  elif dom == "k_psi_so":
+    # outcrop latitudes / Ekman / tapers ~60 nz; the adaptive GM boundary-value solve: per mesh
+    # pass and interval three collocation elements (~60 flop each), the residual estimate (~150)
+    # and scans + chunk Thomas (~70) = ~400, on meshes growing 100 -> ~190 nodes over ~5.5 passes
+    # (measured on this config: profiles/r02) -- an ESTIMATE of useful work, not a count
+    flop = n * (60.0 * nz + 400.0 * 5.5 * 0.5 * (nz + 1.9 * nz))
+    alg = n * 8.0 * (3 * nz + ny)
+    model = ("estimate: 60 nz + 400 flop x ~5.5 adaptive mesh passes x ~1.45 nz intervals = %d "
+             "flop per member and update, x %d members" % (flop / n, n))
   tf = flop / (ms * 1e-3) / 1e12
   roof = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
           "frac": tf / FP64_PEAK_TFLOPS, "kernel": dom, "kernel_ms_per_launch": ms,
