@@ -109,6 +109,12 @@ __device__ __forceinline__ double so_rcp(double x) {
   return y;
 }
 
+// one Newton step (~1e-14): only for the residual ESTIMATE, which feeds threshold tests
+__device__ __forceinline__ double so_rcp1(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+}
+
 struct SoElem {  // condensed 2x2 element of an interval: rows for its left/right node
   double a11, a12, c1, a21, a22, c2;
 };
@@ -117,6 +123,7 @@ struct SoElem {  // condensed 2x2 element of an interval: rows for its left/righ
 // S = u'_0 + u'_1 and D = u'_1 - u'_0 as affine functions of (u_0, u_1).
 __device__ __forceinline__ SoElem so_sub_element(double h, double q0, double q1, double qm,
                                                  double r0, double r1, double rm) {
+#pragma clang fp contract(fast)
   // divisions by the constants 12 and 6 and the repeated 1/h, 1/al are multiplications by
   // reciprocals here (<= 1 ulp each; this solve is compared at 1e-9 / 1e-5, not bitwise)
   const double h2_12 = h * h * (1. / 12.), h_6 = h * (1. / 6.), two_h = 2. * so_rcp(h);
@@ -139,6 +146,7 @@ __device__ __forceinline__ SoElem so_sub_element(double h, double q0, double q1,
 
 // eliminate the node shared by E (left) and e (right)
 __device__ __forceinline__ SoElem so_merge(const SoElem &E, const SoElem &e) {
+#pragma clang fp contract(fast)
   const double rD = so_rcp(E.a22 + e.a11);
   const double w1 = E.a12 * rD, w2 = e.a21 * rD;
   const double cc = E.c2 + e.c1;
@@ -195,11 +203,17 @@ __device__ __forceinline__ SoElem so_shfl_down(const SoElem &e, int d) {
 //      chunk between the two now-known chunk ends (all chunks in parallel);
 //   E  nodal derivatives, F  residuals and insertion counts per interval, G  the new mesh by
 //      a prefix sum of the counts.
-constexpr int SO_MCAP = 256;  // config 4 and the golden cases end on 85-207 nodes  // mesh nodes the device follows SciPy to (status bit 3 beyond)
-// LDS doubles per wave: x[2][MCAP], u[MCAP], up[MCAP], z[nz], sN[nz], sT[nz] + shorts
-// seg[2][MCAP], cnt[MCAP]
+// Two implementations.  nz <= SO_REG_NZ: `so_gm_adaptive_reg`, every lane keeps its <= 4
+// intervals in registers, meshes up to SO_REG_CAP nodes (config 4 and the golden cases end on
+// 85-207; status bit 3 if SciPy would refine further).  Larger grids: `so_gm_adaptive`, chunks
+// of any length worked through LDS scratch, meshes up to solve_bvp's own max_nodes.
+constexpr int SO_REG_NZ = 128, SO_REG_CAP = 256, SO_REG_C = SO_REG_CAP / 64;
+constexpr int SO_BIG_CAP = 1000;
+// LDS doubles per wave.  reg: x, q, t, u, up [CAP] + short mark[CAP].  big: x[2][CAP], u[CAP],
+// up[CAP], z[nz], sN[nz], sT[nz] + shorts seg[2][CAP], cnt[CAP]
 __host__ __device__ inline int so_adaptive_doubles(int nz) {
-  return 4 * SO_MCAP + 3 * nz + (3 * SO_MCAP * 2 + 7) / 8;
+  return (nz + 63) / 64 <= SO_REG_NZ / 64 ? 5 * SO_REG_CAP + (SO_REG_CAP * 2 + 7) / 8
+                         : 4 * SO_BIG_CAP + 3 * nz + (3 * SO_BIG_CAP * 2 + 7) / 8;
 }
 
 struct SoMesh {
@@ -357,7 +371,7 @@ __device__ __forceinline__ int so_gm_adaptive(SoMesh w, double ua, double ub, in
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) added += __shfl_xor(added, o, 64);
     if (added == 0) break;                       // status 0
-    if (m + added > max_nodes || m + added > SO_MCAP) {
+    if (m + added > max_nodes || m + added > SO_BIG_CAP) {
       if (m + added <= max_nodes) *status_bits |= 8;  // SciPy would refine further than we follow
       break;                                     // (beyond max_nodes SciPy stops here too)
     }
@@ -407,6 +421,296 @@ __device__ __forceinline__ int so_gm_adaptive(SoMesh w, double ua, double ub, in
     const int k = w.seg[i];
     if (w.x[i] == w.z[k]) out_lds[k] = w.u[i];
     if (i == m - 1) out_lds[nz - 1] = w.u[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  return m;
+}
+
+// ---- register-resident variant (nz <= SO_REG_NZ, meshes <= SO_REG_CAP nodes) -------------
+// N2 and T are np.interp closures over the column grid and every mesh interval lies inside one
+// original interval, so both are LINEAR on it: the tables q = N2/c^2 and t = T are kept per
+// mesh NODE; mid-points, inserted nodes and the Lobatto points take linear combinations of
+// their interval's end values (1e-16 from the np.interp expression; this solve is compared at
+// 1e-11, its mesh decisions are threshold tests).  A pass, per lane (<= SO_REG_C intervals):
+//   elements from the node tables -> chunk element -> prefix scan of chunk elements (6 doubles)
+//   -> the chunk-end values obey  u_l = A + B u_l(next lane): a suffix scan of AFFINE maps
+//   (2 doubles, no division) -> Thomas inside the chunk, derivatives, residuals, counts -- all
+//   in registers -> the new mesh is written back in place after one wave barrier.
+struct SoRegMesh {
+  double *x, *q, *t, *u, *up;
+  short *mark;  // original level of a node, -1 for inserted nodes
+};
+
+#ifdef PM_SO_PROFILE  // phase clocks of the adaptive solve (profiles/probe_so_phases.py)
+__device__ unsigned long long so_prof[8];
+#define SO_TICK(k)                                                  \
+  {                                                                 \
+    const unsigned long long t_ = __builtin_readcyclecounter();     \
+    if (lane == 0) atomicAdd(&so_prof[k], t_ - so_tprev);           \
+    so_tprev = t_;                                                  \
+  }
+#define SO_PROF_PARAM , unsigned long long &so_tprev
+#define SO_PROF_ARG , so_tprev
+#else
+#define SO_TICK(k)
+#define SO_PROF_PARAM
+#define SO_PROF_ARG
+#endif
+
+// One collocation solve on the current mesh for chunks of exactly <= RC intervals per lane
+// (RC = ceil((m-1)/64), wave-uniform): nodal values to w.u, nodal derivatives to w.up.
+template <int RC>
+__device__ __forceinline__ void so_reg_solve(const SoRegMesh &w, int m, double ua, double ub,
+                                             int lane SO_PROF_PARAM) {
+#pragma clang fp contract(fast)  // not a bitwise path: let mul+add pairs fuse
+  const int ne = m - 1;
+  const int f = lane * RC;
+  int nl = ne - f;
+  nl = nl < 0 ? 0 : (nl > RC ? RC : nl);
+  const bool has = nl > 0;
+  SO_TICK(0)
+  // ---- elements of the chunk
+  SoElem e[RC];
+  {
+    int i0 = f < m - 1 ? f : m - 1;
+    double x0 = w.x[i0], q0 = w.q[i0], t0 = w.t[i0];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+      const int i1 = f + c + 1 < m ? f + c + 1 : m - 1;
+      const double x1 = w.x[i1], q1 = w.q[i1], t1 = w.t[i1];
+      const double qm = 0.5 * (q0 + q1), tm = 0.5 * (t0 + t1);
+      e[c] = so_sub_element(x1 - x0, q0, q1, qm, q0 * t0, q1 * t1, qm * tm);
+      x0 = x1;
+      q0 = q1;
+      t0 = t1;
+    }
+  }
+  SoElem TL = e[0];
+#pragma unroll
+  for (int c = 1; c < RC; ++c)
+    if (c < nl) TL = so_merge(TL, e[c]);
+  SO_TICK(1)
+  // ---- prefix scan: PL = element of [node 0, this chunk's last node]
+  SoElem PL = TL;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const SoElem o = so_shfl_up(PL, d);
+    if (lane >= d && has) PL = so_merge(o, PL);
+  }
+  SO_TICK(2)
+  // ---- chunk-end values: (PL.a22 + TLn.a11) u_l + TLn.a12 u_l(next) = PL.c2 + TLn.c1 - PL.a21 ua
+  const double n11 = __shfl_down(TL.a11, 1, 64), n12 = __shfl_down(TL.a12, 1, 64),
+               nc1 = __shfl_down(TL.c1, 1, 64);
+  const bool next_has = __shfl_down(has ? 1 : 0, 1, 64) != 0 && lane < 63;
+  double A = ub, B = 0.;
+  if (has && next_has) {
+    const double rden = so_rcp(PL.a22 + n11);
+    A = (PL.c2 + nc1 - PL.a21 * ua) * rden;
+    B = -n12 * rden;
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double A2 = __shfl_down(A, d, 64), B2 = __shfl_down(B, d, 64);
+    if (lane + d < 64) {
+      A = __builtin_fma(B, A2, A);
+      B = B * B2;
+    }
+  }
+  const double ul = A;
+  double uf = __shfl_up(ul, 1, 64);
+  if (lane == 0) uf = ua;
+  SO_TICK(3)
+  // ---- Thomas inside the chunk between uf (node f) and ul (node f + nl)
+  double us[RC + 1];
+  {
+    double rd[RC], rr[RC];
+    double rdprev = 1., rprev = uf, cprev = 0.;
+#pragma unroll
+    for (int c = 1; c < RC; ++c) {
+      const double wq = e[c - 1].a21 * rdprev;
+      const double d2 = (e[c - 1].a22 + e[c].a11) - wq * cprev;
+      const double r2 = (e[c - 1].c2 + e[c].c1) - wq * rprev;
+      rd[c] = so_rcp(d2);
+      rr[c] = r2;
+      rdprev = rd[c];
+      rprev = r2;
+      cprev = e[c].a12;
+    }
+    double unext = ul;
+    us[0] = uf;
+#pragma unroll
+    for (int c = RC; c >= 1; --c) {
+      double v = unext;  // c >= nl: the chunk end (or beyond it: unused)
+      if (c < nl) v = (rr[c < RC ? c : RC - 1] - e[c < RC ? c : RC - 1].a12 * unext) * rd[c < RC ? c : RC - 1];
+      us[c] = v;
+      unext = v;
+    }
+  }
+  // ---- nodal values and derivatives (continuous across nodes by construction) go to LDS;
+  // the elements die here
+#pragma unroll
+  for (int c = 0; c < RC; ++c) {
+    if (c < nl) {
+      w.u[f + c] = us[c];
+      w.up[f + c] = 0.5 * (e[c].a11 * us[c] + e[c].a12 * us[c + 1] - e[c].c1);
+      if (c == nl - 1 && !next_has) {
+        w.u[ne] = ub;
+        w.up[ne] = 0.5 * (-e[c].a21 * us[c] - e[c].a22 * us[c + 1] + e[c].c2);
+      }
+    }
+  }
+  SO_TICK(4)
+}
+
+__device__ __forceinline__ int so_gm_adaptive_reg(const SoRegMesh &w, int nz, double ua,
+                                                  double ub, int lane, double *out_lds,
+                                                  int *status_bits) {
+#pragma clang fp contract(fast)  // not a bitwise path: let mul+add pairs fuse
+  const double tol = 1e-3;
+  const int max_nodes = 1000;
+  constexpr int RC = SO_REG_C;
+  int m = nz;
+#ifdef PM_SO_PROFILE
+  unsigned long long so_tprev = __builtin_readcyclecounter();
+#endif
+  for (int pass = 0; pass < 64; ++pass) {  // SciPy has no cap while nodes are added; 64 >> any run
+    const int ne = m - 1;
+    const int C = (ne + 63) >> 6;                 // <= RC because m <= SO_REG_CAP
+    const int f = lane * C;                       // first interval / first node of the chunk
+    int nl = ne - f;                              // intervals of this lane
+    nl = nl < 0 ? 0 : (nl > C ? C : nl);
+    const bool has = nl > 0;
+    switch (C) {  // wave-uniform
+      case 1: so_reg_solve<1>(w, m, ua, ub, lane SO_PROF_ARG); break;
+      case 2: so_reg_solve<2>(w, m, ua, ub, lane SO_PROF_ARG); break;
+      case 3: so_reg_solve<3>(w, m, ua, ub, lane SO_PROF_ARG); break;
+      default: so_reg_solve<4>(w, m, ua, ub, lane SO_PROF_ARG); break;
+    }
+    const bool next_has = __shfl_down(has ? 1 : 0, 1, 64) != 0 && lane < 63;
+    __builtin_amdgcn_wave_barrier();
+    // ---- rms residual and insertion count of every interval (estimate_rms_residuals); a real
+    // loop (register pressure); the counts of the lane's intervals are packed 2 bits each
+    int cntbits = 0, added = 0;
+    if (has) {
+      const double s37 = 0.6546536707079771;  // sqrt(3/7)
+      double x0 = w.x[f], q0 = w.q[f], t0 = w.t[f], y0a = w.u[f], p0a = w.up[f];
+#pragma unroll 1
+      for (int c = 0; c < nl; ++c) {
+        const int i1 = f + c + 1;
+        const double x1 = w.x[i1], q1 = w.q[i1], t1 = w.t[i1], y0b = w.u[i1], p0b = w.up[i1];
+        const double h = x1 - x0;
+        const double p1a = q0 * y0a - q0 * t0, p1b = q1 * y0b - q1 * t1;
+        const double rh = so_rcp(h);
+        const double sl0 = (y0b - y0a) * rh, t0c = (p0a + p0b - 2 * sl0) * rh;
+        const double sl1 = (p0b - p0a) * rh, t1c = (p1a + p1b - 2 * sl1) * rh;
+        const double c00 = t0c * rh, c01 = (sl0 - p0a) * rh - t0c;
+        const double c10 = t1c * rh, c11 = (sl1 - p1a) * rh - t1c;
+        const double sq = (q1 - q0) * rh, st = (t1 - t0) * rh;
+        const double hs = 0.5 * h, s = hs * s37;
+        double acc = 0.;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          const double dx = side == 0 ? hs + s : hs - s;
+          const double Y0 = ((c00 * dx + c01) * dx + p0a) * dx + y0a;
+          const double Y1 = ((c10 * dx + c11) * dx + p1a) * dx + p0a;
+          const double Y0p = (3 * c00 * dx + 2 * c01) * dx + p0a;
+          const double Y1p = (3 * c10 * dx + 2 * c11) * dx + p1a;
+          const double qe = sq * dx + q0, te = st * dx + t0;
+          const double F0 = Y1, F1 = qe * Y0 - qe * te;
+          const double e0 = (Y0p - F0) * so_rcp1(1 + __builtin_fabs(F0));
+          const double e1 = (Y1p - F1) * so_rcp1(1 + __builtin_fabs(F1));
+          acc += e0 * e0 + e1 * e1;
+        }
+        // rms = sqrt(0.5 * 49/90 * acc) compared through its square
+        const double ms = 0.5 * (49. / 90. * acc);
+        const int k = (ms >= (100 * tol) * (100 * tol)) ? 2 : ((ms > tol * tol) ? 1 : 0);
+        cntbits |= k << (2 * c);
+        added += k;
+        x0 = x1;
+        q0 = q1;
+        t0 = t1;
+        y0a = y0b;
+        p0a = p0b;
+      }
+    }
+    SO_TICK(5)
+    // ---- new mesh (modify_mesh): positions by a prefix sum of the nodes each lane writes; its
+    // last entry is the new node count
+    const int mine = nl + added;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    added = __builtin_amdgcn_readlane(incl, 63) - ne;
+    const bool grow = added != 0 && m + added <= max_nodes && m + added <= SO_REG_CAP;
+    if (!grow) {
+      if (added != 0 && m + added <= max_nodes) *status_bits |= 8;  // SciPy would refine further
+      // (beyond max_nodes SciPy stops with this solution too)
+      break;
+    }
+    // in place: everything a lane needs is read before the barrier
+    int pos = incl - mine;
+    double xs[RC + 1], qs[RC + 1], ts[RC + 1];
+    short mk[RC + 1];
+#pragma unroll
+    for (int c = 0; c <= RC; ++c) {
+      const int i = f + c < m ? f + c : m - 1;
+      xs[c] = w.x[i];
+      qs[c] = w.q[i];
+      ts[c] = w.t[i];
+      mk[c] = w.mark[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double third = 1. / 3.;  // the inserted x differ from SciPy's (2 x_i + x_i+1) / 3 by <= 1 ulp
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+      if (c < nl) {
+        const double xa = xs[c], xb = xs[c + 1], qa = qs[c], qb = qs[c + 1], ta = ts[c],
+                     tb = ts[c + 1];
+        const int k = (cntbits >> (2 * c)) & 3;
+        const double wa = k == 1 ? 0.5 : 2. * third, wb = k == 1 ? 0.5 : third;
+        w.x[pos] = xa;
+        w.q[pos] = qa;
+        w.t[pos] = ta;
+        w.mark[pos] = mk[c];
+        if (k >= 1) {
+          w.x[pos + 1] = wa * xa + wb * xb;
+          w.q[pos + 1] = wa * qa + wb * qb;
+          w.t[pos + 1] = wa * ta + wb * tb;
+          w.mark[pos + 1] = (short)-1;
+        }
+        if (k == 2) {
+          w.x[pos + 2] = wb * xa + wa * xb;
+          w.q[pos + 2] = wb * qa + wa * qb;
+          w.t[pos + 2] = wb * ta + wa * tb;
+          w.mark[pos + 2] = (short)-1;
+        }
+        pos += 1 + k;
+      }
+    }
+    if (has && !next_has) {  // the last node of the mesh
+#pragma unroll
+      for (int c = 1; c <= RC; ++c)
+        if (c == nl) {
+          w.x[pos] = xs[c];
+          w.q[pos] = qs[c];
+          w.t[pos] = ts[c];
+          w.mark[pos] = mk[c];
+        }
+    }
+    m += added;
+    __builtin_amdgcn_wave_barrier();
+    SO_TICK(6)
+#ifdef PM_SO_PROFILE
+    if (lane == 0) atomicAdd(&so_prof[7], 1ull);
+#endif
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < m; i += 64) {
+    const int k = w.mark[i];
+    if (k >= 0 && k < nz) out_lds[k] = w.u[i];
   }
   __builtin_amdgcn_wave_barrier();
   return m;
@@ -623,18 +927,42 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
       ua0 = -(__shfl(ek_sv[0], 0, 64) * 1e6);
       ub0 = -(__shfl(v_last, last_lane, 64) * 1e6);
     }
-    if (adaptive) {  // wave-uniform: follow solve_bvp's own mesh
+    if (P <= SO_REG_NZ / 64 && adaptive) {  // wave-uniform: follow solve_bvp's own mesh
+      double *wk = s_w + 2 * nz;
+      SoRegMesh ms;
+      ms.x = wk;
+      ms.q = wk + SO_REG_CAP;
+      ms.t = wk + 2 * SO_REG_CAP;
+      ms.u = wk + 3 * SO_REG_CAP;
+      ms.up = wk + 4 * SO_REG_CAP;
+      ms.mark = reinterpret_cast<short *>(wk + 5 * SO_REG_CAP);
+      double *outl = wk + so_adaptive_doubles(nz);
+      const double rc2 = 1. / c2;
+      for (int i = lane; i < nz; i += 64) {
+        ms.x[i] = a.z[i];
+        ms.q[i] = s_N2[i] * rc2;
+        ms.t[i] = s_T[i];
+        ms.mark[i] = (short)i;
+      }
+      __builtin_amdgcn_wave_barrier();
+      so_gm_adaptive_reg(ms, nz, ua0, ub0, lane, outl, &gm_status);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = lane * P + p;
+        temp[p] = outl[i < nz ? i : nz - 1];
+      }
+    } else if (P > SO_REG_NZ / 64 && adaptive) {
       double *wk = s_w + 2 * nz;
       SoMesh ms;
       ms.x = wk;
-      ms.xn = wk + SO_MCAP;
-      ms.u = wk + 2 * SO_MCAP;
-      ms.up = wk + 3 * SO_MCAP;
-      double *zl = wk + 4 * SO_MCAP;
+      ms.xn = wk + SO_BIG_CAP;
+      ms.u = wk + 2 * SO_BIG_CAP;
+      ms.up = wk + 3 * SO_BIG_CAP;
+      double *zl = wk + 4 * SO_BIG_CAP;
       double *sNl = zl + nz, *sTl = zl + 2 * nz;
       ms.seg = reinterpret_cast<short *>(zl + 3 * nz);
-      ms.segn = ms.seg + SO_MCAP;
-      ms.cnt = ms.segn + SO_MCAP;
+      ms.segn = ms.seg + SO_BIG_CAP;
+      ms.cnt = ms.segn + SO_BIG_CAP;
       double *outl = wk + so_adaptive_doubles(nz);
       for (int i = lane; i < nz; i += 64) {
         zl[i] = a.z[i];
