@@ -209,11 +209,20 @@ __device__ __forceinline__ SoElem so_shfl_down(const SoElem &e, int d) {
 // of any length worked through LDS scratch, meshes up to solve_bvp's own max_nodes.
 constexpr int SO_REG_NZ = 128, SO_REG_CAP = 256, SO_REG_C = SO_REG_CAP / 64;
 constexpr int SO_BIG_CAP = 1000;
-// LDS doubles per wave.  reg: x, q, t, u, up [CAP] + short mark[CAP].  big: x[2][CAP], u[CAP],
-// up[CAP], z[nz], sN[nz], sT[nz] + shorts seg[2][CAP], cnt[CAP]
-__host__ __device__ inline int so_adaptive_doubles(int nz) {
-  return (nz + 63) / 64 <= SO_REG_NZ / 64 ? 5 * SO_REG_CAP + (SO_REG_CAP * 2 + 7) / 8
-                         : 4 * SO_BIG_CAP + 3 * nz + (3 * SO_BIG_CAP * 2 + 7) / 8;
+// LDS doubles per wave.  reg: x, q, t, u [CAP] + short mark[CAP], and up[CAP] laid over the
+// staging area (y, bs, tau, T, N2: dead once the node tables are filled; the result vector
+// `out` lies there too, written when up is dead).  big: x[2][CAP], u[CAP], up[CAP], z[nz],
+// sN[nz], sT[nz] + shorts seg[2][CAP], cnt[CAP], + out[nz] behind the staging area.
+__host__ __device__ inline bool so_reg_path(int nz) { return (nz + 63) / 64 <= SO_REG_NZ / 64; }
+__host__ __device__ inline int so_big_doubles(int nz) {
+  return 4 * SO_BIG_CAP + 3 * nz + (3 * SO_BIG_CAP * 2 + 7) / 8;
+}
+__host__ __device__ inline int so_lds_doubles(int nz, int ny, bool has_c, bool adaptive) {
+  const int stage = 3 * ny + (has_c ? 2 * nz : 0);
+  if (!adaptive) return stage;
+  if (so_reg_path(nz))
+    return (stage > SO_REG_CAP ? stage : SO_REG_CAP) + 4 * SO_REG_CAP + (SO_REG_CAP * 2 + 7) / 8;
+  return stage + so_big_doubles(nz) + nz;
 }
 
 struct SoMesh {
@@ -728,7 +737,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
   const bool tau_arr = (a.flags & PM_SO_TAU_ARRAY) != 0;
   const bool adaptive = has_c && a.bvp_refine <= 0;
-  const int per_wave = 3 * ny + (has_c ? 2 * nz : 0) + (adaptive ? so_adaptive_doubles(nz) + nz : 0);
+  const int per_wave = so_lds_doubles(nz, ny, has_c, adaptive);
   double *s_y = lds_all + (size_t)wave * per_wave;
   double *s_bs = s_y + ny;
   double *s_tau = s_bs + ny;
@@ -928,15 +937,16 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
       ub0 = -(__shfl(v_last, last_lane, 64) * 1e6);
     }
     if (P <= SO_REG_NZ / 64 && adaptive) {  // wave-uniform: follow solve_bvp's own mesh
-      double *wk = s_w + 2 * nz;
+      const int stage = 3 * ny + 2 * nz;
+      double *wk = s_y + (stage > SO_REG_CAP ? stage : SO_REG_CAP);
       SoRegMesh ms;
       ms.x = wk;
       ms.q = wk + SO_REG_CAP;
       ms.t = wk + 2 * SO_REG_CAP;
       ms.u = wk + 3 * SO_REG_CAP;
-      ms.up = wk + 4 * SO_REG_CAP;
-      ms.mark = reinterpret_cast<short *>(wk + 5 * SO_REG_CAP);
-      double *outl = wk + so_adaptive_doubles(nz);
+      ms.mark = reinterpret_cast<short *>(wk + 4 * SO_REG_CAP);
+      ms.up = s_y;          // over the staging area: written only after the tables are filled
+      double *outl = s_y;   // ... and read for the last time before `out` is written
       const double rc2 = 1. / c2;
       for (int i = lane; i < nz; i += 64) {
         ms.x[i] = a.z[i];
@@ -963,7 +973,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
       ms.seg = reinterpret_cast<short *>(zl + 3 * nz);
       ms.segn = ms.seg + SO_BIG_CAP;
       ms.cnt = ms.segn + SO_BIG_CAP;
-      double *outl = wk + so_adaptive_doubles(nz);
+      double *outl = wk + so_big_doubles(nz);
       for (int i = lane; i < nz; i += 64) {
         zl[i] = a.z[i];
         if (i < nz - 1) {
@@ -1113,10 +1123,16 @@ template <int P>
 int launch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
   const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
   const bool adaptive = has_c && a.bvp_refine <= 0;
-  const size_t per_wave = (size_t)(3 * a.ny + (has_c ? 2 * a.nz : 0) +
-                                   (adaptive ? so_adaptive_doubles(a.nz) + a.nz : 0)) * sizeof(double);
-  int wpb = SO_WAVES_PER_BLOCK;
-  while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
+  const size_t per_wave = (size_t)so_lds_doubles(a.nz, a.ny, has_c, adaptive) * sizeof(double);
+  // waves per block: as many of SO_WAVES_PER_BLOCK, .../2, 1 as keeps the most waves on a CU
+  int wpb = 1, best = 0;
+  for (int w = SO_WAVES_PER_BLOCK; w >= 1; w >>= 1) {
+    const int resident = (int)((160 * 1024) / (per_wave * w)) * w;
+    if (resident > best) {
+      best = resident;
+      wpb = w;
+    }
+  }
   const size_t lds = per_wave * wpb;
   if (lds > 160 * 1024) return fail(PM_EINVAL, "psi_so needs %zu B of LDS per member", lds);
   if (lds > 64 * 1024)
