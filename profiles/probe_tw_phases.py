@@ -1,0 +1,29 @@
+"""Phase clocks of k_thermwind (config 3: 4096 members, nz=100, nb=500).  Needs the profiling
+build:  make -B lib EXTRA=-DPM_PHASE_PROFILE ; afterwards  make -B lib  restores the product."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import pymoc_amd as gpu
+from pymoc_amd import configs, _lib
+from pymoc_amd.device import DeviceArray
+
+N = int(os.environ.get("N", 4096))
+c = configs.config3(N=N)
+e = gpu.TwoColEnsemble(c)
+e.run(241)
+gpu.synchronize()
+out = (C.c_ulonglong * 16)()
+_lib.lib.pm_debug_prof(out)
+K = 20
+for _ in range(K):
+  e.tw.update(e._b_basin, e._b_north, store_psib=False)
+gpu.synchronize()
+_lib.lib.pm_debug_prof(out)
+v = np.array(list(out), dtype=np.float64)
+names = ["loads", "dG", "scan 1", "dI", "scan 2", "Psi + store", "min/max, linspace",
+         "cell staging", "group ranges", "class passes", "Psibz + store"]
+tot = v[:11].sum()
+for n, x in zip(names, v[:11]):
+  print("%-20s %8.0f cycles per member-update  %5.1f %%" % (n, x / v[15], 100 * x / tot))
+print("8-cell groups per member-update after the first of a block: general %.1f, all-ones %.1f, all-zeros %.1f"
+      % (v[11] / v[15], v[12] / v[15], v[13] / v[15]))

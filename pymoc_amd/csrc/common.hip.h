@@ -105,6 +105,39 @@ __device__ __forceinline__ double div_by_recip2(double a, double d, double yh, d
   return q;
 }
 
+// Phase clocks for profiling builds (make -B lib EXTRA=-DPM_PHASE_PROFILE; read and cleared
+// through pm_debug_prof).  PM_TICK(k) adds the cycles since the previous tick of this wave to
+// slot k of a per-wave accumulator; a kernel that uses it declares `PM_TICK_INIT` once and ends
+// with `PM_TICK_FLUSH` (a sample of the waves reports; slot 15 counts the reports).
+#ifdef PM_PHASE_PROFILE
+__device__ unsigned long long pm_prof[16];
+#define PM_TICK_INIT                                             \
+  unsigned long long pm_acc[16] = {0};                           \
+  unsigned long long pm_tprev = __builtin_readcyclecounter();
+#define PM_TICK(k)                                                \
+  {                                                               \
+    const unsigned long long t_ = __builtin_readcyclecounter();   \
+    pm_acc[k] += t_ - pm_tprev;                                   \
+    pm_tprev = t_;                                                \
+  }
+#define PM_COUNT(k) pm_acc[k] += 1ull;
+#define PM_TICK_FLUSH /* one wave in 64 reports (slot 15 counts them) */ \
+  if (threadIdx.x == 0 && (blockIdx.x & 15) == 0) {               \
+    for (int k_ = 0; k_ < 15; ++k_)                               \
+      if (pm_acc[k_]) atomicAdd(&pm_prof[k_], pm_acc[k_]);        \
+    atomicAdd(&pm_prof[15], 1ull);                                \
+  }
+#define PM_TICK_PARAM , unsigned long long &pm_tprev, unsigned long long (&pm_acc)[16]
+#define PM_TICK_ARG , pm_tprev, pm_acc
+#else
+#define PM_TICK_INIT
+#define PM_TICK(k)
+#define PM_COUNT(k)
+#define PM_TICK_FLUSH
+#define PM_TICK_PARAM
+#define PM_TICK_ARG
+#endif
+
 // 64-bit mask of the G lanes of this lane's group inside the wave.
 template <int G>
 __device__ __forceinline__ unsigned long long group_mask(int lane) {

@@ -450,34 +450,18 @@ struct SoRegMesh {
   short *mark;  // original level of a node, -1 for inserted nodes
 };
 
-#ifdef PM_SO_PROFILE  // phase clocks of the adaptive solve (profiles/probe_so_phases.py)
-__device__ unsigned long long so_prof[8];
-#define SO_TICK(k)                                                  \
-  {                                                                 \
-    const unsigned long long t_ = __builtin_readcyclecounter();     \
-    if (lane == 0) atomicAdd(&so_prof[k], t_ - so_tprev);           \
-    so_tprev = t_;                                                  \
-  }
-#define SO_PROF_PARAM , unsigned long long &so_tprev
-#define SO_PROF_ARG , so_tprev
-#else
-#define SO_TICK(k)
-#define SO_PROF_PARAM
-#define SO_PROF_ARG
-#endif
-
 // One collocation solve on the current mesh for chunks of exactly <= RC intervals per lane
 // (RC = ceil((m-1)/64), wave-uniform): nodal values to w.u, nodal derivatives to w.up.
 template <int RC>
 __device__ __forceinline__ void so_reg_solve(const SoRegMesh &w, int m, double ua, double ub,
-                                             int lane SO_PROF_PARAM) {
+                                             int lane PM_TICK_PARAM) {
 #pragma clang fp contract(fast)  // not a bitwise path: let mul+add pairs fuse
   const int ne = m - 1;
   const int f = lane * RC;
   int nl = ne - f;
   nl = nl < 0 ? 0 : (nl > RC ? RC : nl);
   const bool has = nl > 0;
-  SO_TICK(0)
+  PM_TICK(0)
   // ---- elements of the chunk
   SoElem e[RC];
   {
@@ -498,7 +482,7 @@ __device__ __forceinline__ void so_reg_solve(const SoRegMesh &w, int m, double u
 #pragma unroll
   for (int c = 1; c < RC; ++c)
     if (c < nl) TL = so_merge(TL, e[c]);
-  SO_TICK(1)
+  PM_TICK(1)
   // ---- prefix scan: PL = element of [node 0, this chunk's last node]
   SoElem PL = TL;
 #pragma unroll
@@ -506,7 +490,7 @@ __device__ __forceinline__ void so_reg_solve(const SoRegMesh &w, int m, double u
     const SoElem o = so_shfl_up(PL, d);
     if (lane >= d && has) PL = so_merge(o, PL);
   }
-  SO_TICK(2)
+  PM_TICK(2)
   // ---- chunk-end values: (PL.a22 + TLn.a11) u_l + TLn.a12 u_l(next) = PL.c2 + TLn.c1 - PL.a21 ua
   const double n11 = __shfl_down(TL.a11, 1, 64), n12 = __shfl_down(TL.a12, 1, 64),
                nc1 = __shfl_down(TL.c1, 1, 64);
@@ -528,7 +512,7 @@ __device__ __forceinline__ void so_reg_solve(const SoRegMesh &w, int m, double u
   const double ul = A;
   double uf = __shfl_up(ul, 1, 64);
   if (lane == 0) uf = ua;
-  SO_TICK(3)
+  PM_TICK(3)
   // ---- Thomas inside the chunk between uf (node f) and ul (node f + nl)
   double us[RC + 1];
   {
@@ -568,20 +552,18 @@ __device__ __forceinline__ void so_reg_solve(const SoRegMesh &w, int m, double u
       }
     }
   }
-  SO_TICK(4)
+  PM_TICK(4)
 }
 
 __device__ __forceinline__ int so_gm_adaptive_reg(const SoRegMesh &w, int nz, double ua,
                                                   double ub, int lane, double *out_lds,
-                                                  int *status_bits) {
+                                                  int *status_bits PM_TICK_PARAM) {
 #pragma clang fp contract(fast)  // not a bitwise path: let mul+add pairs fuse
   const double tol = 1e-3;
   const int max_nodes = 1000;
   constexpr int RC = SO_REG_C;
   int m = nz;
-#ifdef PM_SO_PROFILE
-  unsigned long long so_tprev = __builtin_readcyclecounter();
-#endif
+  PM_TICK(8)
   for (int pass = 0; pass < 64; ++pass) {  // SciPy has no cap while nodes are added; 64 >> any run
     const int ne = m - 1;
     const int C = (ne + 63) >> 6;                 // <= RC because m <= SO_REG_CAP
@@ -590,10 +572,10 @@ __device__ __forceinline__ int so_gm_adaptive_reg(const SoRegMesh &w, int nz, do
     nl = nl < 0 ? 0 : (nl > C ? C : nl);
     const bool has = nl > 0;
     switch (C) {  // wave-uniform
-      case 1: so_reg_solve<1>(w, m, ua, ub, lane SO_PROF_ARG); break;
-      case 2: so_reg_solve<2>(w, m, ua, ub, lane SO_PROF_ARG); break;
-      case 3: so_reg_solve<3>(w, m, ua, ub, lane SO_PROF_ARG); break;
-      default: so_reg_solve<4>(w, m, ua, ub, lane SO_PROF_ARG); break;
+      case 1: so_reg_solve<1>(w, m, ua, ub, lane PM_TICK_ARG); break;
+      case 2: so_reg_solve<2>(w, m, ua, ub, lane PM_TICK_ARG); break;
+      case 3: so_reg_solve<3>(w, m, ua, ub, lane PM_TICK_ARG); break;
+      default: so_reg_solve<4>(w, m, ua, ub, lane PM_TICK_ARG); break;
     }
     const bool next_has = __shfl_down(has ? 1 : 0, 1, 64) != 0 && lane < 63;
     __builtin_amdgcn_wave_barrier();
@@ -642,7 +624,7 @@ __device__ __forceinline__ int so_gm_adaptive_reg(const SoRegMesh &w, int nz, do
         p0a = p0b;
       }
     }
-    SO_TICK(5)
+    PM_TICK(5)
     // ---- new mesh (modify_mesh): positions by a prefix sum of the nodes each lane writes; its
     // last entry is the new node count
     const int mine = nl + added;
@@ -711,10 +693,8 @@ __device__ __forceinline__ int so_gm_adaptive_reg(const SoRegMesh &w, int nz, do
     }
     m += added;
     __builtin_amdgcn_wave_barrier();
-    SO_TICK(6)
-#ifdef PM_SO_PROFILE
-    if (lane == 0) atomicAdd(&so_prof[7], 1ull);
-#endif
+    PM_TICK(6)
+    PM_COUNT(7)
   }
   __builtin_amdgcn_wave_barrier();
   for (int i = lane; i < m; i += 64) {
@@ -734,6 +714,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   const bool m_ok = m_raw < a.n;
   const int m = m_ok ? m_raw : a.n - 1;
   const int nz = a.nz, ny = a.ny;
+  PM_TICK_INIT
   const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
   const bool tau_arr = (a.flags & PM_SO_TAU_ARRAY) != 0;
   const bool adaptive = has_c && a.bvp_refine <= 0;
@@ -955,7 +936,8 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
         ms.mark[i] = (short)i;
       }
       __builtin_amdgcn_wave_barrier();
-      so_gm_adaptive_reg(ms, nz, ua0, ub0, lane, outl, &gm_status);
+      so_gm_adaptive_reg(ms, nz, ua0, ub0, lane, outl, &gm_status PM_TICK_ARG);
+      PM_TICK(9)
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int i = lane * P + p;
@@ -1117,6 +1099,8 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
     if (lane == 0 && m_ok)
       a.status[m] = (ambiguous ? 1 : 0) | (anybad ? 2 : 0) | (bs_nan ? 4 : 0) | gm_status;
   }
+  PM_TICK(10)
+  PM_TICK_FLUSH
 }
 
 template <int P>

@@ -535,12 +535,12 @@ int pm_selftest_lane_shift(int32_t *mismatches) {
 
 }  // extern "C"
 
-#ifdef PM_SO_PROFILE
-// profiling build only (make lib EXTRA=-DPM_SO_PROFILE): read and clear the phase clocks
-extern "C" int pm_debug_so_prof(unsigned long long *out8) {
-  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pm::so_prof), sizeof(zero)) != hipSuccess) return -1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(pm::so_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+#ifdef PM_PHASE_PROFILE
+// profiling build only (make -B lib EXTRA=-DPM_PHASE_PROFILE): read and clear the phase clocks
+extern "C" int pm_debug_prof(unsigned long long *out16) {
+  unsigned long long zero[16] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pm::pm_prof), sizeof(zero)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(pm::pm_prof), zero, sizeof(zero)) != hipSuccess) return -1;
   return 0;
 }
 #endif

@@ -72,46 +72,73 @@ __device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
   return r;
 }
 
-// mask_k * u_k of one cell for TW_JT classes: clip((top - bg)/(top - bot), 0, 1) * u
-// (psi_thermwind.py:183).  Regular cells (finite, non-zero thickness; yk = RN(1/d), else
-// NaN) take the correctly-rounded reciprocal division and a max/min clamp; degenerate cells
-// (zero thickness -> +-inf / NaN, hazard H6) take IEEE division and NumPy's NaN-propagating
-// clip.  The branch is wave-uniform (cell data is broadcast from LDS).
-__device__ __forceinline__ void psib_cell_terms(double t, double d, double yk, double uk,
-                                                const double (&bg)[TW_JT],
+// Cells of the Psib sum in LDS, 6 doubles each (three 16-byte broadcast loads):
+//   top, d = top - bot | yh = RN(1/d) or NaN, yl = recip_lo(d, yh) | u, (pad)
+constexpr int TW_CELL = 6;
+struct PsibCell {
+  double top, d, yh, yl, u;
+};
+// LDS doubles per wave: cells, the psib row, two group-range rows; even, so that every wave's
+// cells stay 16-byte aligned
+__host__ __device__ inline int tw_lds_doubles(int nz, int nb) {
+  return (TW_CELL * nz + nb + 2 * ((nz + 7) / 8) + 1) & ~1;
+}
+__device__ __forceinline__ PsibCell psib_load_cell(const double *cells, int k) {
+  const double2 *c = reinterpret_cast<const double2 *>(cells + (size_t)k * TW_CELL);
+  const double2 v0 = c[0], v1 = c[1], v2 = c[2];
+  return PsibCell{v0.x, v0.y, v1.x, v1.y, v2.x};
+}
+
+// RN(fma(r, yh, q)) clamped to [0, 1] by the VOP3 clamp modifier (the last Markstein step and
+// np.clip in one instruction; finite operands only)
+__device__ __forceinline__ double fma_clamp01(double r, double yh, double q) {
+  double o;
+  asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(o) : "v"(r), "v"(yh), "v"(q));
+  return o;
+}
+
+// mask_k * u_k of one REGULAR cell for TW_JT classes: clip((top - bg)/(top - bot), 0, 1) * u
+// (psi_thermwind.py:183), the quotient correctly rounded in 4 instructions from the
+// double-double reciprocal (div_by_recip2), the clip folded into the last of them.
+__device__ __forceinline__ void psib_regular_terms(const PsibCell &c, const double (&bg)[TW_JT],
+                                                   double (&out)[TW_JT]) {
+  double tt[TW_JT], q[TW_JT], rr[TW_JT];
+#pragma unroll
+  for (int j = 0; j < TW_JT; ++j) tt[j] = c.top - bg[j];
+#pragma unroll
+  for (int j = 0; j < TW_JT; ++j) rr[j] = tt[j] * c.yl;
+#pragma unroll
+  for (int j = 0; j < TW_JT; ++j) q[j] = __builtin_fma(tt[j], c.yh, rr[j]);
+#pragma unroll
+  for (int j = 0; j < TW_JT; ++j) rr[j] = __builtin_fma(-c.d, q[j], tt[j]);
+#pragma unroll
+  for (int j = 0; j < TW_JT; ++j) out[j] = fma_clamp01(rr[j], c.yh, q[j]) * c.u;
+}
+
+// Any cell: regular ones (finite, thickness in [1e-100, 1e100]; yh is NaN otherwise) as above;
+// degenerate cells (zero thickness -> +-inf / NaN, hazard H6) take IEEE division and NumPy's
+// NaN-propagating clip.  The branch is wave-uniform (cell data is broadcast from LDS).
+__device__ __forceinline__ void psib_cell_terms(const PsibCell &c, const double (&bg)[TW_JT],
                                                 double (&out)[TW_JT]) {
-  if (yk == yk) {
-    double tt[TW_JT], q[TW_JT], rr[TW_JT];
-#pragma unroll
-    for (int j = 0; j < TW_JT; ++j) tt[j] = t - bg[j];
-#pragma unroll
-    for (int j = 0; j < TW_JT; ++j) q[j] = tt[j] * yk;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-#pragma unroll
-      for (int j = 0; j < TW_JT; ++j) rr[j] = __builtin_fma(-d, q[j], tt[j]);
-#pragma unroll
-      for (int j = 0; j < TW_JT; ++j) q[j] = __builtin_fma(rr[j], yk, q[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < TW_JT; ++j)
-      out[j] = __builtin_fmin(__builtin_fmax(q[j], 0.), 1.) * uk;
+  if (c.yh == c.yh) {
+    psib_regular_terms(c, bg, out);
   } else {
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) out[j] = np_clip01((t - bg[j]) / d) * uk;
+    for (int j = 0; j < TW_JT; ++j) out[j] = np_clip01((c.top - bg[j]) / c.d) * c.u;
   }
 }
 
 // One isopycnal class: sum_k clip((top_k - bg)/(top_k - bot_k), 0, 1) * u_k over cells
-// [k0, k0+n) in NumPy's pairwise order, for TW_JT classes at once.  Cell arrays in LDS:
-// top, d = top - bot, y = RN(1/d) or NaN, u.
+// [k0, k0+n) in NumPy's pairwise order, for TW_JT classes at once.
 // Range test of a pass: every class of the pass lies in [gmin, gmax] (wave-uniform scalars);
-// gbot[g] / gtop[g] hold min(bot) / max(top) of the 8 cells k = 8g .. 8g+7 (-inf / +inf when a
-// cell of the group is degenerate or inverted, or carries a non-finite u_k).  If gmax <= gbot[g] every mask of the group
-// is exactly 1 for every class of the pass (fl(top-g) >= fl(top-bot) > 0, quotient >= 1), so
-// the terms are the u_k themselves; if gmin >= gtop[g] every mask is exactly 0 and the group
-// only adds zeros.  Both shortcuts leave every partial sum of NumPy's pairwise order
-// bit-identical (x + 0 = x).
+// gbot[g] / gtop[g] hold min(bot) / max(top) of the 8 cells k = 8g .. 8g+7, or -inf / +inf when
+// a cell of the group is degenerate or inverted or carries a non-finite u_k ("irregular
+// group").  If gmax <= gbot[g] every mask of the group is exactly 1 for every class of the
+// pass (fl(top-g) >= fl(top-bot) > 0, quotient >= 1), so the terms are the u_k themselves; if
+// gmin >= gtop[g] every mask is exactly 0 and the group only adds zeros.  Both shortcuts leave
+// every partial sum of NumPy's pairwise order bit-identical (x + 0 = x).  A regular group
+// that straddles the pass's range runs its 8 cells without any per-cell branch; an irregular
+// group tests every cell.
 struct PsibRange {
   const double *gbot, *gtop;
   double gmin, gmax;
@@ -123,74 +150,91 @@ __device__ __forceinline__ double tw_uniform(double x) {
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ void psib_block_sum(const double *top, const double *dd,
-                                               const double *yy, const double *u, int k0,
-                                               int n, const double (&bg)[TW_JT],
-                                               double (&res)[TW_JT], const PsibRange &rg) {
+// terms of the 8 cells of group k8/8 into r (ADD: accumulate, else initialise).
+// kind: 0 general and regular, 1 general and irregular, 2 all masks one, 3 all masks zero
+template <bool ADD>
+__device__ __forceinline__ void psib_group(const double *cells, int k8, int kind,
+                                           const double (&bg)[TW_JT],
+                                           double (&r)[8][TW_JT] PM_TICK_PARAM) {
+  double term[TW_JT];
+  if (kind == 2) {
+    PM_COUNT(12)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const double uk = cells[(size_t)(k8 + a) * TW_CELL + 4];
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) r[a][j] = ADD ? r[a][j] + uk : uk;
+    }
+  } else if (kind == 3) {
+    PM_COUNT(13)
+    if (!ADD) {  // all masks 0: the group adds zeros
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int j = 0; j < TW_JT; ++j) r[a][j] = 0.;
+    }
+  } else if (kind == 0) {
+    PM_COUNT(11)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      psib_regular_terms(psib_load_cell(cells, k8 + a), bg, term);
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) r[a][j] = ADD ? r[a][j] + term[j] : term[j];
+    }
+  } else {
+    PM_COUNT(14)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      psib_cell_terms(psib_load_cell(cells, k8 + a), bg, term);
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) r[a][j] = ADD ? r[a][j] + term[j] : term[j];
+    }
+  }
+}
+
+// n <= 128 cells from k0 (a multiple of 8): NumPy's 8-accumulator block.  The groups of the
+// block are classified at once -- lane l compares the range of group k0/8 + l with the pass's
+// class range, three ballots give the masks -- so the loop below visits only the groups that
+// add something, with scalar bit tests instead of an LDS round trip and two compares per group.
+__device__ __forceinline__ void psib_block_sum(const double *cells, int k0, int n,
+                                               const double (&bg)[TW_JT],
+                                               double (&res)[TW_JT],
+                                               const PsibRange &rg PM_TICK_PARAM) {
   double term[TW_JT];
   if (n < 8) {
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) res[j] = 0.;
     for (int k = k0; k < k0 + n; ++k) {
-      psib_cell_terms(top[k], dd[k], yy[k], u[k], bg, term);
+      psib_cell_terms(psib_load_cell(cells, k), bg, term);
 #pragma unroll
       for (int j = 0; j < TW_JT; ++j) res[j] += term[j];
     }
     return;
   }
+  const int lane = threadIdx.x & 63;
+  const int ng = n >> 3, g0 = k0 >> 3;  // ng <= 16
+  const bool mine = lane < ng;
+  const double vgb = rg.gbot[g0 + (mine ? lane : 0)], vgt = rg.gtop[g0 + (mine ? lane : 0)];
+  const unsigned long long ones = __ballot(mine && rg.gmax <= vgb);
+  const unsigned long long zero = __ballot(mine && rg.gmin >= vgt) & ~ones;
+  const unsigned long long irr = __ballot(mine && vgb == -__builtin_inf());
+  auto kind_of = [&](int g) -> int {
+    return ((ones >> g) & 1ull) ? 2 : (((zero >> g) & 1ull) ? 3 : (((irr >> g) & 1ull) ? 1 : 0));
+  };
   double r[8][TW_JT];
-  {  // first group of 8 initialises the accumulators (k0 is a multiple of 8)
-    const double gb = tw_uniform(rg.gbot[k0 >> 3]), gt = tw_uniform(rg.gtop[k0 >> 3]);
-    if (rg.gmax <= gb) {
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const double uk = u[k0 + a];
-#pragma unroll
-        for (int j = 0; j < TW_JT; ++j) r[a][j] = uk;
-      }
-    } else if (rg.gmin >= gt) {
-#pragma unroll
-      for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int j = 0; j < TW_JT; ++j) r[a][j] = 0.;
-    } else {
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        psib_cell_terms(top[k0 + a], dd[k0 + a], yy[k0 + a], u[k0 + a], bg, term);
-#pragma unroll
-        for (int j = 0; j < TW_JT; ++j) r[a][j] = term[j];
-      }
-    }
-  }
-  const int nfull = n - (n % 8);
-  for (int k = 8; k < nfull; k += 8) {
-    const int g = (k0 + k) >> 3;
-    const double gb = tw_uniform(rg.gbot[g]), gt = tw_uniform(rg.gtop[g]);
-    if (rg.gmax <= gb) {
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const double uk = u[k0 + k + a];
-#pragma unroll
-        for (int j = 0; j < TW_JT; ++j) r[a][j] += uk;
-      }
-    } else if (rg.gmin >= gt) {
-      // all masks 0: the group adds zeros
-    } else {
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const int kk = k0 + k + a;
-        psib_cell_terms(top[kk], dd[kk], yy[kk], u[kk], bg, term);
-#pragma unroll
-        for (int j = 0; j < TW_JT; ++j) r[a][j] += term[j];
-      }
-    }
+  psib_group<false>(cells, k0, kind_of(0), bg, r PM_TICK_ARG);  // initialises the accumulators
+  unsigned long long todo = ~zero & ((1ull << ng) - 1ull) & ~1ull;
+  while (todo != 0ull) {
+    const int g = __builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    psib_group<true>(cells, k0 + 8 * g, kind_of(g), bg, r PM_TICK_ARG);
   }
 #pragma unroll
   for (int j = 0; j < TW_JT; ++j)
     res[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) +
              ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
-  for (int k = nfull; k < n; ++k) {
-    psib_cell_terms(top[k0 + k], dd[k0 + k], yy[k0 + k], u[k0 + k], bg, term);
+  for (int k = (ng << 3); k < n; ++k) {
+    psib_cell_terms(psib_load_cell(cells, k0 + k), bg, term);
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) res[j] += term[j];
   }
@@ -198,60 +242,63 @@ __device__ __forceinline__ void psib_block_sum(const double *top, const double *
 
 // out-of-line copy for the recursive (nz > 129) path: 16 inlined copies per kernel cost
 // minutes of compile time and every register
-__device__ __noinline__ void psib_block_sum_call(const double *top, const double *dd,
-                                                 const double *yy, const double *u, int k0,
-                                                 int n, const double (&bg)[TW_JT],
-                                                 double (&res)[TW_JT], const PsibRange &rg) {
-  psib_block_sum(top, dd, yy, u, k0, n, bg, res, rg);
+__device__ __noinline__ void psib_block_sum_call(const double *cells, int k0, int n,
+                                                 const double (&bg)[TW_JT],
+                                                 double (&res)[TW_JT],
+                                                 const PsibRange &rg PM_TICK_PARAM) {
+  psib_block_sum(cells, k0, n, bg, res, rg PM_TICK_ARG);
 }
 
 // np.add.reduce pairwise recursion (blocks of <= 128, left half rounded down to a
 // multiple of 8).  D bounds the recursion depth: D=4 covers n <= 128*16.
 template <int D>
-__device__ __forceinline__ void psib_pairwise(const double *top, const double *dd,
-                                              const double *yy, const double *u, int k0,
-                                              int n, const double (&bg)[TW_JT],
-                                              double (&res)[TW_JT], const PsibRange &rg) {
+__device__ __forceinline__ void psib_pairwise(const double *cells, int k0, int n,
+                                              const double (&bg)[TW_JT], double (&res)[TW_JT],
+                                              const PsibRange &rg PM_TICK_PARAM) {
   if constexpr (D == 0) {
-    psib_block_sum_call(top, dd, yy, u, k0, n, bg, res, rg);
+    psib_block_sum_call(cells, k0, n, bg, res, rg PM_TICK_ARG);
   } else {
     if (n <= 128) {
-      psib_block_sum_call(top, dd, yy, u, k0, n, bg, res, rg);
+      psib_block_sum_call(cells, k0, n, bg, res, rg PM_TICK_ARG);
       return;
     }
     int n2 = n / 2;
     n2 -= n2 % 8;
     double l[TW_JT], r[TW_JT];
-    psib_pairwise<D - 1>(top, dd, yy, u, k0, n2, bg, l, rg);
-    psib_pairwise<D - 1>(top, dd, yy, u, k0 + n2, n - n2, bg, r, rg);
+    psib_pairwise<D - 1>(cells, k0, n2, bg, l, rg PM_TICK_ARG);
+    psib_pairwise<D - 1>(cells, k0 + n2, n - n2, bg, r, rg PM_TICK_ARG);
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) res[j] = l[j] + r[j];
   }
 }
 
-// in-place exclusive running sum in index order: s[i] <- sum_{k<i} s[k], i = 0..n-1
-// (s[n-1] on entry is ignored).  Every lane executes it redundantly (wave-uniform LDS
-// addresses broadcast); returns the total s[0]+...+s[n-2].
-__device__ __forceinline__ double serial_prefix_inplace(double *s, int n) {
+// Exclusive running sum in index order of a sequence held in registers (element i = lane
+// i / P, slot i % P; elements >= n-1 are ignored): s[i] <- sum_{k<i} d_k for i = 0..n-1, in LDS;
+// returns the total d_0 + ... + d_{n-2}.  The order ((d0 + d1) + d2) + ... is part of the
+// result (bit-identity with the oracle), so the chain is serial -- but it runs on v_readlane
+// broadcasts and lane 0's fire-and-forget stores: no LDS round trip inside the loop.  (The
+// first version read the sequence back from LDS four elements at a time and waited out a
+// round trip per group: 100 cycles per element, a fifth of the kernel.)
+template <int P>
+__device__ __forceinline__ double serial_prefix_lanes(const double (&d)[P], double *s, int n,
+                                                      int lane) {
   double acc = 0.;
-  int i = 0;
-  for (; i + 4 <= n - 1; i += 4) {
-    const double d0 = s[i], d1 = s[i + 1], d2 = s[i + 2], d3 = s[i + 3];
-    s[i] = acc;
-    acc = acc + d0;
-    s[i + 1] = acc;
-    acc = acc + d1;
-    s[i + 2] = acc;
-    acc = acc + d2;
-    s[i + 3] = acc;
-    acc = acc + d3;
+  const int nfull = (n - 1) / P;  // lanes whose P elements all count
+  // branch-free body: every lane stores the same word (an exec-masked store would cost two
+  // branches per element)
+  for (int L = 0; L < nfull; ++L) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      s[L * P + p] = acc;
+      acc = acc + lane_value(d[p], L);
+    }
   }
-  for (; i < n - 1; ++i) {
-    const double d = s[i];
-    s[i] = acc;
-    acc = acc + d;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {  // the last, partial lane
+    const int i = nfull * P + p;
+    if (i < n) s[i] = acc;
+    if (i < n - 1) acc = acc + lane_value(d[p], nfull);
   }
-  s[n - 1] = acc;
   return acc;
 }
 
@@ -266,16 +313,16 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
   const int m = m_ok ? m_raw : a.n - 1;
   const int nz = a.nz, nb = a.nb;
   const int ngrp = (nz + 7) >> 3;
-  const int per_wave = 4 * nz + nb + 2 * ngrp;
-  double *s_a = lds_all + (size_t)wave * per_wave;  // [nz]  increments / top
-  double *s_b = s_a + nz;                           // [nz]  d = top - bot
-  double *s_c = s_b + nz;                           // [nz]  u
-  double *s_y = s_c + nz;                           // [nz]  RN(1/d), NaN for degenerate cells
-  double *s_psib = s_y + nz;                        // [nb]
+  const int per_wave = tw_lds_doubles(nz, nb);
+  double *s_cell = lds_all + (size_t)wave * per_wave;  // [nz][TW_CELL] cells of the Psib sum
+  double *s_a = s_cell;                                // [nz]  G of the solve (before Psib)
+  double *s_b = s_a + nz;                              // [nz]  I of the solve
+  double *s_psib = s_cell + TW_CELL * nz;              // [nb]
   double *s_gbot = s_psib + nb;                     // [ngrp] min(bot) of each 8-cell group
   double *s_gtop = s_gbot + ngrp;                   // [ngrp] max(top)
   const size_t base = (size_t)m * nz;
 
+  PM_TICK_INIT
   double z[P], zu[P], b1[P], b2[P], b1u[P], b2u[P], Psi[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -291,12 +338,14 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
     Psi[p] = 0.;
   }
 
+  PM_TICK(0)
   if (ops & PM_TW_SOLVE) {
     const double rf = 1. / a.f[m];  // psi_thermwind.py:123
-    double g[P], gu[P], h[P];
+    double g[P], gu[P], h[P], dG[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = lane * P + p;
+      dG[p] = 0.;
       g[p] = rf * (b2[p] - b1[p]);
       gu[p] = rf * (b2u[p] - b1u[p]);
       h[p] = zu[p] - z[p];
@@ -306,23 +355,27 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
         const double b1m = a.b1_mid ? a.b1_mid[base + i] : s1 * (zm - z[p]) + b1[p];
         const double b2m = a.b2_mid ? a.b2_mid[base + i] : s2 * (zm - z[p]) + b2[p];
         const double gm = rf * (b2m - b1m);
-        s_a[i] = h[p] / 6. * (g[p] + gu[p] + 4. * gm);  // dG over [z_i, z_i+1]
+        dG[p] = h[p] / 6. * (g[p] + gu[p] + 4. * gm);  // dG over [z_i, z_i+1]
       }
     }
+    PM_TICK(1)
+    serial_prefix_lanes<P>(dG, s_a, nz, lane);  // s_a[i] = G_i, in level order
+    PM_TICK(2)
     __builtin_amdgcn_wave_barrier();
-    serial_prefix_inplace(s_a, nz);  // s_a[i] = G_i, in level order
-    __builtin_amdgcn_wave_barrier();
+    double dI[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = lane * P + p;
+      dI[p] = 0.;
       if (i < nz - 1) {
         const double Gl = s_a[i], Gu = s_a[i + 1];
         const double Gm = 0.5 * (Gl + Gu) - 0.125 * h[p] * (gu[p] - g[p]);
-        s_b[i] = h[p] / 6. * (Gl + Gu + 4. * Gm);  // dI
+        dI[p] = h[p] / 6. * (Gl + Gu + 4. * Gm);
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    const double Iend = serial_prefix_inplace(s_b, nz);  // s_b[i] = I_i
+    PM_TICK(3)
+    const double Iend = serial_prefix_lanes<P>(dI, s_b, nz, lane);  // s_b[i] = I_i
+    PM_TICK(4)
     __builtin_amdgcn_wave_barrier();
     double Il[P];
 #pragma unroll
@@ -350,7 +403,11 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
     }
   }
 
-  if (!(ops & PM_TW_PSIB)) return;  // wave-uniform
+  PM_TICK(5)
+  if (!(ops & PM_TW_PSIB)) {  // wave-uniform
+    PM_TICK_FLUSH
+    return;
+  }
 
   // ---- Psib (psi_thermwind.py:170-185)
   double mn = b1[0], mx = b1[0];
@@ -372,6 +429,7 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
   Linspace lin;
   lin.init(mn, mx, nb);
 
+  PM_TICK(6)
   const bool range_ok = __builtin_fabs(mn) < 1e100 && __builtin_fabs(mx) < 1e100;
   const double Psi_up0 = from_next_lane(Psi[0]);
 #pragma unroll
@@ -384,11 +442,13 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
       const double top = north ? b2u[p] : b1u[p];
       const double bot = north ? b2[p] : b1[p];
       const double d = top - bot, ad = __builtin_fabs(d);
-      const bool regular = range_ok && ad >= 1e-290 && ad <= 1e290 && __builtin_fabs(top) < 1e100;
-      s_a[k] = top;
-      s_b[k] = d;
-      s_c[k] = u;
-      s_y[k] = regular ? 1.0 / d : __builtin_nan("");
+      // regular: every product of the reciprocal division stays far from over- and underflow
+      const bool regular = range_ok && ad >= 1e-100 && ad <= 1e100 && __builtin_fabs(top) < 1e100;
+      const double yh = regular ? 1.0 / d : __builtin_nan("");
+      double2 *cell = reinterpret_cast<double2 *>(s_cell + (size_t)k * TW_CELL);
+      cell[0] = double2{top, d};
+      cell[1] = double2{yh, recip_lo(d, yh)};
+      cell[2] = double2{u, 0.};
       // staged in the psib row (free until the first pass writes it) for the group ranges
       // a non-finite u_k (user-assigned Psi) must reach the products: 0 * NaN and 0 * inf are
       // NaN in the reference's `mask * udydz` (psi_thermwind.py:183-184), so such a cell bars
@@ -398,6 +458,7 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
     }
   }
   __builtin_amdgcn_wave_barrier();
+  PM_TICK(7)
   const int nc = nz - 1;
   for (int g = lane; g < ngrp; g += 64) {
     double gb = __builtin_inf(), gt = -__builtin_inf();
@@ -408,13 +469,15 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
         const double bk = s_psib[k];
         ok = bk != -__builtin_inf();
         gb = bk < gb ? bk : gb;
-        gt = s_a[k] > gt ? s_a[k] : gt;
+        const double tk = s_cell[(size_t)k * TW_CELL];
+        gt = tk > gt ? tk : gt;
       }
     }
     s_gbot[g] = ok ? gb : -__builtin_inf();  // never "all masks 1"
     s_gtop[g] = ok ? gt : __builtin_inf();   // never "all masks 0"
   }
   __builtin_amdgcn_wave_barrier();
+  PM_TICK(8)
   PsibRange rg;
   rg.gbot = s_gbot;
   rg.gtop = s_gtop;
@@ -431,18 +494,18 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
       rg.gmax = lin.at(ilast < nb ? ilast : nb - 1);
     }
     if constexpr (BIG == 2) {
-      psib_pairwise<4>(s_a, s_b, s_y, s_c, 0, nc, bg, res, rg);
+      psib_pairwise<4>(s_cell, 0, nc, bg, res, rg PM_TICK_ARG);
     } else if constexpr (BIG == 1) {
       // 128 < nc <= 256: NumPy's recursion is exactly two blocks, both inlined
       int n2 = nc / 2;
       n2 -= n2 % 8;
       double r2[TW_JT];
-      psib_block_sum(s_a, s_b, s_y, s_c, 0, n2, bg, res, rg);
-      psib_block_sum(s_a, s_b, s_y, s_c, n2, nc - n2, bg, r2, rg);
+      psib_block_sum(s_cell, 0, n2, bg, res, rg PM_TICK_ARG);
+      psib_block_sum(s_cell, n2, nc - n2, bg, r2, rg PM_TICK_ARG);
 #pragma unroll
       for (int j = 0; j < TW_JT; ++j) res[j] = res[j] + r2[j];
     } else {
-      psib_block_sum(s_a, s_b, s_y, s_c, 0, nc, bg, res, rg);  // nc <= 128: one pairwise block
+      psib_block_sum(s_cell, 0, nc, bg, res, rg PM_TICK_ARG);  // nc <= 128: one pairwise block
     }
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) {
@@ -456,7 +519,11 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
   }
   __builtin_amdgcn_wave_barrier();
 
-  if (!(ops & PM_TW_PSIBZ)) return;
+  PM_TICK(9)
+  if (!(ops & PM_TW_PSIBZ)) {
+    PM_TICK_FLUSH
+    return;
+  }
   // ---- Psibz (psi_thermwind.py:203-208) and the drivers' wA coupling
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -473,11 +540,13 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
       if (a.wA2) a.wA2[base + i] = (-p2) * 1e6;  // -Psi_iso_n * 1e6 (:106)
     }
   }
+  PM_TICK(10)
+  PM_TICK_FLUSH
 }
 
 template <int P, int BIG>
 int launch_thermwind_impl(const pm_thermwind &a, int ops, hipStream_t st) {
-  const size_t per_wave = (size_t)(4 * a.nz + a.nb + 2 * ((a.nz + 7) / 8)) * sizeof(double);
+  const size_t per_wave = (size_t)tw_lds_doubles(a.nz, a.nb) * sizeof(double);
   int wpb = TW_WAVES_PER_BLOCK;
   while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
   const size_t lds = per_wave * wpb;
