@@ -322,15 +322,46 @@ void orc_column_ensemble_steps(const double *z, const double *kappa, const doubl
  * collocation equations reduce to the two running integrals below. */
 /* b1m / b2m: optional b1, b2 at the interval midpoints z[i] + h/2 (callable profiles are
  * evaluated there by solve_bvp); NULL = the np.interp closure of the level values. */
+/* Exclusive running sum s[i] = d[0] + ... + d[i-1], i = 0..nz-1, of n = nz-1 increments in the
+ * order the engine's wave uses (thermwind.hip.h, lane_blocked_scan): element i sits in lane
+ * i / P, slot i % P, P = ceil(nz / 64); every lane sums its slots left to right (r), the 64 lane
+ * totals go through a Hillis-Steele inclusive scan (steps 1, 2, 4, ..., 32: x[l] = x[l-d] + x[l]),
+ * and s[i] = e + r_before with e the total of the lanes to the left.  Any summation order
+ * restates solve_bvp's collocation solution equally well (the reference agrees to 1e-13 either
+ * way); this one needs 6 + P dependent additions instead of nz. */
+static void lane_blocked_scan(const double *d, int n, int nz, double *s) {
+  const int P = (nz + 63) / 64;
+  double x[64], y[64];
+  for (int l = 0; l < 64; ++l) {
+    double r = 0.;
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      r = r + (i < n ? d[i] : 0.);
+    }
+    x[l] = r;
+  }
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    for (int l = 0; l < 64; ++l) y[l] = l >= dd ? x[l - dd] + x[l] : x[l];
+    for (int l = 0; l < 64; ++l) x[l] = y[l];
+  }
+  for (int l = 0; l < 64; ++l) {
+    const double e = l > 0 ? x[l - 1] : 0.;
+    double r = 0.;
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      if (i < nz) s[i] = p == 0 ? e : e + r;
+      r = r + (i < n ? d[i] : 0.);
+    }
+  }
+}
+
 void orc_thermwind_solve_mid(const double *z, const double *b1, const double *b2, int nz,
                              double f, const double *b1m_in, const double *b2m_in,
                              double *Psi) {
   const double rf = 1. / f; /* psi_thermwind.py:123: 1. / self.f * (...) */
-  double *g = (double *)malloc(sizeof(double) * nz * 3);
-  double *G = g + nz, *I = g + 2 * nz;
+  double *g = (double *)malloc(sizeof(double) * nz * 4);
+  double *G = g + nz, *I = g + 2 * nz, *inc = g + 3 * nz;
   for (int i = 0; i < nz; ++i) g[i] = rf * (b2[i] - b1[i]);
-  G[0] = 0.;
-  I[0] = 0.;
   for (int i = 0; i < nz - 1; ++i) {
     const double h = z[i + 1] - z[i];
     const double zm = z[i] + 0.5 * h;
@@ -339,10 +370,15 @@ void orc_thermwind_solve_mid(const double *z, const double *b1, const double *b2
     const double b1m = b1m_in ? b1m_in[i] : s1 * (zm - z[i]) + b1[i];
     const double b2m = b2m_in ? b2m_in[i] : s2 * (zm - z[i]) + b2[i];
     const double gm = rf * (b2m - b1m);
-    G[i + 1] = G[i] + h / 6. * (g[i] + g[i + 1] + 4. * gm);
-    const double Gm = 0.5 * (G[i] + G[i + 1]) - 0.125 * h * (g[i + 1] - g[i]);
-    I[i + 1] = I[i] + h / 6. * (G[i] + G[i + 1] + 4. * Gm);
+    inc[i] = h / 6. * (g[i] + g[i + 1] + 4. * gm); /* G[i+1] - G[i] */
   }
+  lane_blocked_scan(inc, nz - 1, nz, G);
+  for (int i = 0; i < nz - 1; ++i) {
+    const double h = z[i + 1] - z[i];
+    const double Gm = 0.5 * (G[i] + G[i + 1]) - 0.125 * h * (g[i + 1] - g[i]);
+    inc[i] = h / 6. * (G[i] + G[i + 1] + 4. * Gm); /* I[i+1] - I[i] */
+  }
+  lane_blocked_scan(inc, nz - 1, nz, I);
   const double span = z[nz - 1] - z[0];
   for (int i = 0; i < nz; ++i)
     Psi[i] = (I[i] - I[nz - 1] * ((z[i] - z[0]) / span)) / 1e6; /* Sv, :135 */

@@ -1,4 +1,4 @@
-"""Phase clocks of k_thermwind (config 3: 4096 members, nz=100, nb=500).  Needs the profiling
+"""Phase clocks of k_thermwind (CONFIG=3|4|5 ensembles at their BASELINE sizes).  Needs the profiling
 build:  make -B lib EXTRA=-DPM_PHASE_PROFILE ; afterwards  make -B lib  restores the product."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,10 +7,15 @@ import pymoc_amd as gpu
 from pymoc_amd import configs, _lib
 from pymoc_amd.device import DeviceArray
 
-N = int(os.environ.get("N", 4096))
-c = configs.config3(N=N)
-e = gpu.TwoColEnsemble(c)
-e.run(241)
+CONFIG = int(os.environ.get("CONFIG", 3))
+N = int(os.environ.get("N", {3: 4096, 4: 8192, 5: 4096}[CONFIG]))
+if CONFIG == 5:
+  e = gpu.JN2018Ensemble(configs.config5(N=N))
+  e.run(361)
+  e._b_basin, e._b_north = e.cols.b.ptr, e.cols.b.ptr + e._off
+else:
+  e = gpu.TwoColEnsemble(configs.config3(N=N) if CONFIG == 3 else configs.config4(N=N))
+  e.run(241)
 gpu.synchronize()
 out = (C.c_ulonglong * 16)()
 _lib.lib.pm_debug_prof(out)

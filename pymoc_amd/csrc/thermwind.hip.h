@@ -272,34 +272,33 @@ __device__ __forceinline__ void psib_pairwise(const double *cells, int k0, int n
   }
 }
 
-// Exclusive running sum in index order of a sequence held in registers (element i = lane
-// i / P, slot i % P; elements >= n-1 are ignored): s[i] <- sum_{k<i} d_k for i = 0..n-1, in LDS;
-// returns the total d_0 + ... + d_{n-2}.  The order ((d0 + d1) + d2) + ... is part of the
-// result (bit-identity with the oracle), so the chain is serial -- but it runs on v_readlane
-// broadcasts and lane 0's fire-and-forget stores: no LDS round trip inside the loop.  (The
-// first version read the sequence back from LDS four elements at a time and waited out a
-// round trip per group: 100 cycles per element, a fifth of the kernel.)
+// Exclusive running sum of a sequence held in registers (element i = lane i / P, slot i % P;
+// the caller zeroes the slots of elements that do not count): pre[p] <- d_0 + ... + d_{i-1}.
+// Order (restated by the oracle's lane_blocked_scan, so the two stay bit-identical): every
+// lane sums its slots left to right, the lane totals go through a Hillis-Steele inclusive scan
+// (x[l] = x[l-d] + x[l], d = 1, 2, ..., 32), and pre = (total of the lanes to the left) +
+// (running sum inside the lane).  6 + P dependent additions; the first version of the solve
+// ran two ordered 100-term chains through LDS, a quarter of the kernel.
 template <int P>
-__device__ __forceinline__ double serial_prefix_lanes(const double (&d)[P], double *s, int n,
-                                                      int lane) {
-  double acc = 0.;
-  const int nfull = (n - 1) / P;  // lanes whose P elements all count
-  // branch-free body: every lane stores the same word (an exec-masked store would cost two
-  // branches per element)
-  for (int L = 0; L < nfull; ++L) {
+__device__ __forceinline__ void lane_blocked_scan(const double (&d)[P], double (&pre)[P],
+                                                  int lane) {
+  double r = 0.;
+  double run[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      s[L * P + p] = acc;
-      acc = acc + lane_value(d[p], L);
-    }
+  for (int p = 0; p < P; ++p) {
+    run[p] = r;
+    r = r + d[p];
   }
+  double x = r;
 #pragma unroll
-  for (int p = 0; p < P; ++p) {  // the last, partial lane
-    const int i = nfull * P + p;
-    if (i < n) s[i] = acc;
-    if (i < n - 1) acc = acc + lane_value(d[p], nfull);
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    const double o = __shfl_up(x, dd, 64);
+    if (lane >= dd) x = o + x;
   }
-  return acc;
+  double e = __shfl_up(x, 1, 64);
+  if (lane == 0) e = 0.;
+#pragma unroll
+  for (int p = 0; p < P; ++p) pre[p] = (p == 0) ? e : e + run[p];
 }
 
 template <int P, int BIG>
@@ -359,31 +358,29 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
       }
     }
     PM_TICK(1)
-    serial_prefix_lanes<P>(dG, s_a, nz, lane);  // s_a[i] = G_i, in level order
+    double Gl[P];
+    lane_blocked_scan<P>(dG, Gl, lane);  // G at the lane's levels
     PM_TICK(2)
-    __builtin_amdgcn_wave_barrier();
+    const double G_next = from_next_lane(Gl[0]);
     double dI[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = lane * P + p;
       dI[p] = 0.;
       if (i < nz - 1) {
-        const double Gl = s_a[i], Gu = s_a[i + 1];
-        const double Gm = 0.5 * (Gl + Gu) - 0.125 * h[p] * (gu[p] - g[p]);
-        dI[p] = h[p] / 6. * (Gl + Gu + 4. * Gm);
+        const double Gu = (p < P - 1) ? Gl[p + 1 < P ? p + 1 : p] : G_next;
+        const double Gm = 0.5 * (Gl[p] + Gu) - 0.125 * h[p] * (gu[p] - g[p]);
+        dI[p] = h[p] / 6. * (Gl[p] + Gu + 4. * Gm);
       }
     }
     PM_TICK(3)
-    const double Iend = serial_prefix_lanes<P>(dI, s_b, nz, lane);  // s_b[i] = I_i
-    PM_TICK(4)
-    __builtin_amdgcn_wave_barrier();
     double Il[P];
+    lane_blocked_scan<P>(dI, Il, lane);  // I at the lane's levels
+    PM_TICK(4)
+    double Iend = 0.;  // I at the top level nz-1
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int i = lane * P + p;
-      Il[p] = s_b[i < nz ? i : nz - 1];
-    }
-    __builtin_amdgcn_wave_barrier();
+    for (int p = 0; p < P; ++p)
+      if ((nz - 1) % P == p) Iend = lane_value(Il[p], (nz - 1) / P);
     const double z0 = a.z[0], span = a.z[nz - 1] - z0;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
