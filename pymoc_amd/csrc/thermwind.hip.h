@@ -301,8 +301,11 @@ __device__ __forceinline__ void lane_blocked_scan(const double (&d)[P], double (
   for (int p = 0; p < P; ++p) pre[p] = (p == 0) ? e : e + run[p];
 }
 
+// P <= 4 (nz <= 256): held to 128 registers, i.e. 4 waves per SIMD -- BASELINE's 4096-member
+// ensembles then run as ONE batch of resident waves (at 135 registers config 5 ran 3 + 1)
 template <int P, int BIG>
-__global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermwind a,
+__global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK)
+__attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermwind(pm_thermwind a,
                                                                        int ops) {
   extern __shared__ double lds_all[];
   const int lane = threadIdx.x & 63;
@@ -544,8 +547,17 @@ __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK) void k_thermwind(pm_thermw
 template <int P, int BIG>
 int launch_thermwind_impl(const pm_thermwind &a, int ops, hipStream_t st) {
   const size_t per_wave = (size_t)tw_lds_doubles(a.nz, a.nb) * sizeof(double);
-  int wpb = TW_WAVES_PER_BLOCK;
-  while (wpb > 1 && per_wave * wpb > 160 * 1024) wpb >>= 1;
+  // waves per block: as many of TW_WAVES_PER_BLOCK, .../2, 1 as keeps the most waves on a CU
+  // (nz = 200: 14 KB per wave -- blocks of 4 would leave room for 8 waves, single waves for 11)
+  int wpb = 1, best = 0;
+  for (int w = TW_WAVES_PER_BLOCK; w >= 1; w >>= 1) {
+    int resident = (int)((160 * 1024) / (per_wave * w)) * w;
+    resident = resident > 16 ? 16 : resident;  // 4 waves per SIMD is all the registers allow
+    if (resident > best) {
+      best = resident;
+      wpb = w;
+    }
+  }
   const size_t lds = per_wave * wpb;
   if (lds > 160 * 1024) return fail(PM_EINVAL, "thermwind needs %zu B of LDS per member", lds);
   if (lds > 64 * 1024)
