@@ -301,11 +301,13 @@ __device__ __forceinline__ void lane_blocked_scan(const double (&d)[P], double (
   for (int p = 0; p < P; ++p) pre[p] = (p == 0) ? e : e + run[p];
 }
 
-// P <= 4 (nz <= 256): held to 128 registers, i.e. 4 waves per SIMD -- BASELINE's 4096-member
-// ensembles then run as ONE batch of resident waves (at 135 registers config 5 ran 3 + 1)
+// P <= 2 (nz <= 128): held to 128 registers, i.e. 4 waves per SIMD -- BASELINE's 4096-member
+// ensembles then run as ONE batch of resident waves.  (nz = 200 needs 135; capping it at 128
+// with 8 spilled registers, and laying the psib row over the cells so that 16 waves fit the
+// LDS, both left config 5's 165 us unchanged.)
 template <int P, int BIG>
 __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK)
-__attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermwind(pm_thermwind a,
+__attribute__((amdgpu_waves_per_eu((P <= 2 && BIG != 2) ? 4 : 1))) void k_thermwind(pm_thermwind a,
                                                                        int ops) {
   extern __shared__ double lds_all[];
   const int lane = threadIdx.x & 63;
