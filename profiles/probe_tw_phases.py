@@ -32,3 +32,15 @@ for n, x in zip(names, v[:11]):
   print("%-20s %8.0f cycles per member-update  %5.1f %%" % (n, x / v[15], 100 * x / tot))
 print("8-cell groups per member-update after the first of a block: general %.1f, all-ones %.1f, all-zeros %.1f"
       % (v[11] / v[15], v[12] / v[15], v[13] / v[15]))
+
+# timeline of the last launch: wave start / end on the 100 MHz clock
+if hasattr(_lib.lib, "pm_debug_wave_times"):
+  wt = (C.c_ulonglong * (2 * N))()
+  _lib.lib.pm_debug_wave_times(wt, N)
+  w = np.array(list(wt), dtype=np.float64).reshape(N, 2) * 1e-2  # us
+  t0 = w[:, 0].min()
+  st, en = w[:, 0] - t0, w[:, 1] - t0
+  print("waves: %d; start min/median/max %.1f / %.1f / %.1f us; end median/max %.1f / %.1f us; lifetime median %.1f us"
+        % (N, st.min(), np.median(st), st.max(), np.median(en), en.max(), np.median(en - st)))
+  hist, edges = np.histogram(st, bins=10)
+  print("start-time histogram:", list(zip(np.round(edges[:-1], 1), hist)))

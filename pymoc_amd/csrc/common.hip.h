@@ -111,6 +111,15 @@ __device__ __forceinline__ double div_by_recip2(double a, double d, double yh, d
 // with `PM_TICK_FLUSH` (a sample of the waves reports; slot 15 counts the reports).
 #ifdef PM_PHASE_PROFILE
 __device__ unsigned long long pm_prof[16];
+// start / end of every wave on the constant 100 MHz clock (PM_WAVE_BEGIN / PM_WAVE_END(id)):
+// the timeline shows whether a grid ran as one batch of resident waves or several
+__device__ unsigned long long pm_wave_times[2 * 16384];
+#define PM_WAVE_BEGIN const unsigned long long pm_t0 = wall_clock64();
+#define PM_WAVE_END(id)                                             \
+  if ((threadIdx.x & 63) == 0 && (id) < 16384) {                    \
+    pm_wave_times[2 * (id)] = pm_t0;                                \
+    pm_wave_times[2 * (id) + 1] = wall_clock64();                   \
+  }
 #define PM_TICK_INIT                                             \
   unsigned long long pm_acc[16] = {0};                           \
   unsigned long long pm_tprev = __builtin_readcyclecounter();
@@ -130,6 +139,8 @@ __device__ unsigned long long pm_prof[16];
 #define PM_TICK_PARAM , unsigned long long &pm_tprev, unsigned long long (&pm_acc)[16]
 #define PM_TICK_ARG , pm_tprev, pm_acc
 #else
+#define PM_WAVE_BEGIN
+#define PM_WAVE_END(id)
 #define PM_TICK_INIT
 #define PM_TICK(k)
 #define PM_COUNT(k)

@@ -543,4 +543,8 @@ extern "C" int pm_debug_prof(unsigned long long *out16) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(pm::pm_prof), zero, sizeof(zero)) != hipSuccess) return -1;
   return 0;
 }
+extern "C" int pm_debug_wave_times(unsigned long long *out, int n) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pm::pm_wave_times), sizeof(unsigned long long) * 2 * n) != hipSuccess) return -1;
+  return 0;
+}
 #endif

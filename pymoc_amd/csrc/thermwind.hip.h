@@ -327,6 +327,7 @@ __attribute__((amdgpu_waves_per_eu((P <= 2 && BIG != 2) ? 4 : 1))) void k_thermw
   const size_t base = (size_t)m * nz;
 
   PM_TICK_INIT
+  PM_WAVE_BEGIN
   double z[P], zu[P], b1[P], b2[P], b1u[P], b2u[P], Psi[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -483,7 +484,19 @@ __attribute__((amdgpu_waves_per_eu((P <= 2 && BIG != 2) ? 4 : 1))) void k_thermw
   PsibRange rg;
   rg.gbot = s_gbot;
   rg.gtop = s_gtop;
-  for (int i0 = 0; i0 < nb; i0 += 64 * TW_JT) {
+  // A NaN anywhere in b1 / b2 makes bgrid all NaN (np.min / np.max propagate it), every mask
+  // NaN and every class sum NaN -- a blown-up member (the reference loses two of config 5's
+  // 4096) would otherwise drag all nb x (nz-1) pairs through the IEEE-division path and decide
+  // the kernel's duration: 165 us instead of 120 us in config 5.
+  const bool all_nan = mn != mn;  // wave-uniform
+  if (all_nan) {
+    for (int i = lane; i < nb; i += 64) {
+      s_psib[i] = __builtin_nan("");
+      if (m_ok && a.psib) a.psib[(size_t)m * nb + i] = __builtin_nan("");
+      if (m_ok && a.bgrid) a.bgrid[(size_t)m * nb + i] = lin.at(i);
+    }
+  }
+  for (int i0 = 0; i0 < (all_nan ? 0 : nb); i0 += 64 * TW_JT) {
     double bg[TW_JT], res[TW_JT];
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) {
@@ -544,6 +557,7 @@ __attribute__((amdgpu_waves_per_eu((P <= 2 && BIG != 2) ? 4 : 1))) void k_thermw
   }
   PM_TICK(10)
   PM_TICK_FLUSH
+  PM_WAVE_END(m_raw)
 }
 
 template <int P, int BIG>
