@@ -78,10 +78,17 @@ constexpr int TW_CELL = 6;
 struct PsibCell {
   double top, d, yh, yl, u;
 };
-// LDS doubles per wave: cells, the psib row, two group-range rows; even, so that every wave's
-// cells stay 16-byte aligned
+// The psib row (nb doubles, read by Psibz) overlays the cells when the class passes' results
+// fit in registers (<= TW_HELD passes): they are written once the last pass has read the cells.
+// Only where it buys residency: nz > 128 (smaller grids keep 16 waves on a CU anyway).
+constexpr int TW_HELD = 4;
+__host__ __device__ inline bool tw_overlay(int nz, int nb) {
+  return nz > 128 && nb <= 64 * TW_JT * TW_HELD && nb <= TW_CELL * nz;
+}
+// LDS doubles per wave: cells, the psib row unless overlaid, two group-range rows; even, so
+// that every wave's cells stay 16-byte aligned
 __host__ __device__ inline int tw_lds_doubles(int nz, int nb) {
-  return (TW_CELL * nz + nb + 2 * ((nz + 7) / 8) + 1) & ~1;
+  return (TW_CELL * nz + (tw_overlay(nz, nb) ? 0 : nb) + 2 * ((nz + 7) / 8) + 1) & ~1;
 }
 __device__ __forceinline__ PsibCell psib_load_cell(const double *cells, int k) {
   const double2 *c = reinterpret_cast<const double2 *>(cells + (size_t)k * TW_CELL);
@@ -307,7 +314,7 @@ __device__ __forceinline__ void lane_blocked_scan(const double (&d)[P], double (
 // LDS, both left config 5's 165 us unchanged.)
 template <int P, int BIG>
 __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK)
-__attribute__((amdgpu_waves_per_eu((P <= 2 && BIG != 2) ? 4 : 1))) void k_thermwind(pm_thermwind a,
+__attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermwind(pm_thermwind a,
                                                                        int ops) {
   extern __shared__ double lds_all[];
   const int lane = threadIdx.x & 63;
@@ -321,8 +328,9 @@ __attribute__((amdgpu_waves_per_eu((P <= 2 && BIG != 2) ? 4 : 1))) void k_thermw
   double *s_cell = lds_all + (size_t)wave * per_wave;  // [nz][TW_CELL] cells of the Psib sum
   double *s_a = s_cell;                                // [nz]  G of the solve (before Psib)
   double *s_b = s_a + nz;                              // [nz]  I of the solve
-  double *s_psib = s_cell + TW_CELL * nz;              // [nb]
-  double *s_gbot = s_psib + nb;                     // [ngrp] min(bot) of each 8-cell group
+  const bool overlay = P >= 3 && tw_overlay(nz, nb);
+  double *s_psib = overlay ? s_cell : s_cell + TW_CELL * nz;  // [nb]
+  double *s_gbot = s_cell + TW_CELL * nz + (overlay ? 0 : nb);  // [ngrp] min(bot) of each 8-cell group
   double *s_gtop = s_gbot + ngrp;                   // [ngrp] max(top)
   const size_t base = (size_t)m * nz;
 
@@ -451,13 +459,12 @@ __attribute__((amdgpu_waves_per_eu((P <= 2 && BIG != 2) ? 4 : 1))) void k_thermw
       double2 *cell = reinterpret_cast<double2 *>(s_cell + (size_t)k * TW_CELL);
       cell[0] = double2{top, d};
       cell[1] = double2{yh, recip_lo(d, yh)};
-      cell[2] = double2{u, 0.};
-      // staged in the psib row (free until the first pass writes it) for the group ranges
-      // a non-finite u_k (user-assigned Psi) must reach the products: 0 * NaN and 0 * inf are
+      // sixth slot: bot for the group ranges, -inf for a cell that bars its group from the
+      // shortcuts.  A non-finite u_k (user-assigned Psi) must reach the products: 0 * NaN and 0 * inf are
       // NaN in the reference's `mask * udydz` (psi_thermwind.py:183-184), so such a cell bars
       // its group from both shortcuts like a degenerate cell does
       const bool ufin = __builtin_fabs(u) <= 1.7976931348623157e308;
-      if (nb >= nz) s_psib[k] = (regular && d > 0. && ufin) ? bot : -__builtin_inf();
+      cell[2] = double2{u, (regular && d > 0. && ufin) ? bot : -__builtin_inf()};
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -469,7 +476,7 @@ __attribute__((amdgpu_waves_per_eu((P <= 2 && BIG != 2) ? 4 : 1))) void k_thermw
     for (int a = 0; a < 8; ++a) {
       const int k = g * 8 + a;
       if (k < nc && ok) {
-        const double bk = s_psib[k];
+        const double bk = s_cell[(size_t)k * TW_CELL + 5];
         ok = bk != -__builtin_inf();
         gb = bk < gb ? bk : gb;
         const double tk = s_cell[(size_t)k * TW_CELL];
@@ -489,6 +496,12 @@ __attribute__((amdgpu_waves_per_eu((P <= 2 && BIG != 2) ? 4 : 1))) void k_thermw
   // 4096) would otherwise drag all nb x (nz-1) pairs through the IEEE-division path and decide
   // the kernel's duration: 165 us instead of 120 us in config 5.
   const bool all_nan = mn != mn;  // wave-uniform
+  double held[TW_HELD][TW_JT];
+#pragma unroll
+  for (int q = 0; q < TW_HELD; ++q)
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) held[q][j] = __builtin_nan("");
+  if (all_nan && overlay) __builtin_amdgcn_wave_barrier();
   if (all_nan) {
     for (int i = lane; i < nb; i += 64) {
       s_psib[i] = __builtin_nan("");
@@ -526,13 +539,30 @@ __attribute__((amdgpu_waves_per_eu((P <= 2 && BIG != 2) ? 4 : 1))) void k_thermw
     for (int j = 0; j < TW_JT; ++j) {
       const int i = i0 + j * 64 + lane;
       if (i < nb) {
-        s_psib[i] = res[j];
+        if (!overlay) s_psib[i] = res[j];
         if (m_ok && a.psib) a.psib[(size_t)m * nb + i] = res[j];
         if (m_ok && a.bgrid) a.bgrid[(size_t)m * nb + i] = bg[j];
       }
     }
+    if (overlay) {  // wave-uniform pass index: a scalar select per slot
+      const int ps = i0 / (64 * TW_JT);
+#pragma unroll
+      for (int q = 0; q < TW_HELD; ++q)
+#pragma unroll
+        for (int j = 0; j < TW_JT; ++j) held[q][j] = (q == ps) ? res[j] : held[q][j];
+    }
   }
   __builtin_amdgcn_wave_barrier();
+  if (overlay && !all_nan) {  // the cells are dead: the psib row takes their place
+#pragma unroll
+    for (int q = 0; q < TW_HELD; ++q)
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) {
+        const int i = (q * TW_JT + j) * 64 + lane;
+        if (i < nb) s_psib[i] = held[q][j];
+      }
+    __builtin_amdgcn_wave_barrier();
+  }
 
   PM_TICK(9)
   if (!(ops & PM_TW_PSIBZ)) {
