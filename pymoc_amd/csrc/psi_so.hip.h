@@ -715,6 +715,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   const int m = m_ok ? m_raw : a.n - 1;
   const int nz = a.nz, ny = a.ny;
   PM_TICK_INIT
+  PM_WAVE_BEGIN
   const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
   const bool tau_arr = (a.flags & PM_SO_TAU_ARRAY) != 0;
   const bool adaptive = has_c && a.bvp_refine <= 0;
@@ -1101,6 +1102,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   }
   PM_TICK(10)
   PM_TICK_FLUSH
+  PM_WAVE_END(m_raw)
 }
 
 template <int P>

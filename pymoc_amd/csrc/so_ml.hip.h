@@ -615,6 +615,7 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
   const bool m_ok = m_raw < a.n;
   const int m = m_ok ? m_raw : a.n - 1;
   const int n = a.n, nz = a.cols.nz, ny = a.ml.ny;
+  PM_WAVE_BEGIN
   const pm_columns &c = a.cols;
   MlLds w;
   w.carve(lds_all + (size_t)wave * MlLds::doubles(nz, ny), nz, ny);
@@ -795,6 +796,7 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
     }
     if (a.ml.status) a.ml.status[m] = status | (anybad ? 2 : 0);
   }
+  PM_WAVE_END(m_raw)
 }
 
 inline size_t ml_lds_bytes(int nz, int ny) {
