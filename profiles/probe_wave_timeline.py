@@ -29,7 +29,8 @@ if CONFIG == 5:
   b_basin, b_north = e.cols.b.ptr, e.cols.b.ptr + e._off
   e.so.update(b_basin, e.ml.bs); gpu.synchronize(); timeline("k_psi_so", N)
   e.tw.update(b_basin, b_north, store_psib=False); gpu.synchronize(); timeline("k_thermwind", N)
-  e.run(36); gpu.synchronize(); timeline("k_jn2018_steps", N)
+  e.run(35); gpu.synchronize()   # to the MOC boundary: the next launch fuses a whole interval
+  e.run(36); gpu.synchronize(); timeline("k_jn2018_steps x36", N)
 else:
   N = 8192 if CONFIG == 4 else 4096
   e = gpu.TwoColEnsemble(configs.config4(N=N) if CONFIG == 4 else configs.config3(N=N))
