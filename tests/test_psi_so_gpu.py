@@ -316,3 +316,35 @@ def test_config4_full_length_sweep_adaptive_mesh(gpu):
     s = drivers.run_twocol(configs.member(c, i, 4), 2400, {2400}, so=True)[2400]
     for k in ("b_basin", "Psi", "Psi_SO"):
       assert relerr(st[k][i], s[k]) <= 1e-10, (i, k)
+
+
+def test_gm_adaptive_mesh_tall_grid_vs_oracle(gpu):
+  """nz > 128 takes the general adaptive kernel (chunks through LDS scratch, meshes up to
+  solve_bvp's 1000 nodes): the golden BVP cases re-sampled on 160 and 257 levels against the
+  oracle's solve_bvp restatement."""
+  from pymoc_amd.device import DeviceArray
+  g = load_golden("psi_so")
+  seen = 0
+  for k in range(int(g["ncases"])):
+    p = "c%02d_" % k
+    kw = _kwargs(g, p)
+    if kw["c"] is None or g[p + "tau"].ndim != 0:
+      continue
+    seen += 1
+    for nz in (160, 257):
+      z0, b0 = g[p + "z"], g[p + "b"]
+      z = np.linspace(z0[0], z0[-1], nz)
+      b = np.interp(z, z0, b0)
+      kw2 = dict(kw)
+      KGM = kw2.pop("KGM")
+      tau = float(g[p + "tau"])
+      t = gpu.PsiSOBatch(z, g[p + "y"], 2, tau=tau, KGM=KGM, **kw2)
+      t.update(DeviceArray.from_host(np.stack([b] * 2)), DeviceArray.from_host(np.stack([g[p + "bs"]] * 2)))
+      GM = t.Psi_GM.download()
+      oPsi, oEk, oGM, _ = O.psi_so_solve(z, g[p + "y"], b, g[p + "bs"], tau, KGM=KGM, **kw2)
+      assert np.array_equal(GM[0], GM[1])
+      assert relerr(GM[0], oGM) <= TOL_BVP_ADAPT, (k, nz)
+      assert np.all(t.status.download() & 10 == 0)
+    if seen >= 4:
+      break
+  assert seen >= 3
