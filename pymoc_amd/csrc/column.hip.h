@@ -13,6 +13,7 @@
 // The 3-point stencil needs one value from each neighbour lane per step (b of the
 // level above, bz of the interface below): two DPP wave shifts, no LDS, no barrier.
 #pragma once
+#include <type_traits>
 #include "common.hip.h"
 
 namespace pm {
@@ -472,7 +473,7 @@ __device__ __forceinline__ int conv_spec_run(const ColGrid<P> &g, ColRegs<P> &r,
                                              const double (&wA)[P], double dt, double bs,
                                              double bbot, double N2min, int lane, int nz,
                                              ConvCache<P> &cc, int s, int nsteps) {
-  constexpr int UNR = P <= 2 ? 4 : (P <= 4 ? 2 : 1);
+  constexpr int UNR = P <= 2 ? 16 : (P <= 4 ? 2 : 1);
   double adjv[P];    // column.py:268 for the cached zconv: changes only with the pattern
   double bs_eff[P];  // bs for real levels, +inf for padding: `b > bs_eff` is the whole test
   // Level 0 always ends a step's convect + boundary condition holding bbot (column.py:232
@@ -554,41 +555,40 @@ __device__ __forceinline__ int conv_spec_run(const ColGrid<P> &g, ColRegs<P> &r,
       col_vertadvdiff<64, P, DIV, false>(g, r, wA, dt, true, bs, bbot, false, 0., lane, nz);
     }
   };
-  // full blocks; the only loop-carried scalar is the count of blocks left.  Single-exit loops
-  // (a `return` inside makes the compiler wrap the hot path in flag logic): a pattern of
-  // another SEL class ends the loop through its own counter.
-  int left = (nsteps - s) / UNR;
-  const int s_full = s + left * UNR;
-  int ret = -1;
-  for (; left > 0; --left) {
-    block_begin();
+  // Blocks of UNR steps, then of 4, then of 1.  The only loop-carried scalar of a tier is the count of blocks left;
+  // single-exit loops (a `return` inside makes the compiler wrap the hot path in flag logic): a
+  // pattern of another SEL class ends the loop through its own counter.
+  int pos = s, ret = -1;
+  auto tier = [&](auto U) {
+    constexpr int N = decltype(U)::value;
+    int left = (nsteps - pos) / N;
+    const int s_end = pos + left * N;
+    for (; left > 0; --left) {
+      block_begin();
 #pragma unroll
-    for (int k = 0; k < UNR; ++k) spec();
-    if (__builtin_expect(block_bad(), 0)) {
-      redo(UNR);
-      if (conv_variant<P>(cc) != SEL) {
-        ret = s_full - (left - 1) * UNR;
-        left = 1;
-      } else {
-        set_adj();
+      for (int k = 0; k < N; ++k) spec();
+      if (__builtin_expect(block_bad(), 0)) {
+        redo(N);
+        if (conv_variant<P>(cc) != SEL) {
+          ret = s_end - (left - 1) * N;
+          left = 1;
+        } else {
+          set_adj();
+        }
       }
     }
-  }
+    pos = s_end;
+  };
+  // the long blocks only in long launches: a pattern change redoes the whole block, and the
+  // coupled drivers' 24-step launches (new forcing, hence often a new pattern, every launch)
+  // came out 9 % slower with them
+  if (UNR <= 4 || nsteps - pos >= 4 * UNR) tier(std::integral_constant<int, UNR>{});
   if (ret >= 0) return ret;
-  left = nsteps - s_full;
-  for (; left > 0; --left) {  // tail: blocks of one step
-    block_begin();
-    spec();
-    if (__builtin_expect(block_bad(), 0)) {
-      redo(1);
-      if (conv_variant<P>(cc) != SEL) {
-        ret = nsteps - (left - 1);
-        left = 1;
-      } else {
-        set_adj();
-      }
-    }
+  if constexpr (UNR > 4) {
+    tier(std::integral_constant<int, 4>{});
+    if (ret >= 0) return ret;
   }
+  if constexpr (UNR > 1) tier(std::integral_constant<int, 1>{});
   return ret >= 0 ? ret : nsteps;
 }
 
