@@ -705,7 +705,9 @@ __device__ __forceinline__ int so_gm_adaptive_reg(const SoRegMesh &w, int nz, do
   return m;
 }
 
-template <int P>
+// BVP: the member batch uses the F2010 boundary-value smoother (c is not None).  Without it
+// (JN2018, config 5) the kernel is a third of the registers and runs 4+ waves per SIMD.
+template <int P, bool BVP>
 __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a, int ops) {
   extern __shared__ double lds_all[];
   const int lane = threadIdx.x & 63;
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   const int nz = a.nz, ny = a.ny;
   PM_TICK_INIT
   PM_WAVE_BEGIN
-  const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
+  const bool has_c = BVP;  // == (a.flags & PM_SO_HAS_C) != 0, checked by the launcher
   const bool tau_arr = (a.flags & PM_SO_TAU_ARRAY) != 0;
   const bool adaptive = has_c && a.bvp_refine <= 0;
   const int per_wave = so_lds_doubles(nz, ny, has_c, adaptive);
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
     }
   }
   int gm_status = 0;
-  if (!has_c) {
+  if constexpr (!BVP) {
 #pragma unroll
     for (int p = 0; p < P; ++p)
       temp[p] = KGM * np_maximum(z[p] / dy[p], -a.smax) * a.L * topt[p] * bott[p];  // :325
@@ -1105,15 +1107,15 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   PM_WAVE_END(m_raw)
 }
 
-template <int P>
-int launch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
-  const bool has_c = (a.flags & PM_SO_HAS_C) != 0;
-  const bool adaptive = has_c && a.bvp_refine <= 0;
-  const size_t per_wave = (size_t)so_lds_doubles(a.nz, a.ny, has_c, adaptive) * sizeof(double);
+template <int P, bool BVP>
+int launch_psi_so_impl(const pm_psi_so &a, int ops, hipStream_t st) {
+  const bool adaptive = BVP && a.bvp_refine <= 0;
+  const size_t per_wave = (size_t)so_lds_doubles(a.nz, a.ny, BVP, adaptive) * sizeof(double);
   // waves per block: as many of SO_WAVES_PER_BLOCK, .../2, 1 as keeps the most waves on a CU
   int wpb = 1, best = 0;
   for (int w = SO_WAVES_PER_BLOCK; w >= 1; w >>= 1) {
-    const int resident = (int)((160 * 1024) / (per_wave * w)) * w;
+    int resident = (int)((160 * 1024) / (per_wave * w)) * w;
+    resident = resident > 32 ? 32 : resident;
     if (resident > best) {
       best = resident;
       wpb = w;
@@ -1122,12 +1124,18 @@ int launch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
   const size_t lds = per_wave * wpb;
   if (lds > 160 * 1024) return fail(PM_EINVAL, "psi_so needs %zu B of LDS per member", lds);
   if (lds > 64 * 1024)
-    PM_HIP(hipFuncSetAttribute((const void *)k_psi_so<P>,
+    PM_HIP(hipFuncSetAttribute((const void *)k_psi_so<P, BVP>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = (unsigned)((a.n + wpb - 1) / wpb);
-  hipLaunchKernelGGL((k_psi_so<P>), dim3(grid), dim3(64 * wpb), lds, st, a, ops);
+  hipLaunchKernelGGL((k_psi_so<P, BVP>), dim3(grid), dim3(64 * wpb), lds, st, a, ops);
   PM_HIP(hipGetLastError());
   return PM_OK;
+}
+
+template <int P>
+int launch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
+  return (a.flags & PM_SO_HAS_C) ? launch_psi_so_impl<P, true>(a, ops, st)
+                                 : launch_psi_so_impl<P, false>(a, ops, st);
 }
 
 inline int dispatch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
