@@ -262,8 +262,12 @@ int pm_jn2018_bc_switch(const pm_jn2018_bc *bc, pm_stream_t stream);
  * pm_column_steps + pm_so_ml_step per step.  `cols` holds 2n columns (basin rows [0,n),
  * north rows [n,2n), nsel = 2, bbot / ksel updated in place); `ml.b_basin` / `ml.Psi_b` are
  * ignored (the basin column and Psi_SO are used).  nz <= 256.                          */
+#define PM_JN_UNIFORM_AREA 1 /* hint: Area(z) of every column is constant in z (true for every
+                                reference script); a kernel variant then keeps it in scalar
+                                registers.  A wrong hint is detected: the launch fails the
+                                members' status with bit 4 (16) and leaves them untouched.  */
 typedef struct pm_jn2018 {
-  int32_t n, reserved0, reserved1, reserved2;
+  int32_t n, hints, reserved1, reserved2;
   pm_columns cols;
   const double *wA;        /* [2n][nz] */
   const double *Psi_SO;    /* [n][nz]  */

@@ -50,6 +50,7 @@ class pm_thermwind(C.Structure):
 (PM_SO_HAS_C, PM_SO_BVP_WITH_EK, PM_SO_HAS_HSILL, PM_SO_HAS_HEK, PM_SO_HAS_HTAPERTOP,
  PM_SO_HAS_HTAPERBOT, PM_SO_TAU_ARRAY) = 1, 2, 4, 8, 16, 32, 64
 PM_SO_OP_EKMAN, PM_SO_OP_GM, PM_SO_OP_SOLVE = 1, 2, 3
+PM_JN_UNIFORM_AREA = 1
 
 
 class pm_psi_so(C.Structure):
@@ -112,7 +113,7 @@ class pm_jn2018_bc(C.Structure):
 class pm_jn2018(C.Structure):
   """Mirror of `struct pm_jn2018` (include/pymoc_hip.h)."""
   _fields_ = [
-      ("n", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32),
+      ("n", C.c_int32), ("hints", C.c_int32), ("reserved1", C.c_int32),
       ("reserved2", C.c_int32), ("cols", pm_columns), ("wA", c_dp), ("Psi_SO", c_dp),
       ("Psi_res_b", c_dp), ("Psi_res_n", c_dp), ("ml", pm_so_ml)
   ]

@@ -89,6 +89,9 @@ class ColumnBatch(object):
         raise ValueError("kappa_alt required for a two-set batch")
       ks.append(_per_col_profile(kappa_alt, ncols, nz))
     self.area.upload(area, self.stream)
+    # every column's Area is constant in z (all reference scripts): lets the fused JN2018
+    # kernel keep it in scalar registers (pm_jn2018.hints)
+    self.uniform_area = bool(np.all(area == area[:, :1]))
     self.kappa.upload(np.stack(ks), self.stream)
     self.dAk.upload(np.stack([dAkappa_dz(area, k, self.z_host) for k in ks]), self.stream)
 

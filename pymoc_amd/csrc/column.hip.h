@@ -34,6 +34,8 @@ struct ColRegs {
   double dAk[P];   // d(Area*kappa)/dz at z_i (np.gradient, host precomputed)
   double rarea[P]; // RN(1/area)
   double rarea_l[P];  // low part of 1/area (DIV == 2)
+  // Area constant in z (UA instantiations): one wave-uniform value instead of the arrays
+  double area_u, rarea_u, rarea_lu;
 };
 
 // P consecutive levels of one column row (`row` points at level 0 of the column) starting at
@@ -216,7 +218,11 @@ __device__ __forceinline__ void col_convect_cached(double (&b)[P], const double 
 // BC = false: the caller has already imposed the (constant) boundary values, which no
 // interior update ever touches -- valid when bzbot is None and the surface value is bs.
 // WEFF: `wA` already holds weff = wA - d(A kappa)/dz (callers that keep it across steps).
-template <int G, int P, int DIV, bool BC = true, bool WEFF = false>
+// UA: Area is constant in z -- r.area_u / rarea_u / rarea_lu replace the per-level arrays.
+// FLUXFMA: the select-free upwind flux (needs wn / wp, two more values per level, which the
+// register-starved fused JN2018 loop cannot afford).
+template <int G, int P, int DIV, bool BC = true, bool WEFF = false, bool UA = false,
+          bool FLUXFMA = (DIV == 2)>
 __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> &r,
                                                 const double (&wA)[P],
                                                 double dt, bool do_conv, double bs,
@@ -287,7 +293,7 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
     bz_dn[p] = (p > 0) ? bz[p > 0 ? p - 1 : 0] : pbz;
     dbz[p] = bz[p] - bz_dn[p];
     const double weff = WEFF ? wA[p] : wA[p] - r.dAk[p];  // column.py:241
-    if constexpr (DIV == 2) {
+    if constexpr (FLUXFMA) {
       // upwind flux (-weff)*bz* (column.py:242-246) without a select: weff is static over
       // the launch, so exactly one of the two factors below is (-weff) and the other 0, and
       // fma(wn, bz, RN(wp*bz_dn)) = RN((-weff)*bz*) -- the unselected product is an exact
@@ -306,29 +312,29 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       r1[p] = dbz[p] * g.rdzc_l[p];
-      r2[p] = flx[p] * r.rarea_l[p];
+      r2[p] = flx[p] * (UA ? r.rarea_lu : r.rarea_l[p]);
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       bzz[p] = __builtin_fma(dbz[p], g.rdzc[p], r1[p]);
-      adv[p] = __builtin_fma(flx[p], r.rarea[p], r2[p]);
+      adv[p] = __builtin_fma(flx[p], (UA ? r.rarea_u : r.rarea[p]), r2[p]);
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       r1[p] = __builtin_fma(-g.dzc[p], bzz[p], dbz[p]);
-      r2[p] = __builtin_fma(-r.area[p], adv[p], flx[p]);
+      r2[p] = __builtin_fma(-(UA ? r.area_u : r.area[p]), adv[p], flx[p]);
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       bzz[p] = __builtin_fma(r1[p], g.rdzc[p], bzz[p]);
-      adv[p] = __builtin_fma(r2[p], r.rarea[p], adv[p]);
+      adv[p] = __builtin_fma(r2[p], (UA ? r.rarea_u : r.rarea[p]), adv[p]);
     }
   } else if constexpr (DIV == 3) {  // grid division by reciprocal, area by IEEE division
     double r1[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       bzz[p] = dbz[p] * g.rdzc[p];
-      adv[p] = flx[p] / r.area[p];
+      adv[p] = flx[p] / (UA ? r.area_u : r.area[p]);
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -342,26 +348,26 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       bzz[p] = dbz[p] * g.rdzc[p];
-      adv[p] = flx[p] * r.rarea[p];
+      adv[p] = flx[p] * (UA ? r.rarea_u : r.rarea[p]);
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         r1[p] = __builtin_fma(-g.dzc[p], bzz[p], dbz[p]);
-        r2[p] = __builtin_fma(-r.area[p], adv[p], flx[p]);
+        r2[p] = __builtin_fma(-(UA ? r.area_u : r.area[p]), adv[p], flx[p]);
       }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         bzz[p] = __builtin_fma(r1[p], g.rdzc[p], bzz[p]);
-        adv[p] = __builtin_fma(r2[p], r.rarea[p], adv[p]);
+        adv[p] = __builtin_fma(r2[p], (UA ? r.rarea_u : r.rarea[p]), adv[p]);
       }
     }
   } else {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       bzz[p] = dbz[p] / g.dzc[p];
-      adv[p] = flx[p] / r.area[p];
+      adv[p] = flx[p] / (UA ? r.area_u : r.area[p]);
     }
   }
 #pragma unroll

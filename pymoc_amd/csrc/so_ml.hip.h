@@ -604,7 +604,9 @@ __device__ __forceinline__ void col_load_coef(ColRegs<P> &r, const pm_columns &c
 }
 
 // SMALLNY (ny <= 64): the mixed layer lives in registers (ml_step_reg); otherwise in LDS.
-template <int P, bool SMALLNY>
+// UA (pm_jn2018.hints & PM_JN_UNIFORM_AREA): Area constant in z -- scalar registers instead of
+// 4 P vector registers per column, which pays for the low parts of the 4-instruction division.
+template <int P, bool SMALLNY, bool UA>
 __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_jn2018 a,
                                                                           double dt,
                                                                           int nsteps) {
@@ -629,9 +631,23 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
   st.ksel_n = c.ksel[coln];
   ColGrid<P> g;
   ColRegs<P> rb, rn;
-  col_load_grid<P>(g, c, lane);
-  col_load_static<P>(rb, c, colb, st.ksel_b, lane);
-  col_load_static<P>(rn, c, coln, st.ksel_n, lane);
+  constexpr int DV = UA ? 2 : 1;  // division form of the column steps
+  col_load_grid<P, DV>(g, c, lane);
+  col_load_static<P, DV>(rb, c, colb, st.ksel_b, lane);
+  col_load_static<P, DV>(rn, c, coln, st.ksel_n, lane);
+  bool hint_ok = true;
+  if constexpr (UA) {
+    rb.area_u = lane_value(rb.area[0], 0);
+    rb.rarea_u = lane_value(rb.rarea[0], 0);
+    rb.rarea_lu = lane_value(rb.rarea_l[0], 0);
+    rn.area_u = lane_value(rn.area[0], 0);
+    rn.rarea_u = lane_value(rn.rarea[0], 0);
+    rn.rarea_lu = lane_value(rn.rarea_l[0], 0);
+    bool same = true;
+#pragma unroll
+    for (int p = 0; p < P; ++p) same = same && rb.area[p] == rb.area_u && rn.area[p] == rn.area_u;
+    hint_ok = __ballot(!same) == 0ull;  // padding lanes hold copies of the top level
+  }
   // weff = wA - d(A kappa)/dz (column.py:241) is static between coefficient-set switches:
   // kept instead of wA and dAkappa (16 registers less for the two columns, 2P subtractions
   // less per step) and rebuilt when the BC switch changes a column's set
@@ -703,7 +719,7 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
   ccb.zconv = ccn.zconv = 0.;
   // lanes / slots holding levels 0 and 1 of a column
   constexpr int L1 = 1 / P, S1 = 1 % P;
-  for (int s = 0; s < nsteps; ++s) {
+  for (int s = 0; s < (hint_ok ? nsteps : 0); ++s) {
     // ---- bottom-BC switch (run_JansenNadeau_2018.py:233-254)
     // levels 0 and 1 of both columns by v_readlane (scalar registers, no LDS round trip)
     const double bb0 = lane_value(rb.b[0], 0), bb1 = lane_value(rb.b[S1], L1);
@@ -715,11 +731,11 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
     if (st.ksel_n != kn) load_coef(rn, weff_n, coln, st.ksel_n);
     // ---- basin.timestep / north.timestep, do_conv=True (:257-258)
     col_convect_cached<P>(rb.b, g.z, bs_b, N2_b, lane, nz, ccb);
-    col_vertadvdiff<64, P, 1, true, true>(g, rb, weff_b, dt, true, bs_b, st.bbot_b, false, 0.,
-                                          lane, nz);
+    col_vertadvdiff<64, P, DV, true, true, UA, false>(g, rb, weff_b, dt, true, bs_b, st.bbot_b,
+                                                      false, 0., lane, nz);
     col_convect_cached<P>(rn.b, g.z, bs_n, N2_n, lane, nz, ccn);
-    col_vertadvdiff<64, P, 1, true, true>(g, rn, weff_n, dt, true, bs_n, st.bbot_n, false, 0.,
-                                          lane, nz);
+    col_vertadvdiff<64, P, DV, true, true, UA, false>(g, rn, weff_n, dt, true, bs_n, st.bbot_n,
+                                                      false, 0., lane, nz);
     // ---- channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi) (:261)
     if (ml_ok) {
       // The workspace pointers are re-derived from an offset the optimiser cannot see through:
@@ -794,7 +810,7 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
       c.nonfinite[colb] = anybad ? 1 : 0;
       c.nonfinite[coln] = anybad ? 1 : 0;
     }
-    if (a.ml.status) a.ml.status[m] = status | (anybad ? 2 : 0);
+    if (a.ml.status) a.ml.status[m] = status | (anybad ? 2 : 0) | (hint_ok ? 0 : 16);
   }
   PM_WAVE_END(m_raw)
 }
@@ -830,19 +846,20 @@ int launch_jn2018_steps(const pm_jn2018 &a, double dt, int nsteps, hipStream_t s
   const size_t lds = per_wave * wpb + prop;
   if (lds > 160 * 1024) return fail(PM_EINVAL, "jn2018 needs %zu B of LDS per member", lds);
   const unsigned grid = (unsigned)((a.n + wpb - 1) / wpb);
-  if (a.ml.ny <= 64) {
+  const bool ua = (a.hints & PM_JN_UNIFORM_AREA) != 0;
+  auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
-      PM_HIP(hipFuncSetAttribute((const void *)k_jn2018_steps<P, true>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_jn2018_steps<P, true>), dim3(grid), dim3(64 * wpb), lds, st, a, dt,
-                       nsteps);
-  } else {
-    if (lds > 64 * 1024)
-      PM_HIP(hipFuncSetAttribute((const void *)k_jn2018_steps<P, false>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_jn2018_steps<P, false>), dim3(grid), dim3(64 * wpb), lds, st, a, dt,
-                       nsteps);
-  }
+      PM_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), lds, st, a, dt, nsteps);
+    return PM_OK;
+  };
+  int rc;
+  if (a.ml.ny <= 64)
+    rc = ua ? go(k_jn2018_steps<P, true, true>) : go(k_jn2018_steps<P, true, false>);
+  else
+    rc = ua ? go(k_jn2018_steps<P, false, true>) : go(k_jn2018_steps<P, false, false>);
+  if (rc != PM_OK) return rc;
   PM_HIP(hipGetLastError());
   return PM_OK;
 }

@@ -319,6 +319,7 @@ class JN2018Ensemble(object):
     from .device import _sh
     d = pm_jn2018()
     d.n = self.n
+    d.hints = _lib.PM_JN_UNIFORM_AREA if self.cols.uniform_area else 0
     d.cols = self.cols.descriptor()
     d.wA, d.Psi_SO = self.wA.ptr, self.so.Psi.ptr
     d.Psi_res_b, d.Psi_res_n = self.tw.psibz1.ptr, self.tw.psibz2.ptr
