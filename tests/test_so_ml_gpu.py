@@ -155,6 +155,34 @@ def test_jn2018_fused_equals_stepwise_bitwise(gpu):
   assert np.array_equal(a.cols.ksel.download(), b.cols.ksel.download())
 
 
+def test_jn2018_fused_area_variants_and_hint_check(gpu):
+  """The fused kernel has a uniform-Area variant (pm_jn2018.hints); with a basin area that
+  varies in z the driver must pick the general variant (still bit-identical to the stepwise
+  launches), and a WRONG hint is detected on the device: members flagged, state untouched."""
+  c = configs.config5(N=64)
+  c["rest_mask"] = np.repeat(c["rest_mask"][None], 64, axis=0)
+  nz = c["z"].size
+  c["A_basin"] = np.broadcast_to(np.asarray(c["A_basin"], dtype=np.float64).reshape(-1, 1),
+                                 (64, 1)) * (1. + 0.2 * np.linspace(0., 1., nz)[None])
+  a = gpu.JN2018Ensemble(c, fused=True)
+  b = gpu.JN2018Ensemble(c, fused=False)
+  assert not a.cols.uniform_area
+  a.run(80)
+  b.run(80)
+  sa, sb = a.state(), b.state()
+  for k in sa:
+    assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+  before = a.cols.get_b().copy()
+  a.cols.uniform_area = True  # lie to the library
+  a.run(5)
+  assert np.all(a.ml.status.download() & 16 == 16)
+  assert np.array_equal(a.cols.get_b(), before, equal_nan=True)
+  u = gpu.JN2018Ensemble(configs.config5(N=64), fused=True)
+  assert u.cols.uniform_area
+  u.run(5)
+  assert np.all(u.ml.status.download() & 16 == 0)
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_config5_sweep_members_vs_reference(gpu, fused):
   g = load_golden("sweep")
