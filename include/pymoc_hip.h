@@ -209,8 +209,9 @@ typedef struct pm_psi_so {
   int32_t *status;      /* [n] out: bit0 bs not monotone north of its minimum (several
                            roots: ys then follows brentq's own iteration, like the
                            reference), bit1 non-finite Psi, bit2 NaN in bs, bit3 the adaptive GM
-                           mesh would exceed the 256 nodes followed on the device (the
-                           solution of the last mesh is returned) (may be NULL)          */
+                           mesh would exceed the nodes followed on the device (256 for
+                           nz <= 128, else solve_bvp's own 1000; the solution of the last
+                           mesh is returned) (may be NULL)                               */
 } pm_psi_so;
 
 int pm_psi_so_update(const pm_psi_so *so, int32_t ops, pm_stream_t stream);
@@ -233,7 +234,8 @@ typedef struct pm_so_ml {
   double Ks, h, L, v_pist;
   int32_t *status;         /* [n] out: 1 where the reference raises IndexError (Psi_b all
                               zero / no upwelling level; state left untouched), 2 non-finite
-                              result (may be NULL)                                      */
+                              result, 16 (pm_jn2018_steps only) a wrong
+                              PM_JN_UNIFORM_AREA hint (may be NULL)                     */
 } pm_so_ml;
 
 int pm_so_ml_step(const pm_so_ml *ml, double dt, pm_stream_t stream);
