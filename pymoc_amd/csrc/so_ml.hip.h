@@ -479,8 +479,8 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_so_ml_step(pm_so_ml
   c.dy = a.y[1] - a.y[0];
   c.s = a.Ks * dt / (c.dy * c.dy);  // :191
   bool ok = ml_prepare(w, nz, lane, first_pos);
-  ml_tables(w, ny, c.s);
   const bool small = ny <= 64;  // block-uniform: register-resident step with PCR diffusion
+  if (!small) ml_tables(w, ny, c.s);  // Thomas factors: only the ordered sweep reads them
   const double *T = nullptr;
   if (small) {
     double *Tw = lds_all + (size_t)(blockDim.x >> 6) * MlLds::doubles(nz, ny);
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK, 2) void k_jn2018_steps(pm_
   mc.s = a.ml.Ks * dt / (mc.dy * mc.dy);
   int first_pos;
   bool ml_ok = ml_prepare(w, nz, lane, first_pos);
-  ml_tables(w, ny, mc.s);
+  if constexpr (!SMALLNY) ml_tables(w, ny, mc.s);  // Thomas factors: only the ordered sweep
   if constexpr (SMALLNY) {  // the block's PCR tables of the Crank-Nicolson system
     double *Tw = lds_all + (size_t)(blockDim.x >> 6) * MlLds::doubles(nz, ny);
     if (wave == 0) ml_build_pcr(Tw, ny, mc.s, lane);
