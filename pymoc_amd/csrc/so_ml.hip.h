@@ -83,6 +83,7 @@ struct MlStatic {
   const double *surflux, *rest_mask, *b_rest;  // this member's rows in global memory
   double h, L, v_pist, dy, s;
   double rh, rL, rdy;  // RN(1/h), RN(1/L), RN(1/dy) for the correctly rounded divisions
+  double rh_l, rL_l, rdy_l;  // their low parts (div_by_recip2)
 };
 
 // loop-invariant parts of the surface-flux tendency (:250-252), same operations as the
@@ -96,6 +97,9 @@ __device__ __forceinline__ void ml_flux_tables(const MlLds &w, MlStatic &c, int 
   c.rh = 1.0 / c.h;
   c.rL = 1.0 / c.L;
   c.rdy = 1.0 / c.dy;
+  c.rh_l = recip_lo(c.h, c.rh);
+  c.rL_l = recip_lo(c.L, c.rL);
+  c.rdy_l = recip_lo(c.dy, c.rdy);
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -422,7 +426,8 @@ __device__ __forceinline__ bool ml_step_reg(MlReg &q, const MlLds &w, const MlSt
     else if (ps > 0.)
       num = -ps * 1e6 * (bs - bs_dn);
     if (ps != 0. && ps == ps)
-      adv = div_by_recip(div_by_recip(div_by_recip(num, c.h, c.rh), c.L, c.rL), c.dy, c.rdy);
+      adv = div_by_recip2(div_by_recip2(div_by_recip2(num, c.h, c.rh, c.rh_l), c.L, c.rL, c.rL_l),
+                          c.dy, c.rdy, c.rdy_l);
   }
   bs = bs + dt * (flux + adv);  // every tendency uses the old bs
   if (!upwell) {  // no-flux BC re-set (:264-266)
