@@ -4,9 +4,10 @@ Same constructor, attributes (`Psi`, `bgrid`, `b1`, `b2`, `f`, `z`, `sol_init`),
 and error text as `pymoc.modules.Psi_Thermwind` (src/pymoc/modules/psi_thermwind.py:7-232).
 Array and float profiles behave exactly like the reference.  Profiles given as CALLABLES are
 evaluated on `z` and at the collocation midpoints, where SciPy's solve_bvp evaluates them, so
-`solve()` agrees with the reference to ~1e-8 at nz = 100 (what remains is the node or two that
-solve_bvp's residual control inserts for curved profiles; SURVEY hazard H7); in `Psib` they
-are sampled on `z`, exactly as the reference does.
+`solve()` agrees with the reference to 1e-15 whenever solve_bvp keeps `z` as its mesh (rms
+residuals below tol = 1e-3: three of the four golden cases G14) and to ~4e-9 where its residual
+control inserts a node (SURVEY hazard H7); in `Psib` they are sampled on `z`, exactly as the
+reference does.
 """
 import numpy as np
 

@@ -184,8 +184,11 @@ def test_config3_sweep_members_vs_reference(gpu):
 
 def test_psi_thermwind_callable_profiles(gpu):
   """Callable profiles (the reference's example scripts start that way): the drop-in class
-  evaluates them at the collocation midpoints, like solve_bvp -- 1e-7 of the reference at
-  nz >= 100, bit-identical to the oracle given the same midpoint samples (G14, hazard H7)."""
+  evaluates them at the collocation midpoints, like solve_bvp, and is bit-identical to the
+  oracle given the same midpoint samples (G14, hazard H7).  Against the reference: 1e-13
+  wherever solve_bvp keeps the column grid as its mesh (three of the four golden cases: its
+  rms residuals stay below tol = 1e-3), 1e-8 in the case where it inserts one node (nz = 100,
+  b2 = 0: 101 nodes, measured 4e-9)."""
   g = load_golden("thermwind_callable")
   b2f = lambda zz: 0.004 * np.exp(zz / 800.)
   for nz in (100, 200):
@@ -193,13 +196,13 @@ def test_psi_thermwind_callable_profiles(gpu):
     zm = z[:-1] + 0.5 * (z[1:] - z[:-1])
     A = gpu.Psi_Thermwind(z=z, b1=configs.iteration_b_basin)
     A.solve()
-    assert relerr(A.Psi, g["nz%d_Psi" % nz]) <= 1e-7
+    assert relerr(A.Psi, g["nz%d_Psi" % nz]) <= (1e-8 if nz == 100 else 1e-13)
     b1, b1m = configs.iteration_b_basin(z), np.append(configs.iteration_b_basin(zm), 0.)
     assert np.array_equal(A.Psi, O.thermwind_solve(z, b1, 0. * z, 1.2e-4, b1_mid=b1m,
                                                    b2_mid=0. * z))
     B = gpu.Psi_Thermwind(z=z, b1=configs.iteration_b_basin, b2=b2f, f=1e-4)
     B.solve()
-    assert relerr(B.Psi, g["nz%d_Psi2" % nz]) <= 1e-7
+    assert relerr(B.Psi, g["nz%d_Psi2" % nz]) <= 1e-13
     B.update(b1=b1)  # arrays from now on: back to the level-interpolated path
     B.solve()
     assert B._b1_callable is False and B._b2_callable is True
