@@ -70,7 +70,8 @@ def test_psib_nonfinite_psi_golden(gpu):
 
 
 @pytest.mark.parametrize("nz,nb", [(2, 5), (3, 500), (9, 64), (64, 1), (65, 257), (100, 500),
-                                   (129, 500), (130, 100), (200, 500), (513, 300),
+                                   (129, 500), (130, 100), (200, 500), (200, 700), (300, 1500),
+                                   (513, 300),
                                    (1024, 500)])
 def test_thermwind_ragged_sizes_vs_oracle_bitwise(gpu, nz, nb):
   rng = np.random.default_rng(nz * 7 + nb)
