@@ -82,13 +82,15 @@ def test_thermwind_ragged_sizes_vs_oracle_bitwise(gpu, nz, nb):
   b2[3] = b1[3]            # identical columns
   b1[4, :2] = b1[4, min(2, nz - 1)]  # zero-thickness cells
   b2[5] = 0.0
+  b1[6, nz // 2] = np.nan  # a blown-up member: bgrid and every class sum are NaN (the kernel
+  b2[7] = np.nan           # skips the class passes for such members)
   f = rng.uniform(0.8e-4, 1.4e-4, n)
   Psi, bgrid, psib, o1, o2 = _run(gpu, z, b1, b2, f, nb)
   for m in range(n):
     rP = O.thermwind_solve(z, b1[m], b2[m], f[m])
-    assert np.array_equal(Psi[m], rP), (nz, nb, m)
+    assert np.array_equal(Psi[m], rP, equal_nan=True), (nz, nb, m)
     rg, rp, r1, r2 = O.thermwind_psibz(b1[m], b2[m], rP, nb)
-    assert np.array_equal(bgrid[m], rg), (nz, nb, m)
+    assert np.array_equal(bgrid[m], rg, equal_nan=True), (nz, nb, m)
     assert np.array_equal(psib[m], rp, equal_nan=True), (nz, nb, m)
     assert np.array_equal(o1[m], r1, equal_nan=True), (nz, nb, m)
     assert np.array_equal(o2[m], r2, equal_nan=True), (nz, nb, m)
