@@ -209,9 +209,12 @@ typedef struct pm_psi_so {
   int32_t *status;      /* [n] out: bit0 bs not monotone north of its minimum (several
                            roots: ys then follows brentq's own iteration, like the
                            reference), bit1 non-finite Psi, bit2 NaN in bs, bit3 the adaptive GM
-                           mesh would exceed the nodes followed on the device (256 for
-                           nz <= 128, else solve_bvp's own 1000; the solution of the last
-                           mesh is returned) (may be NULL)                               */
+                           mesh would exceed solve_bvp's own max_nodes = 1000 (it stops
+                           there too; the solution of the last mesh is returned).  For
+                           nz <= 128 the first launch follows meshes up to 256 nodes and
+                           a follow-up launch redoes the members it flagged, which needs
+                           `status` (without it bit 3 semantics cannot be repaired and
+                           the 256-node solution stands) (may be NULL)                   */
 } pm_psi_so;
 
 int pm_psi_so_update(const pm_psi_so *so, int32_t ops, pm_stream_t stream);

@@ -217,10 +217,11 @@ __host__ __device__ inline bool so_reg_path(int nz) { return (nz + 63) / 64 <= S
 __host__ __device__ inline int so_big_doubles(int nz) {
   return 4 * SO_BIG_CAP + 3 * nz + (3 * SO_BIG_CAP * 2 + 7) / 8;
 }
-__host__ __device__ inline int so_lds_doubles(int nz, int ny, bool has_c, bool adaptive) {
+__host__ __device__ inline int so_lds_doubles(int nz, int ny, bool has_c, bool adaptive,
+                                              bool force_big = false) {
   const int stage = 3 * ny + (has_c ? 2 * nz : 0);
   if (!adaptive) return stage;
-  if (so_reg_path(nz))
+  if (so_reg_path(nz) && !force_big)
     return (stage > SO_REG_CAP ? stage : SO_REG_CAP) + 4 * SO_REG_CAP + (SO_REG_CAP * 2 + 7) / 8;
   return stage + so_big_doubles(nz) + nz;
 }
@@ -707,12 +708,32 @@ __device__ __forceinline__ int so_gm_adaptive_reg(const SoRegMesh &w, int nz, do
 
 // BVP: the member batch uses the F2010 boundary-value smoother (c is not None).  Without it
 // (JN2018, config 5) the kernel is a third of the registers and runs 4+ waves per SIMD.
-template <int P, bool BVP>
+// FIX: the follow-up launch of the adaptive solve for nz <= SO_REG_NZ.  A small persistent grid
+// scans `status` for members whose mesh outgrew the register-resident solver (bit 3) and redoes
+// exactly those with the general solver (meshes up to solve_bvp's own 1000 nodes), so that the
+// result is solve_bvp's for ANY input; it exits at once when no member is flagged (~2 us).
+template <int P, bool BVP, bool FIX = false>
 __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a, int ops) {
   extern __shared__ double lds_all[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int m_raw = blockIdx.x * (blockDim.x >> 6) + wave;
+  const int wave_id = blockIdx.x * (blockDim.x >> 6) + wave;
+  // FIX: every lane looks at one member's status, a ballot collects the flagged ones of 64
+  int scan_next = wave_id * 64, cur_base = 0;
+  unsigned long long pending = 0ull;
+  for (;;) {
+  int m_raw = wave_id;
+  if constexpr (FIX) {
+    while (pending == 0ull) {
+      if (scan_next >= a.n) return;  // wave-uniform: nothing left for this wave
+      cur_base = scan_next;
+      scan_next += gridDim.x * (blockDim.x >> 6) * 64;
+      const int mm = cur_base + lane;
+      pending = __ballot(mm < a.n && (a.status[mm] & 8) != 0);
+    }
+    m_raw = cur_base + __builtin_ctzll(pending);
+    pending &= pending - 1ull;
+  }
   const bool m_ok = m_raw < a.n;
   const int m = m_ok ? m_raw : a.n - 1;
   const int nz = a.nz, ny = a.ny;
@@ -721,7 +742,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   const bool has_c = BVP;  // == (a.flags & PM_SO_HAS_C) != 0, checked by the launcher
   const bool tau_arr = (a.flags & PM_SO_TAU_ARRAY) != 0;
   const bool adaptive = has_c && a.bvp_refine <= 0;
-  const int per_wave = so_lds_doubles(nz, ny, has_c, adaptive);
+  const int per_wave = so_lds_doubles(nz, ny, has_c, adaptive, FIX);
   double *s_y = lds_all + (size_t)wave * per_wave;
   double *s_bs = s_y + ny;
   double *s_tau = s_bs + ny;
@@ -920,7 +941,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
       ua0 = -(__shfl(ek_sv[0], 0, 64) * 1e6);
       ub0 = -(__shfl(v_last, last_lane, 64) * 1e6);
     }
-    if (P <= SO_REG_NZ / 64 && adaptive) {  // wave-uniform: follow solve_bvp's own mesh
+    if (!FIX && P <= SO_REG_NZ / 64 && adaptive) {  // wave-uniform: follow solve_bvp's own mesh
       const int stage = 3 * ny + 2 * nz;
       double *wk = s_y + (stage > SO_REG_CAP ? stage : SO_REG_CAP);
       SoRegMesh ms;
@@ -946,7 +967,7 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
         const int i = lane * P + p;
         temp[p] = outl[i < nz ? i : nz - 1];
       }
-    } else if (P > SO_REG_NZ / 64 && adaptive) {
+    } else if ((FIX || P > SO_REG_NZ / 64) && adaptive) {
       double *wk = s_w + 2 * nz;
       SoMesh ms;
       ms.x = wk;
@@ -1105,6 +1126,9 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   PM_TICK(10)
   PM_TICK_FLUSH
   PM_WAVE_END(m_raw)
+  if constexpr (!FIX) break;
+  __builtin_amdgcn_wave_barrier();  // the next flagged member reuses the wave's LDS
+  }
 }
 
 template <int P, bool BVP>
@@ -1129,6 +1153,19 @@ int launch_psi_so_impl(const pm_psi_so &a, int ops, hipStream_t st) {
   const unsigned grid = (unsigned)((a.n + wpb - 1) / wpb);
   hipLaunchKernelGGL((k_psi_so<P, BVP>), dim3(grid), dim3(64 * wpb), lds, st, a, ops);
   PM_HIP(hipGetLastError());
+  if constexpr (BVP && P <= SO_REG_NZ / 64) {
+    // (PYMOC_SO_NO_FIXUP=1 skips it: tests use that to see the flag the first launch leaves)
+    if (adaptive && a.status && (ops & PM_SO_OP_GM) && !getenv("PYMOC_SO_NO_FIXUP")) {
+      // members whose mesh outgrew the register-resident solver: redone by the general one
+      const size_t lds_fix = (size_t)so_lds_doubles(a.nz, a.ny, true, true, true) * sizeof(double);
+      if (lds_fix > 64 * 1024)
+        PM_HIP(hipFuncSetAttribute((const void *)k_psi_so<P, BVP, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fix));
+      const unsigned gfix = (unsigned)(a.n < 256 ? a.n : 256);
+      hipLaunchKernelGGL((k_psi_so<P, BVP, true>), dim3(gfix), dim3(64), lds_fix, st, a, ops);
+      PM_HIP(hipGetLastError());
+    }
+  }
   return PM_OK;
 }
 

@@ -348,3 +348,32 @@ def test_gm_adaptive_mesh_tall_grid_vs_oracle(gpu):
     if seen >= 4:
       break
   assert seen >= 3
+
+
+def test_gm_adaptive_mesh_beyond_the_register_solver(gpu, monkeypatch):
+  """A thin GM boundary layer (c = 0.02) drives solve_bvp beyond the 256 nodes the
+  register-resident solver follows: the first launch flags the member (status bit 3), the
+  follow-up launch redoes exactly the flagged members with the general solver (meshes up to
+  solve_bvp's own 1000 nodes), so the result is the oracle's / SciPy's for any input."""
+  from pymoc_amd.device import DeviceArray
+  m = configs.twocol_so_member(nz=100, ny=40)
+  z, y = m["z"], m["y"]
+  kw = dict(KGM=m["KGM"], f=m["f"], L=m["L"], bvp_with_Ek=True)
+  cs = np.array([0.1, 0.02, 0.1, 0.01])  # members 1 and 3 overflow, 0 and 2 do not
+  ref = [O.psi_so_solve(z, y, m["b_basin0"], m["bs_SO"], m["tau"], c=c, **kw)[2] for c in (0.1, 0.02, 0.01)]
+
+  def run(c):
+    t = gpu.PsiSOBatch(z, y, 3, tau=m["tau"], c=c, **kw)
+    t.update(DeviceArray.from_host(np.stack([m["b_basin0"]] * 3)),
+             DeviceArray.from_host(np.stack([m["bs_SO"]] * 3)))
+    return t.Psi_GM.download(), t.status.download()
+
+  monkeypatch.setenv("PYMOC_SO_NO_FIXUP", "1")
+  GM, st = run(0.02)
+  assert np.all(st & 8 == 8) and relerr(GM[0], ref[1]) > 1e-8  # flagged, last mesh's solution
+  monkeypatch.delenv("PYMOC_SO_NO_FIXUP")
+  for c, r in zip((0.1, 0.02, 0.01), ref):
+    GM, st = run(c)
+    assert np.all(st & 10 == 0), c
+    assert np.array_equal(GM[0], GM[1]) and np.array_equal(GM[0], GM[2])
+    assert relerr(GM[0], r) <= TOL_BVP_ADAPT, c
