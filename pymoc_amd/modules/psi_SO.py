@@ -9,8 +9,8 @@ are tabulated on a FINE_Y-point refinement of `y` that the kernel interpolates l
 1e-6 otherwise).  `ys` is the direct inverse of the piecewise-linear bs(y) where
 that is unique (the reference root-finds it with brentq to xtol=2e-12) and brentq's own
 iteration where bs is not monotone; the GM boundary-value problem
-(`c` not None) is solved by 4th-order collocation on a refined fixed mesh instead of
-SciPy's adaptive solve_bvp (agreement ~1e-6).
+(`c` not None) is solved by the same 4th-order collocation on the mesh SciPy's solve_bvp
+itself ends on, its residual control followed on the device (agreement 1e-14).
 """
 import numpy as np
 
