@@ -51,9 +51,13 @@ def main():
       comm, np.isin(np.arange(hi - lo), ens.nonfinite_members())[:, None].astype(float),
       args.members)
   if rank == 0:
+    # members the explicit scheme loses (the reference loses the same ones)
+    # are reported, not folded into the ranges
+    ok = bad[:, 0] == 0
     print("%d members on %d GPU(s), %d steps: max AMOC %.2f .. %.2f Sv, mid-depth b %.2e .. "
-          "%.2e, %d non-finite members" % (args.members, world, total, psi_max.min(),
-                                           psi_max.max(), b_mid.min(), b_mid.max(), int(bad.sum())))
+          "%.2e over the %d finite members, %d non-finite members"
+          % (args.members, world, total, psi_max[ok].min(), psi_max[ok].max(), b_mid[ok].min(),
+             b_mid[ok].max(), int(ok.sum()), int(bad.sum())))
   if args.out and rec.nd > 0:
     os.makedirs(args.out, exist_ok=True)
     rec.save_ensemble(os.path.join(args.out, "diags_rank%d.npz" % rank), cfg["tau"], cfg["KGM"])
