@@ -415,6 +415,17 @@ def kernel_breakdown(config, cfg, ens, env, reps=20):
           "frac": tf / FP64_PEAK_TFLOPS, "kernel": dom, "kernel_ms_per_launch": ms,
           "flop_model": model, "traffic": None,
           "algorithmic_hbm_GBps": alg / (ms * 1e-3) / 1e9}
+  # instruction mix and vector-issue utilisation of the kernel on this config: SQ counters from
+  # a separate rocprofv3 --pmc run (profiles/collect_coupled_pmc_r02.sh), replayed
+  cnt = load_json(os.path.join(ROOT, "profiles", "coupled_counters.json")).get(
+      "config%d/%s" % (config, dom))
+  if cnt:
+    roof["valu_busy_frac"] = cnt["valu_busy"]
+    roof["valu_insts_per_wave"] = cnt["valu_per_wave"]
+    roof["salu_insts_per_wave"] = cnt["salu_per_wave"]
+    roof["counters_source"] = ("SQ_ACTIVE_INST_VALU x 4 / (kernel cycles x 1024 SIMDs) and "
+                               "SQ_INSTS_* / SQ_WAVES, replayed from profiles/coupled_counters.json "
+                               "(separate rocprofv3 --pmc pass, not measured in this run)")
   return shares, roof
 
 
