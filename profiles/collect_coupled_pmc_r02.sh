@@ -3,6 +3,8 @@
 # configs' kernels (BASELINE configs 3, 4, 5 as `bench.py --config N`), rocprofv3 --pmc in its
 # own passes, never combined with tracing.  Summarised by profiles/summarize_coupled_r02.py into
 # profiles/coupled_counters.json, which bench.py replays (labelled as replayed).
+# NOTE gpurun MERGES the box's gpurun_out/ into the local one: delete the local output
+# directory of an earlier collection before summarising, or the summary averages old and new runs.
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_coupled
 rm -rf $OUT && mkdir -p $OUT

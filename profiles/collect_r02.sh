@@ -7,6 +7,8 @@
 #      memory-bound regime (262144 columns, one step per launch), whose true traffic is known,
 #      to calibrate them for this kernel's accesses (gfx950: FETCH_SIZE reads ~1/2)
 set -e
+# NOTE gpurun MERGES the box's gpurun_out/ into the local one: delete the local output
+# directory of an earlier collection before summarising, or the summary averages old and new runs.
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_r02
 rm -rf $OUT && mkdir -p $OUT
