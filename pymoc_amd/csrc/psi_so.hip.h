@@ -205,7 +205,8 @@ __device__ __forceinline__ SoElem so_shfl_down(const SoElem &e, int d) {
 //      a prefix sum of the counts.
 // Two implementations.  nz <= SO_REG_NZ: `so_gm_adaptive_reg`, every lane keeps its <= 4
 // intervals in registers, meshes up to SO_REG_CAP nodes (config 4 and the golden cases end on
-// 85-207; status bit 3 if SciPy would refine further).  Larger grids: `so_gm_adaptive`, chunks
+// 85-207; a member whose mesh grows further is flagged with status bit 3 and redone by the
+// follow-up launch, k_psi_so<.., FIX>).  Larger grids and that follow-up: `so_gm_adaptive`, chunks
 // of any length worked through LDS scratch, meshes up to solve_bvp's own max_nodes.
 constexpr int SO_REG_NZ = 128, SO_REG_CAP = 256, SO_REG_C = SO_REG_CAP / 64;
 constexpr int SO_BIG_CAP = 1000;
