@@ -215,6 +215,12 @@ typedef struct pm_psi_so {
                            a follow-up launch redoes the members it flagged, which needs
                            `status` (without it bit 3 semantics cannot be repaired and
                            the 256-node solution stands) (may be NULL)                   */
+  const double *ys_in;      /* [n][nz] optional: outcrop latitudes computed by the caller   */
+  const double *tau_ave_in; /* [n][nz] optional: wind stress averaged from ys to y[-1].
+                               For CALLABLE bs / tau, which only the host can evaluate: the
+                               drop-in class root-finds and averages exactly like the
+                               reference (psi_SO.py:106-140, :238-240) and hands the results
+                               in; both NULL = computed on the device from bs[n][ny], tau  */
 } pm_psi_so;
 
 int pm_psi_so_update(const pm_psi_so *so, int32_t ops, pm_stream_t stream);

@@ -63,7 +63,8 @@ class pm_psi_so(C.Structure):
       ("c", C.c_double), ("Hsill", C.c_double), ("HEk", C.c_double),
       ("Htapertop", C.c_double), ("Htaperbot", C.c_double),
       ("Psi", c_dp), ("Psi_Ek", c_dp), ("Psi_GM", c_dp), ("Ek_raw", c_dp),
-      ("GM_raw", c_dp), ("ys", c_dp), ("status", c_dp)
+      ("GM_raw", c_dp), ("ys", c_dp), ("status", c_dp), ("ys_in", c_dp),
+      ("tau_ave_in", c_dp)
   ]
 
 

@@ -792,7 +792,9 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
     z[p] = a.z[ic];
     b[p] = a.b[base + ic];
     double yv;
-    if (b[p] < bsmin) {
+    if (a.ys_in != nullptr) {  // the caller's own inversion of a callable bs(y)
+      yv = a.ys_in[base + ic];
+    } else if (b[p] < bsmin) {
       yv = y0g - 1e3;
     } else if (b[p] > bs_last) {
       yv = yN;
@@ -839,7 +841,9 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   for (int p = 0; p < P; ++p) {
     const int i = lane * P + p;
     double tau_ave;
-    if (!tau_arr) {
+    if (a.tau_ave_in != nullptr) {  // the caller's own average of a callable tau(y)
+      tau_ave = a.tau_ave_in[base + (i < nz ? i : nz - 1)];
+    } else if (!tau_arr) {
       // tau + 0*y is tau unless the outcrop latitude is non-finite
       tau_ave = (ys[p] - ys[p] == 0.) ? tmean_scalar : __builtin_nan("");
     } else {

@@ -2,11 +2,14 @@
 
 Same constructor, attributes, methods and error text as `pymoc.modules.Psi_SO`
 (src/pymoc/modules/psi_SO.py:8-375).  Array and float inputs behave exactly like the
-reference; a callable `b` is only ever evaluated on `z` (exact); callable `bs` / `tau`, which
-the reference evaluates between grid points (inside brentq and the 100-point wind average),
-are tabulated on a FINE_Y-point refinement of `y` that the kernel interpolates linearly
-(1e-4 from the reference where bs(y) is flat, i.e. where the outcrop latitude is ill-conditioned;
-1e-6 otherwise).  `ys` is the direct inverse of the piecewise-linear bs(y) where
+reference; a callable `b` is only ever evaluated on `z` (exact).  CALLABLE `bs` / `tau`, which
+the reference evaluates between grid points (inside brentq and the 100-point wind average,
+psi_SO.py:106-140, :238-240), can only be evaluated on the host: this class then root-finds
+the outcrop latitudes with the same brentq iteration (`pymoc_amd.utils.brentq`, a restatement
+of SciPy's, bit-identical to it) and averages the wind exactly like the reference, and hands
+both to the kernel (`pm_psi_so.ys_in / tau_ave_in`); everything downstream runs on the device
+(agreement with the reference 1e-13).  For array `bs`, `ys` is the direct inverse of the
+piecewise-linear bs(y) where
 that is unique (the reference root-finds it with brentq to xtol=2e-12) and brentq's own
 iteration where bs is not monotone; the GM boundary-value problem
 (`c` not None) is solved by the same 4th-order collocation on the mesh SciPy's solve_bvp
@@ -14,7 +17,6 @@ itself ends on, its residual control followed on the device (agreement 1e-14, DE
 """
 import numpy as np
 
-FINE_Y = 2048  # points of the y table that callable bs / tau are sampled on
 
 from .. import _lib
 from ..device import DeviceArray
@@ -72,10 +74,7 @@ class Psi_SO(object):
   # ---- device plumbing: one arena, one H2D and one D2H per call
   # arena (float64 slots): [b | bs | tau | KGM | Psi_Ek | Psi | Psi_GM | Ek_raw | GM_raw | ys]
   def _kernel_y(self):
-    """The meridional grid handed to the kernel: `y` itself, or its refinement when bs / tau
-    are callables (same end points, so every use of y[0] / y[-1] is unchanged)."""
-    if (self._bs_callable or self._tau_callable) and np.size(self.y) < FINE_Y:
-      return np.linspace(self.y[0], self.y[-1], FINE_Y)
+    """The meridional grid handed to the kernel."""
     return self.y
 
   def _alloc(self):
@@ -98,6 +97,7 @@ class Psi_SO(object):
     d.Psi_Ek, d.Psi, d.Psi_GM = off(o), off(o + nz), off(o + 2 * nz)
     d.Ek_raw, d.GM_raw, d.ys = off(o + 3 * nz), off(o + 4 * nz), off(o + 5 * nz)
     d.status = self._status.ptr
+    self._extra = DeviceArray((2 * nz,))  # ys_in | tau_ave_in (callable bs / tau only)
     self._desc, self._out_ptr = d, off(o)
 
   def _run(self, ops, b=None):
@@ -130,6 +130,16 @@ class Psi_SO(object):
       h[nz + 2 * ny + 1:] = self.Psi_Ek
     d.flags, d.bvp_refine = fl, 0
     d.f, d.rho, d.L, d.smax = float(self.f), float(self.rho), float(self.L), float(self.smax)
+    d.ys_in, d.tau_ave_in = None, None
+    if self._bs_callable or self._tau_callable:
+      # only the host can evaluate the callables between grid points: the reference's own
+      # root-finding and wind average (psi_SO.py:106-140, :238-240), handed to the kernel
+      ys_h = np.array([self._ys_host(bv) for bv in h[0:nz]])
+      yN = self.y[-1]
+      tau_h = np.array([np.mean(self.tau(np.linspace(y0, yN, 100))) for y0 in ys_h])
+      ex = np.concatenate([ys_h, tau_h])
+      _lib.check(_lib.lib.pm_memcpy_h2d(self._extra.ptr, ex.ctypes.data, ex.nbytes, None))
+      d.ys_in, d.tau_ave_in = self._extra.ptr, self._extra.ptr + 8 * nz
     self._arena_upload(h)
     _lib.check(_lib.lib.pm_psi_so_update(C.byref(d), int(ops), None))
     _lib.check(_lib.lib.pm_memcpy_d2h(self._out.ctypes.data, self._out_ptr, 6 * nz * 8, None))
@@ -137,6 +147,17 @@ class Psi_SO(object):
 
   def _arena_upload(self, h):
     _lib.check(_lib.lib.pm_memcpy_h2d(self._arena.ptr, h.ctypes.data, h.nbytes, None))
+
+  def _ys_host(self, b):
+    """Psi_SO.ys of the reference, line by line (psi_SO.py:106-140), for callable profiles."""
+    from ..utils.brentq import brentq
+    bsy = self.bs(self.y)
+    if b < np.min(bsy):
+      return self.y[0] - 1e3
+    if b > self.bs(self.y[-1]):
+      return self.y[-1]
+    minind = np.argmin(bsy)
+    return brentq(lambda yy: self.bs(yy) - b, self.y[minind], self.y[-1])
 
   # ---- API (psi_SO.py:106-375)
   def ys(self, b):

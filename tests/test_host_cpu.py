@@ -176,3 +176,22 @@ def test_explicit_scheme_limits_hold_for_the_bench_configs():
   for c in (configs.config2(N=256), configs.config3(N=256), configs.config4(N=256)):
     dz = np.diff(c["z"]).min()
     assert (c["kappa"].max() * c["dt"] / dz**2) < 0.5
+
+
+def test_brentq_restatement_equals_scipy():
+  """pymoc_amd.utils.brentq (host root-finding for CALLABLE bs in Psi_SO.ys) is SciPy's brentq
+  decision for decision: bit-identical roots on random smooth functions."""
+  from scipy import optimize
+  from pymoc_amd.utils.brentq import brentq
+  rng = np.random.default_rng(5)
+  seen = 0
+  for k in range(600):
+    a, b, c = rng.uniform(0.5, 3), rng.uniform(-2, 2), rng.uniform(-1, 1)
+    f = lambda y: np.tanh(a * y + b) + 0.3 * np.sin(3 * y) + 0.2 * c - 0.1 * k / 600
+    if f(-4.) * f(4.) > 0:
+      continue
+    seen += 1
+    assert optimize.brentq(f, -4., 4.) == brentq(f, -4., 4.)
+  assert seen > 200
+  with pytest.raises(ValueError):
+    brentq(lambda y: 1. + y * y, -1., 1.)
