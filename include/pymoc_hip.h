@@ -163,9 +163,21 @@ typedef struct pm_thermwind {
   const double *b1_mid; /* [n][nz] b1 at the midpoints z[k] + (z[k+1]-z[k])/2 of the     */
   const double *b2_mid; /*         intervals, for CALLABLE profiles (solve_bvp evaluates */
                         /*         them there); NULL = linear between the levels        */
+  double *dPsi;         /* [n][nz] out with PM_TW_SOLVE, may be NULL: d(Psi 1e6)/dz at the  */
+                        /*         levels (the second component of solve_bvp's solution)    */
 } pm_thermwind;
 
 int pm_thermwind_update(const pm_thermwind *tw, int32_t ops, pm_stream_t stream);
+
+/* solve_bvp's rms residual of every interval of ONE member's mesh x[m] (scipy 1.15.3
+ * _bvp.py:estimate_rms_residuals: 5-point Lobatto rule on the C1 cubic spline of (y, f)) for the
+ * thermal-wind problem y0' = y1, y1' = g(x): y0[m] = Psi (in Sv, as stored) and y1[m] = dPsi from
+ * pm_thermwind_update on the mesh, g[m] = (b2 - b1)/f at the nodes, g_lob[2][m-1] at the two
+ * inner Lobatto points x_mid +- h sqrt(3/7)/2 of every interval (CALLABLE profiles: sampled by
+ * the host, which owns solve_bvp's mesh loop: pymoc_amd/modules/psi_thermwind.py).  rms[m-1].  */
+int pm_thermwind_residuals(int32_t m, const double *x, const double *y0, const double *y1,
+                           const double *g, const double *g_lob, double *rms,
+                           pm_stream_t stream);
 
 /* ------------------------------------------------------------------ Psi_SO
  * Replaces pymoc.modules.Psi_SO for n independent members on shared grids z[nz], y[ny]:

@@ -43,7 +43,8 @@ class pm_thermwind(C.Structure):
       ("n", C.c_int32), ("nz", C.c_int32), ("nb", C.c_int32), ("reserved", C.c_int32),
       ("z", c_dp), ("b1", c_dp), ("b2", c_dp), ("f", c_dp), ("Psi", c_dp),
       ("bgrid", c_dp), ("psib", c_dp), ("psibz1", c_dp), ("psibz2", c_dp),
-      ("Psi_SO", c_dp), ("wA1", c_dp), ("wA2", c_dp), ("b1_mid", c_dp), ("b2_mid", c_dp)
+      ("Psi_SO", c_dp), ("wA1", c_dp), ("wA2", c_dp), ("b1_mid", c_dp), ("b2_mid", c_dp),
+      ("dPsi", c_dp)
   ]
 
 
@@ -162,6 +163,7 @@ SIGNATURES = {
     "pm_column_kernel_name": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_char_p, C.c_size_t]),
     "pm_thermwind_update": (C.c_int, [C.POINTER(pm_thermwind), C.c_int32, C.c_void_p]),
+    "pm_thermwind_residuals": (C.c_int, [C.c_int32] + [c_dp] * 6 + [C.c_void_p]),
     "pm_psi_so_update": (C.c_int, [C.POINTER(pm_psi_so), C.c_int32, C.c_void_p]),
     "pm_so_ml_step": (C.c_int, [C.POINTER(pm_so_ml), C.c_double, C.c_void_p]),
     "pm_jn2018_bc_switch": (C.c_int, [C.POINTER(pm_jn2018_bc), C.c_void_p]),

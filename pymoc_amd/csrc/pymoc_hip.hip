@@ -326,6 +326,17 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
   }
 }
 
+int pm_thermwind_residuals(int32_t m, const double *x, const double *y0, const double *y1,
+                           const double *g, const double *g_lob, double *rms,
+                           pm_stream_t stream) {
+  PM_REQUIRE(m >= 2 && x && y0 && y1 && g && g_lob && rms, "bad mesh size or NULL pointer");
+  hipStream_t st = resolve_stream(stream);
+  hipLaunchKernelGGL(k_thermwind_residuals, dim3((unsigned)((m - 1 + 127) / 128)), dim3(128), 0, st,
+                     (int)m, x, y0, y1, g, g_lob, rms);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
 // ------------------------------------------------------------- Psi_Thermwind
 int pm_thermwind_update(const pm_thermwind *tw, int32_t ops, pm_stream_t stream) {
   PM_REQUIRE(tw, "tw is NULL");

@@ -402,6 +402,7 @@ __attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermw
       Psi[p] = (Il[p] - Iend * ((z[p] - z0) / span)) / 1e6;  // Sv
       if (i < nz && m_ok) {
         a.Psi[base + i] = Psi[p];
+        if (a.dPsi) a.dPsi[base + i] = Gl[p] - Iend / span;  // d(Psi 1e6)/dz
         // z-space coupling wA = AMOC.Psi * 1e6 (examples/example_timestepping.py:75)
         if ((ops & PM_TW_WA_PSI) && a.wA1) a.wA1[base + i] = Psi[p] * 1e6;
       }
@@ -588,6 +589,42 @@ __attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermw
   PM_TICK(10)
   PM_TICK_FLUSH
   PM_WAVE_END(m_raw)
+}
+
+// pm_thermwind_residuals: one thread per interval (a single member's mesh; the host owns
+// solve_bvp's mesh loop for CALLABLE profiles).  scipy _bvp.py: create_spline +
+// estimate_rms_residuals for y = (y0, y1), f = (y1, g); the mid-point residual of a converged
+// collocation solution is zero.
+__global__ void k_thermwind_residuals(int m, const double *x, const double *y0, const double *y1,
+                                      const double *g, const double *g_lob, double *rms) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m - 1) return;
+  const double h = x[i + 1] - x[i];
+  // cubic of component c on [x_i, x_i+1]: ((c0 dx + c1) dx + yp_a) dx + y_a  (create_spline)
+  const double ya[2] = {y0[i] * 1e6, y1[i]}, yb[2] = {y0[i + 1] * 1e6, y1[i + 1]};  // y0 arrives in Sv
+  const double pa[2] = {y1[i], g[i]}, pb[2] = {y1[i + 1], g[i + 1]};
+  double c0[2], c1[2];
+  for (int c = 0; c < 2; ++c) {
+    const double slope = (yb[c] - ya[c]) / h;
+    const double t = (pa[c] + pb[c] - 2 * slope) / h;
+    c0[c] = t / h;
+    c1[c] = (slope - pa[c]) / h - t;
+  }
+  const double s = 0.5 * h * 0.6546536707079771;  // sqrt(3/7)
+  double acc = 0.;
+  for (int side = 0; side < 2; ++side) {
+    const double xe = x[i] + 0.5 * h + (side == 0 ? s : -s);
+    const double dx = xe - x[i];
+    double Y[2], Yp[2];
+    for (int c = 0; c < 2; ++c) {
+      Y[c] = ((c0[c] * dx + c1[c]) * dx + pa[c]) * dx + ya[c];
+      Yp[c] = (3 * c0[c] * dx + 2 * c1[c]) * dx + pa[c];
+    }
+    const double F0 = Y[1], F1 = g_lob[(size_t)side * (m - 1) + i];
+    const double e0 = (Yp[0] - F0) / (1 + fabs(F0)), e1 = (Yp[1] - F1) / (1 + fabs(F1));
+    acc += e0 * e0 + e1 * e1;
+  }
+  rms[i] = sqrt(0.5 * (49. / 90. * acc));
 }
 
 template <int P, int BIG>

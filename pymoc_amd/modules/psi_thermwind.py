@@ -3,10 +3,11 @@
 Same constructor, attributes (`Psi`, `bgrid`, `b1`, `b2`, `f`, `z`, `sol_init`), methods
 and error text as `pymoc.modules.Psi_Thermwind` (src/pymoc/modules/psi_thermwind.py:7-232).
 Array and float profiles behave exactly like the reference.  Profiles given as CALLABLES are
-evaluated on `z` and at the collocation midpoints, where SciPy's solve_bvp evaluates them, so
-`solve()` agrees with the reference to 1e-15 whenever solve_bvp keeps `z` as its mesh (rms
-residuals below tol = 1e-3: three of the four golden cases G14) and to ~4e-9 where its residual
-control inserts a node (SURVEY hazard H7); in `Psib` they are sampled on `z`, exactly as the
+evaluated where SciPy's solve_bvp evaluates them -- on the mesh, at the collocation midpoints
+and at the Lobatto points of its residual estimate -- and `solve()` follows solve_bvp's own mesh
+refinement (host: mesh and callables; device: collocation solve and residuals of every mesh,
+`_solve_callable`), so it agrees with the reference to 1e-13 also where solve_bvp inserts
+nodes (SURVEY hazard H7, golden G14); in `Psib` they are sampled on `z`, exactly as the
 reference does.
 """
 import numpy as np
@@ -85,8 +86,73 @@ class Psi_Thermwind(object):
 
   def solve(self):
     from .. import _lib
+    if self._b1_callable or self._b2_callable:
+      self.Psi = self._solve_callable()
+      return
     out = self._run(_lib.PM_TW_SOLVE, 1, False)
     self.Psi = out[:np.size(self.z)].copy()
+
+  def _solve_callable(self, tol=1e-3, max_nodes=1000):
+    """solve() for CALLABLE profiles: scipy.integrate.solve_bvp's own loop (scipy 1.15.3
+    _bvp.py, defaults tol = 1e-3, max_nodes = 1000, as psi_thermwind.py:132 calls it).  The
+    host owns the mesh and samples the callables where solve_bvp does (nodes, mid-points, the
+    inner Lobatto points of the residual estimate); the collocation solve and the rms
+    residuals of every mesh run on the device (pm_thermwind_update on the mesh,
+    pm_thermwind_residuals); nodes are inserted by solve_bvp's rule until no interval asks
+    for one.  The column levels stay nodes, so Psi on z is the nodal solution there."""
+    import ctypes as C
+    from .. import _lib
+    from .column import flush_all
+    flush_all()
+    z = np.ascontiguousarray(self.z, dtype=np.float64)
+    x = z.copy()
+    s37 = 0.5 * (3. / 7.) ** 0.5
+    rf = 1. / self.f
+    cap = 1024
+    if getattr(self, "_mesh_arena", None) is None:
+      # in : x | b1 | b2 | b1_mid | b2_mid | g | g_lob[2] | f      out: Psi | dPsi | rms
+      self._mesh_arena = DeviceArray((12 * cap + 8,))
+    p = self._mesh_arena.ptr
+    while True:
+      m = x.size
+      h = x[1:] - x[:-1]
+      xm = x[:-1] + 0.5 * h
+      b1x, b2x = self.b1(x) + 0 * x, self.b2(x) + 0 * x
+      host = np.zeros(9 * cap + 8)
+      host[0:m] = x
+      host[cap:cap + m] = b1x
+      host[2 * cap:2 * cap + m] = b2x
+      host[3 * cap:3 * cap + m - 1] = self.b1(xm)
+      host[4 * cap:4 * cap + m - 1] = self.b2(xm)
+      host[5 * cap:5 * cap + m] = rf * (b2x - b1x)  # the ode's right-hand side, :123
+      for side, sg in ((0, 1.), (1, -1.)):
+        xl = xm + sg * s37 * h
+        host[6 * cap + side * (m - 1):6 * cap + (side + 1) * (m - 1)] = rf * (self.b2(xl) - self.b1(xl))
+      host[8 * cap] = self.f
+      _lib.check(_lib.lib.pm_memcpy_h2d(p, host.ctypes.data, host.nbytes, None))
+      off = lambda k: p + 8 * k
+      d = _lib.pm_thermwind()
+      d.n, d.nz, d.nb, d.reserved = 1, m, 1, 0
+      d.z, d.b1, d.b2, d.f = off(0), off(cap), off(2 * cap), off(8 * cap)
+      d.b1_mid, d.b2_mid = off(3 * cap), off(4 * cap)
+      d.Psi, d.dPsi = off(9 * cap + 8), off(10 * cap + 8)
+      _lib.check(_lib.lib.pm_thermwind_update(C.byref(d), _lib.PM_TW_SOLVE, None))
+      _lib.check(_lib.lib.pm_thermwind_residuals(m, off(0), d.Psi, d.dPsi, off(5 * cap),
+                                                 off(6 * cap), off(11 * cap + 8), None))
+      out = np.empty(3 * cap)
+      _lib.check(_lib.lib.pm_memcpy_d2h(out.ctypes.data, off(9 * cap + 8), out.nbytes, None))
+      psi_x, rms = out[:m], out[2 * cap:2 * cap + m - 1]
+      insert_1, = np.nonzero((rms > tol) & (rms < 100 * tol))
+      insert_2, = np.nonzero(rms >= 100 * tol)
+      nodes_added = insert_1.shape[0] + 2 * insert_2.shape[0]
+      if nodes_added == 0 or m + nodes_added > max_nodes or m + nodes_added > cap:
+        break
+      # modify_mesh (_bvp.py): original nodes are kept
+      x = np.sort(np.hstack((x, 0.5 * (x[insert_1] + x[insert_1 + 1]),
+                             (2 * x[insert_2] + x[insert_2 + 1]) / 3,
+                             (x[insert_2] + 2 * x[insert_2 + 1]) / 3)))
+    self.mesh_nodes = int(x.size)
+    return psi_x[np.searchsorted(x, z)].copy()
 
   def Psib(self, nb=500):
     from .. import _lib
