@@ -375,3 +375,35 @@ def test_gm_adaptive_mesh_beyond_the_register_solver(gpu, monkeypatch):
     assert np.all(st & 10 == 0), c
     assert np.array_equal(GM[0], GM[1]) and np.array_equal(GM[0], GM[2])
     assert relerr(GM[0], r) <= TOL_BVP_ADAPT, c
+
+
+@pytest.mark.parametrize("nz", [9, 40, 64, 65, 66, 128])
+def test_gm_adaptive_mesh_short_grids_vs_oracle(gpu, nz):
+  """The register-resident adaptive solver is templated on the intervals per lane (1 for
+  nz <= 65 ... 4 near its 256-node capacity): golden BVP cases re-sampled on short grids, whose
+  meshes pass through several of these variants while solve_bvp refines them."""
+  from pymoc_amd.device import DeviceArray
+  g = load_golden("psi_so")
+  seen = 0
+  for k in range(int(g["ncases"])):
+    p = "c%02d_" % k
+    kw = _kwargs(g, p)
+    if kw["c"] is None or g[p + "tau"].ndim != 0:
+      continue
+    seen += 1
+    z0, b0 = g[p + "z"], g[p + "b"]
+    z = np.linspace(z0[0], z0[-1], nz)
+    b = np.interp(z, z0, b0)
+    kw2 = dict(kw)
+    KGM = kw2.pop("KGM")
+    tau = float(g[p + "tau"])
+    t = gpu.PsiSOBatch(z, g[p + "y"], 2, tau=tau, KGM=KGM, **kw2)
+    t.update(DeviceArray.from_host(np.stack([b] * 2)), DeviceArray.from_host(np.stack([g[p + "bs"]] * 2)))
+    GM = t.Psi_GM.download()
+    oGM = O.psi_so_solve(z, g[p + "y"], b, g[p + "bs"], tau, KGM=KGM, **kw2)[2]
+    assert np.array_equal(GM[0], GM[1])
+    assert relerr(GM[0], oGM) <= TOL_BVP_ADAPT, (k, nz, relerr(GM[0], oGM))
+    assert np.all(t.status.download() & 10 == 0)
+    if seen >= 4:
+      break
+  assert seen >= 3
