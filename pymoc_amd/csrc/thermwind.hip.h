@@ -220,7 +220,9 @@ __device__ __forceinline__ void psib_block_sum(const double *cells, int k0, int 
   }
   const int lane = threadIdx.x & 63;
   const int ng = n >> 3, g0 = k0 >> 3;  // ng <= 16
-  const bool mine = lane < ng;
+  // (the cells after the last full group, n % 8 of them, are the array's last, partial group:
+  // bit ng classifies them too)
+  const bool mine = lane < ng + ((n & 7) ? 1 : 0);
   const double vgb = rg.gbot[g0 + (mine ? lane : 0)], vgt = rg.gtop[g0 + (mine ? lane : 0)];
   const unsigned long long ones = __ballot(mine && rg.gmax <= vgb);
   const unsigned long long zero = __ballot(mine && rg.gmin >= vgt) & ~ones;
@@ -240,10 +242,21 @@ __device__ __forceinline__ void psib_block_sum(const double *cells, int k0, int 
   for (int j = 0; j < TW_JT; ++j)
     res[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) +
              ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
-  for (int k = (ng << 3); k < n; ++k) {
-    psib_cell_terms(psib_load_cell(cells, k0 + k), bg, term);
+  if ((n & 7) != 0) {  // NumPy's tail: the remaining cells are added one by one
+    const int kt = kind_of(ng);
+    if (kt == 2) {
+      for (int k = (ng << 3); k < n; ++k) {
+        const double uk = cells[(size_t)(k0 + k) * TW_CELL + 4];
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) res[j] += term[j];
+        for (int j = 0; j < TW_JT; ++j) res[j] += uk;
+      }
+    } else if (kt != 3) {  // (all masks zero: the tail adds zeros)
+      for (int k = (ng << 3); k < n; ++k) {
+        psib_cell_terms(psib_load_cell(cells, k0 + k), bg, term);
+#pragma unroll
+        for (int j = 0; j < TW_JT; ++j) res[j] += term[j];
+      }
+    }
   }
 }
 
