@@ -7,7 +7,7 @@ HIPHDR = $(wildcard $(CSRC)/*.h) include/pymoc_hip.h
 all: lib oracle
 
 HIPCFLAGS = --offload-arch=$(ARCH) -O3 -ffp-contract=off -fPIC -std=c++17 -Wno-unused-value $(EXTRA)
-HIPOBJ = $(CSRC)/build/pymoc_hip.o $(CSRC)/build/column_g16.o $(CSRC)/build/column_g32.o $(CSRC)/build/column_g64.o $(CSRC)/build/equi.o $(CSRC)/build/equi_column.o
+HIPOBJ = $(CSRC)/build/pymoc_hip.o $(CSRC)/build/column_g16.o $(CSRC)/build/column_g32.o $(CSRC)/build/column_g64.o $(CSRC)/build/equi.o $(CSRC)/build/equi_column.o $(CSRC)/build/jn2018_fast.o
 
 lib: pymoc_amd/libpymoc_hip.so
 $(CSRC)/build/%.o: $(CSRC)/%.hip $(HIPHDR)

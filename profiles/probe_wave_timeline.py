@@ -18,6 +18,16 @@ def timeline(label, N):
   print("%-16s %5d waves, %4d start later than 2 us; lifetime median %.1f, p99 %.1f, max %.1f us (member %d); "
         "last end %.1f us" % (label, N, late, np.median(life), np.percentile(life, 99), life.max(),
                               int(life.argmax()), en.max()))
+  if os.environ.get("DUMP"):
+    os.makedirs("gpurun_out", exist_ok=True)
+    np.save(os.path.join("gpurun_out", "wave_times_%s.npy" % label.split()[0]), w)
+  if os.environ.get("HIST"):
+    order = np.argsort(-life)[:12]
+    print("   slowest members:", [(int(i), round(float(life[i]), 1)) for i in order])
+    print("   start-time histogram (us):", np.histogram(st, bins=8)[0].tolist(), "edges",
+          np.round(np.histogram(st, bins=8)[1], 1).tolist())
+    print("   end-time histogram (us):  ", np.histogram(en, bins=8)[0].tolist(), "edges",
+          np.round(np.histogram(en, bins=8)[1], 1).tolist())
 
 
 CONFIG = int(os.environ.get("CONFIG", 5))

@@ -1,0 +1,751 @@
+// jn2018_fast.hip -- the fused Jansen & Nadeau time loop, rebuilt for residency.
+//
+// Same work and the same arithmetic, operation by operation, as k_jn2018_steps (so_ml.hip.h):
+//   nsteps x [bottom-BC switch -> basin.timestep(do_conv) -> north.timestep(do_conv) ->
+//             channel.timestep]                   examples/run_JansenNadeau_2018.py:229-261
+//   Column.convect / vertadvdiff                  src/pymoc/modules/column.py:210-271
+//   SO_ML.advdiff                                 src/pymoc/modules/SO_ML.py:198-274
+// for one member per wavefront, bit-identical to the stepwise launches.  What changed is where
+// things live, so that FOUR waves fit a SIMD (<= 128 VGPRs) instead of two and a step issues
+// about half the vector instructions:
+//   * the grid metrics and their double-double reciprocals (7 tables) are block-shared LDS,
+//     laid out so that a lane's slot pair is one conflict-free 16-byte read (k_jn2018_steps
+//     kept 7P doubles of them in every lane);
+//   * every wave-uniform double (bs, N2min, Area and its reciprocal parts, zconv, the mixed
+//     layer's h, L, dy and their reciprocal parts, ...) sits in LDS and is read by broadcast
+//     where it is used: as scalar registers they overflowed the scalar file, and the spills into
+//     vector lanes came back as v_readlane instructions in the time loop;
+//   * boundary and padding levels are held fixed by the TABLES (1/dzc = 0 and weff = 0 there
+//     make their tendency an exact zero) instead of a per-slot dt select; padding levels hold a
+//     large negative constant, so `b > bs` needs no validity test;
+//   * the bottom-BC switch runs as vector code in lane 0, which owns levels 0 and 1 of both
+//     columns and point 0 of the mixed layer: no readlanes, no scalar double juggling;
+//   * the convective adjustment takes its branch-free cached form only when the cached pattern
+//     holds convecting levels at all (the basin column almost never does);
+//   * argmin(bs) of the mixed layer is 0 whenever no point lies below the first one (checked
+//     with one compare); Psi_mod at a lane's interpolation interval stays in registers;
+//   * rare events (a column switching its coefficient set) leave the step loop instead of
+//     carrying their register merges through it; kernel arguments the loop does not need are
+//     re-read from the argument segment where the rare paths use them.
+// Requires: Area constant in z (PM_JN_UNIFORM_AREA, verified on the device), ny <= 64,
+// 4 <= nz <= 256.  Everything else takes k_jn2018_steps.
+// (profiling builds, -DPM_PHASE_PROFILE: the per-wave clocks live in pymoc_hip.hip's translation
+// unit, which then includes this file; the stand-alone object is left empty)
+#if !defined(PM_PHASE_PROFILE) || defined(PM_JF_IN_MAIN_TU)
+#ifndef PM_JF_IN_MAIN_TU
+#define PM_SO_ML_DEVICE_FUNCTIONS_ONLY
+#endif
+#include "so_ml.hip.h"
+
+namespace pm {
+
+// One block of 16 waves per CU (4096 members = 256 blocks): the block's tables are shared by 16
+// members, and the four waves of a SIMD are waves w, w+4, w+8, w+12 of ONE block, which is what
+// the priority rotation in the step loop relies on.
+#ifndef JF_WAVES_N
+#define JF_WAVES_N 16
+#endif
+constexpr int JF_WAVES = JF_WAVES_N;
+// profiling builds count how often the rare paths of the step loop are taken (pm_debug_prof)
+#ifdef PM_PHASE_PROFILE
+__device__ unsigned long long jf_rare[8 + 64];  // [8 + lane]: lanes whose point left its interval
+#endif
+#if defined(PM_PHASE_PROFILE) && defined(JF_COUNT_RARE)
+#define JF_RARE(k) \
+  if ((threadIdx.x & 63) == 0) atomicAdd(&jf_rare[k], 1ull);
+#else
+#define JF_RARE(k)
+#endif
+#ifndef JF_OCC_ATTR
+#define JF_OCC_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+
+// wave-uniform mixed-layer constants (block-shared), laid out in the pairs the three chained
+// exact divisions num/h/L/dy and the Crank-Nicolson row read them in (one 16-byte access each)
+enum { K_RHL = 0, K_RH, K_H, K_RLL, K_RL, K_L, K_RDYL, K_RDY, K_DY, K_SH, K_1MS, K_N = 12 };
+// ... and per-member ones (per wave); a column's block is {bs, area | N2min, zc | rarea, rarea_l}
+enum { S_BS = 0, S_AREA, S_N2, S_ZC, S_RAREA, S_RAREAL, S_COL = 6 };
+enum { S_B = 0, S_NN = S_COL, S_BBOT0 = 2 * S_COL, S_N = 16 };
+
+// Parallel-cyclic-reduction tables of the Crank-Nicolson system (ml_build_pcr's recurrences,
+// so_ml.hip.h), laid out for 16-byte reads: level l: {alpha, gamma}[lane]; then {b_final,
+// RN(1/b_final)}[lane]; then the low part of 1/b_final [lane]
+constexpr int JF_PCR_DOUBLES = (PCR_LEVELS + 1) * 128 + 64;
+
+template <int P>
+struct JfLds {
+  static constexpr int NZP = 64 * P;  // levels incl. padding
+  // block-shared tables, entry of (lane, slot p): ((p / 2) * 64 + lane) * 2 + (p & 1)
+  static constexpr int T_Z = 0, T_DZ = NZP, T_RDZ = 2 * NZP, T_RDZL = 3 * NZP, T_DZC = 4 * NZP,
+                       T_RDZC = 5 * NZP, T_RDZCL = 6 * NZP;
+  static constexpr int PCR = 7 * NZP;
+  static constexpr int KML = PCR + JF_PCR_DOUBLES;
+  static constexpr int PROG = KML + K_N;  // int[16]: the waves' step counters, [wave & 3][wave >> 2]
+  static constexpr int WAVE0 = PROG + 8;
+  // per wave: b_basin[level] and Psi_mod[level] for np.interp (level order: a lane's four levels
+  // are two 16-byte stores; interleaving the two tables put the stores 8-way onto two banks),
+  // kappa of the northern column in the tables' slot-pair layout (the basin's stays in
+  // registers), {surflux/h, rest_mask*v_pist/h}[64], b_rest[64], Psi_s[64], the member's scalars
+  static constexpr int W_BB = 0, W_PM = NZP, W_KN = 2 * NZP, W_F = 3 * NZP, W_BR = 3 * NZP + 128,
+                       W_PS = 3 * NZP + 192, W_S = 3 * NZP + 256;
+  static constexpr int PER_WAVE = W_S + S_N;
+  static constexpr int TOTAL = WAVE0 + JF_WAVES * PER_WAVE;
+};
+
+template <int P>
+__device__ __forceinline__ int jf_entry(int lane, int p) {
+  return ((p >> 1) * 64 + lane) * 2 + (p & 1);
+}
+
+template <int P>
+struct JfCol {
+  double b[P];  // state; padding levels hold JF_PAD
+  // weff = wA - d(A kappa)/dz (column.py:241), split for the select-free upwind flux of K1
+  // (col_vertadvdiff FLUXFMA, column.hip.h): wn = -weff where weff < 0 (else 0), wp = -weff
+  // where weff >= 0 (else 0); both 0 on boundary and padding levels
+  double wn[P], wp[P];
+  // kappa(z_i) of the coefficient set in use: registers for the basin column, the wave's LDS
+  // rows for the northern one (KAPREG of jf_vertadvdiff); there is room for one of them
+  double kap[P];
+};
+constexpr double JF_PAD = -1e300;  // finite, never above bs: padding never "convects"
+
+// what stays in scalar registers of a column's convective state
+template <int P>
+struct JfConv {
+  unsigned long long cm[P];  // convecting pattern the cached zc belongs to
+  bool any;                  // the cached pattern has convecting levels
+  bool valid;                // a pattern has been established in this launch
+};
+
+// two slots of a table: one 16-byte LDS read
+__device__ __forceinline__ double2 jf_pair(const double *T, int lane, int h) {
+  return *reinterpret_cast<const double2 *>(T + (h * 64 + lane) * 2);
+}
+
+// the kernel's argument block, re-read where a rare path needs it (so that the pointers do not
+// occupy scalar registers through the time loop)
+typedef const __attribute__((address_space(4))) pm_jn2018 *jf_kargs;
+__device__ __forceinline__ jf_kargs jf_args() {
+  jf_kargs p = (jf_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// Column.convect (column.py:251-271), do_conv = True, for a wave-owned column; ws = the
+// column's scalar block in LDS.
+template <int P>
+__device__ __forceinline__ void jf_convect(double (&b)[P], JfConv<P> &s, const double *lds,
+                                           double *ws, int lane, int nz) {
+  using L = JfLds<P>;
+  const double bs = ws[S_BS];
+  unsigned long long m[P], acc = 0ull;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    m[p] = __builtin_amdgcn_ballot_w64(b[p] > bs);  // column.py:264 (padding: never)
+    acc |= m[p] ^ s.cm[p];
+  }
+  if (__builtin_expect(acc != 0ull || !s.valid, 0)) {
+    JF_RARE(1)
+    // new pattern: zc = max(z[~ind]) -- z ascends, so z at the highest non-convecting level,
+    // the bottom of the ocean if every level convects (column.py:265-267)
+    unsigned long long anym = 0ull;
+    int jmax = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      anym |= m[p];
+      const int nv = (nz - p + P - 1) / P;  // lanes whose slot p is a real level
+      const unsigned long long vmask = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+      const unsigned long long nm = ~m[p] & vmask;
+      if (nm != 0ull) {
+        const int j = (63 - __clzll((long long)nm)) * P + p;
+        jmax = j > jmax ? j : jmax;
+      }
+      s.cm[p] = m[p];
+    }
+    s.any = anym != 0ull;
+    s.valid = true;
+    if (s.any) {
+      const double zv = lds[L::T_Z + jf_entry<P>(jmax / P, jmax % P)];
+      if (lane == 0) ws[S_ZC] = zv;
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (lane * P + p == nz - 1) b[p] = bs;  // column.py:271
+    }
+  }
+  if (s.any) {
+    JF_RARE(6)
+    const double2 nc = *reinterpret_cast<const double2 *>(ws + S_N2);  // {N2min, zc}
+#pragma unroll
+    for (int h = 0; h < P / 2; ++h) {
+      const double2 z2 = jf_pair(lds + L::T_Z, lane, h);
+      const double adj0 = bs + nc.x * (z2.x - nc.y);  // column.py:268
+      const double adj1 = bs + nc.x * (z2.y - nc.y);
+      b[2 * h] = (b[2 * h] > bs) ? adj0 : b[2 * h];
+      b[2 * h + 1] = (b[2 * h + 1] > bs) ? adj1 : b[2 * h + 1];
+    }
+  }
+}
+
+// Column.vertadvdiff (column.py:210-249) of one column, the bottom value already imposed.
+// Same operations in the same order as col_vertadvdiff<64, P, 2, ..., UA> (column.hip.h).
+template <int P, bool KAPREG>
+__device__ __forceinline__ void jf_vertadvdiff(JfCol<P> &c, const double *lds, const double *ws,
+                                               const double *kap, int lane, double dt) {
+  using L = JfLds<P>;
+  double bz[P];  // (b[i+1]-b[i])/dz[i] (column.py:235)
+  const double nb0 = from_next_lane_z(c.b[0]);
+#pragma unroll
+  for (int h = 0; h < P / 2; ++h) {
+    const double2 dz = jf_pair(lds + L::T_DZ, lane, h), y = jf_pair(lds + L::T_RDZ, lane, h),
+                  yl = jf_pair(lds + L::T_RDZL, lane, h);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = 2 * h + q;
+      const double up = (p < P - 1) ? c.b[p + 1 < P ? p + 1 : p] : nb0;
+      // 1/dz = 0 at and above the top level
+      bz[p] = div_by_recip2(up - c.b[p], q ? dz.y : dz.x, q ? y.y : y.x, q ? yl.y : yl.x);
+    }
+    if (P > 2) __builtin_amdgcn_sched_barrier(0);  // one slot pair's tables live at a time
+  }
+  // (scheduling fence: the second phase's table reads otherwise start before the first phase's
+  // are consumed, and twelve more live registers tip the kernel into scratch)
+  __builtin_amdgcn_sched_barrier(0);
+  const double pbz = from_prev_lane_z(bz[P - 1]);
+  const double area = ws[S_AREA];
+  const double2 ra = *reinterpret_cast<const double2 *>(ws + S_RAREA);  // {1/area, its low part}
+#pragma unroll
+  for (int h = 0; h < P / 2; ++h) {
+    const double2 dzc = jf_pair(lds + L::T_DZC, lane, h), y = jf_pair(lds + L::T_RDZC, lane, h),
+                  yl = jf_pair(lds + L::T_RDZCL, lane, h);
+    double2 kp;
+    if constexpr (KAPREG)
+      kp = make_double2(c.kap[2 * h], c.kap[2 * h + 1]);
+    else
+      kp = jf_pair(kap, lane, h);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = 2 * h + q;
+      const double dn = (p > 0) ? bz[p > 0 ? p - 1 : 0] : pbz;
+      const double bzz =
+          div_by_recip2(bz[p] - dn, q ? dzc.y : dzc.x, q ? y.y : y.x, q ? yl.y : yl.x);  // :238
+      // upwind flux (-weff) bz* (column.py:242-246): exactly one of wn, wp is -weff, the other
+      // product an exact zero
+      const double flx = __builtin_fma(c.wn[p], bz[p], c.wp[p] * dn);
+      const double adv = div_by_recip2(flx, area, ra.x, ra.y);
+      c.b[p] = c.b[p] + dt * (adv + (q ? kp.y : kp.x) * bzz);  // column.py:245-249
+    }
+    if (P > 2) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// mixed-layer state of a lane (point j = lane); everything else about the point lives in the
+// wave's LDS rows
+struct JfMl {
+  double bs;  // bs[j]
+  int jh;     // interval of the last interpolation: bb[jh] <= bs < bb[jh+1]
+};
+
+// Tables of the parallel cyclic reduction: the recurrences of ml_build_pcr (so_ml.hip.h),
+// stored in the layout above.
+__device__ __forceinline__ void jf_build_pcr(double *T, int ny, double s, int lane) {
+  const bool interior = lane >= 1 && lane <= ny - 2;
+  double a = interior ? -s / 2. : 0., b = interior ? 1 + s : 1., c = a;
+#pragma unroll
+  for (int l = 0; l < PCR_LEVELS; ++l) {
+    const int k = 1 << l;
+    const double a_lo = __shfl_up(a, k, 64), b_lo = __shfl_up(b, k, 64), c_lo = __shfl_up(c, k, 64);
+    const double a_hi = __shfl_down(a, k, 64), b_hi = __shfl_down(b, k, 64),
+                 c_hi = __shfl_down(c, k, 64);
+    const double alpha = (lane >= k) ? -a / b_lo : 0.;
+    const double gamma = (lane + k <= 63) ? -c / b_hi : 0.;
+    T[l * 128 + lane * 2] = alpha;
+    T[l * 128 + lane * 2 + 1] = gamma;
+    const double bn = __builtin_fma(gamma, a_hi, __builtin_fma(alpha, c_lo, b));
+    a = alpha * a_lo;
+    c = gamma * c_hi;
+    b = bn;
+  }
+  const double rb = 1.0 / b;
+  T[PCR_LEVELS * 128 + lane * 2] = b;
+  T[PCR_LEVELS * 128 + lane * 2 + 1] = rb;
+  T[(PCR_LEVELS + 1) * 128 + lane] = recip_lo(b, rb);
+}
+
+// x = U^-1 r by parallel cyclic reduction with the block's tables (ml_pcr_solve's recurrences)
+__device__ __forceinline__ double jf_pcr_solve(double r, const double *T, int lane, int a4) {
+#pragma unroll
+  for (int l = 0; l < PCR_LEVELS; ++l) {
+    const int k = 1 << l;
+    // a missing neighbour has a zero multiplier, so the lane index may wrap (bpermute takes
+    // its address modulo 64 lanes; the constants fold into the instruction's offset field)
+    const int lo_i = a4 + (256 - 4 * k), hi_i = a4 + 4 * k;
+    const double2 ag = *reinterpret_cast<const double2 *>(T + l * 128 + lane * 2);
+    const double r_lo = __hiloint2double(__builtin_amdgcn_ds_bpermute(lo_i, __double2hiint(r)),
+                                         __builtin_amdgcn_ds_bpermute(lo_i, __double2loint(r)));
+    const double r_hi = __hiloint2double(__builtin_amdgcn_ds_bpermute(hi_i, __double2hiint(r)),
+                                         __builtin_amdgcn_ds_bpermute(hi_i, __double2loint(r)));
+    r = __builtin_fma(ag.y, r_hi, __builtin_fma(ag.x, r_lo, r));
+    // (fence: a level's multipliers are read with its shuffles, not all 28 registers of them
+    // before the first level)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const double2 br = *reinterpret_cast<const double2 *>(T + PCR_LEVELS * 128 + lane * 2);
+  return div_by_recip2(r, br.x, br.y, T[(PCR_LEVELS + 1) * 128 + lane]);
+}
+
+template <int P>
+__global__ __launch_bounds__(64 * JF_WAVES) JF_OCC_ATTR
+void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
+  using L = JfLds<P>;
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m_raw = blockIdx.x * JF_WAVES + wave;
+  const bool m_ok = m_raw < a.n;
+  const int m = m_ok ? m_raw : a.n - 1;
+  const int n = a.n, nz = a.cols.nz, ny = a.ml.ny;
+  PM_WAVE_BEGIN
+  double *wl = lds + L::WAVE0 + wave * L::PER_WAVE;  // this wave's rows; wl[level] = basin b
+  double *ws = wl + L::W_S;                           // this member's scalars
+
+  // ---- block tables: grid metrics, double-double reciprocals (col_load_grid's operations)
+  for (int e = threadIdx.x; e < L::NZP; e += 64 * JF_WAVES) {
+    const double *z = a.cols.z;
+    const int h = e >> 7, ln = (e >> 1) & 63, q = e & 1;
+    const int i = ln * P + 2 * h + q;
+    const int ic = i < nz ? i : nz - 1;
+    const int iu = ic + 1 < nz ? ic + 1 : nz - 1;
+    const int id = ic > 0 ? ic - 1 : 0;
+    const double zc = z[ic];
+    const double dz = z[iu] - zc;
+    const double dzc = 0.5 * (dz + (zc - z[id]));
+    const bool has_up = i < nz - 1, interior = i >= 1 && i <= nz - 2;
+    const double rdz = has_up ? 1.0 / dz : 0.0;
+    const double rdzc = interior ? 1.0 / dzc : 0.0;  // 0: boundary / padding levels stay put
+    lds[L::T_Z + e] = zc;
+    lds[L::T_DZ + e] = dz;
+    lds[L::T_RDZ + e] = rdz;
+    lds[L::T_RDZL + e] = has_up ? recip_lo(dz, rdz) : 0.0;
+    lds[L::T_DZC + e] = dzc;
+    lds[L::T_RDZC + e] = rdzc;
+    lds[L::T_RDZCL + e] = interior ? recip_lo(dzc, rdzc) : 0.0;
+  }
+  if (wave == 0) {
+    const double ml_h = a.ml.h, ml_L = a.ml.L, dy = a.ml.y[1] - a.ml.y[0];
+    const double ms_s = a.ml.Ks * dt / (dy * dy);  // SO_ML.py:191
+    jf_build_pcr(lds + L::PCR, ny, ms_s, lane);
+    if (lane < 16) reinterpret_cast<int *>(lds + L::PROG)[lane] = 0;
+    if (lane == 0) {
+      double *K = lds + L::KML;
+      const double rh = 1.0 / ml_h, rL = 1.0 / ml_L, rdy = 1.0 / dy;
+      K[K_H] = ml_h;
+      K[K_RH] = rh;
+      K[K_RHL] = recip_lo(ml_h, rh);
+      K[K_L] = ml_L;
+      K[K_RL] = rL;
+      K[K_RLL] = recip_lo(ml_L, rL);
+      K[K_DY] = dy;
+      K[K_RDY] = rdy;
+      K[K_RDYL] = recip_lo(dy, rdy);
+      K[K_SH] = ms_s / 2.;
+      K[K_1MS] = 1 - ms_s;
+    }
+  }
+
+  // ---- this member's columns: state into registers, scalars into the wave's LDS block
+  JfCol<P> cb, cn;
+  JfConv<P> vb, vn;
+  int ksel_b, ksel_n;
+  bool hint_ok = true;
+  {
+    const pm_columns &c = a.cols;
+    auto load_col = [&](JfCol<P> &r, JfConv<P> &v, int col, double *wsc) {
+      bool same = true;
+      const double a0 = c.area[(size_t)col * nz];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = lane * P + p;
+        const int ic = i < nz ? i : nz - 1;
+        r.b[p] = i < nz ? c.b[(size_t)col * nz + ic] : JF_PAD;
+        same = same && c.area[(size_t)col * nz + ic] == a0;
+      }
+      hint_ok = hint_ok && __ballot(!same) == 0ull;
+      if (lane == 0) {
+        const double ra = 1.0 / a0;
+        wsc[S_BS] = c.bs[col];
+        wsc[S_N2] = c.N2min[col];
+        wsc[S_ZC] = 0.;
+        wsc[S_AREA] = a0;
+        wsc[S_RAREA] = ra;
+        wsc[S_RAREAL] = recip_lo(a0, ra);
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) v.cm[p] = 0ull;
+      v.any = false;
+      v.valid = false;
+    };
+    load_col(cb, vb, m, ws + S_B);
+    load_col(cn, vn, n + m, ws + S_NN);
+    ksel_b = c.ksel[m];
+    ksel_n = c.ksel[n + m];
+  }
+  // static conditions of the BC switch (Psi only changes at MOC updates): bit 0 Psi_SO[1] < 0,
+  // bit 1 Psi_SO[1] >= 0, bit 2 Psi_res_b[1] > 0, bit 3 Psi_res_n[1] < 0
+  int cbits;
+  int ml_ind = nz, first_pos = nz;  // SO_ML.py:228-229, :95
+  bool ml_ok;
+  JfMl q;
+  q.bs = 0.;
+  q.jh = 0;
+  {
+    const size_t bz = (size_t)m * nz, by = (size_t)m * ny;
+    const double PsiSO1 = a.Psi_SO[bz + 1], Pb1 = a.Psi_res_b[bz + 1], Pn1 = a.Psi_res_n[bz + 1];
+    cbits = (PsiSO1 < 0 ? 1 : 0) | (PsiSO1 >= 0 ? 2 : 0) | (Pb1 > 0 ? 4 : 0) | (Pn1 < 0 ? 8 : 0);
+    // ---- mixed layer: Psi_mod (SO_ML.py:228-230) is Psi_b with its leading zeros filled
+    const double *Psi_b = a.Psi_SO + bz;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      const double v = i < nz ? Psi_b[i] : 0.;
+      const unsigned long long nzm = __ballot(i < nz && v != 0.), pm_ = __ballot(i < nz && v > 0.);
+      if (nzm) {
+        const int j = ((int)__ffsll((long long)nzm) - 1) * P + p;
+        ml_ind = j < ml_ind ? j : ml_ind;
+      }
+      if (pm_) {
+        const int j = ((int)__ffsll((long long)pm_) - 1) * P + p;
+        first_pos = j < first_pos ? j : first_pos;
+      }
+    }
+    ml_ok = ml_ind < nz;  // all-zero Psi_b: IndexError in the reference
+    const double fillv = ml_ok ? Psi_b[ml_ind] : 0.;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      wl[L::W_PM + i] = (i < ml_ind || i >= nz) ? fillv : Psi_b[i];
+    }
+    double f1 = 0., f2 = 0., br = 0.;
+    if (lane < ny) {
+      q.bs = a.ml.bs[by + lane];
+      if (ml_ok) {  // loop-invariant parts of the surface-flux tendency (SO_ML.py:250-252)
+        const double ml_h = a.ml.h;
+        f1 = a.ml.surflux[by + lane] / ml_h;
+        f2 = a.ml.rest_mask[by + lane] * a.ml.v_pist / ml_h;
+        br = a.ml.b_rest[by + lane];
+      }
+    }
+    wl[L::W_F + 2 * lane] = f1;
+    wl[L::W_F + 2 * lane + 1] = f2;
+    wl[L::W_BR + lane] = br;
+    if (lane == 0) {
+      // Column.bbot of the basin: only an undefined Psi_SO (neither < 0 nor >= 0) carries it
+      // over a step, and then it is what the last step left in level 0 (the launch's first
+      // step: the caller's value).  The north's is rewritten every step.
+      ws[S_BBOT0] = a.cols.bbot[m];
+    }
+  }
+  __syncthreads();
+  int status = ml_ok ? 0 : 1;
+  bool ps_valid = false;
+  const bool lane0 = lane == 0;
+  const bool ml_act = lane < ny, ml_int = lane >= 1 && lane <= ny - 2;
+
+  // A change of a column's coefficient set (rare) leaves the step loop, reloads and re-enters at
+  // the same step: inside the loop the reload's merge with the resident coefficients cost the
+  // register allocator more than the reload itself.
+  int s = hint_ok ? 0 : nsteps;
+  while (s < nsteps) {
+    {
+      jf_kargs ka = jf_args();
+      auto load_coef = [&](JfCol<P> &r, double *kap, int col, int sel) {
+        const double *kappa = ka->cols.kappa, *dAk = ka->cols.dAkappa, *wA = ka->wA;
+        const size_t sbase = ((size_t)sel * (2 * n) + col) * nz;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int i = lane * P + p;
+          const int ic = i < nz ? i : nz - 1;
+          r.kap[p] = kappa[sbase + ic];
+          if (kap) kap[jf_entry<P>(lane, p)] = r.kap[p];
+          const double w = wA[(size_t)col * nz + ic] - dAk[sbase + ic];
+          const double we = (i >= 1 && i <= nz - 2) ? w : 0.0;
+          r.wn[p] = (we < 0.0) ? -we : 0.0;
+          r.wp[p] = (we < 0.0) ? 0.0 : -we;
+        }
+      };
+      load_coef(cb, nullptr, m, ksel_b);
+      load_coef(cn, wl + L::W_KN, n + m, ksel_n);
+      __builtin_amdgcn_wave_barrier();
+    }
+    // BC switch + both columns of step s; false: a coefficient set changed (nothing done yet)
+    auto columns_step = [&](int lane_o, double *wl, double *ws) -> bool {
+#ifndef JF_NO_PRIO_ROTATE
+      // The SIMD's arbiter favours its oldest wave: left alone its four waves (waves w, w+4,
+      // w+8, w+12 of the block) finish ~20 us apart and the last runs alone; with priorities
+      // rotated by step number most SIMDs even out, but a wave that falls behind stays behind
+      // (one wave in ~15 blocks ended 25 us after its mates).  So each wave publishes its step
+      // counter and takes its priority from its rank: the one furthest behind issues first.
+      {
+        int *prog = reinterpret_cast<int *>(lds + L::PROG) + (wave & 3) * 4;
+        prog[wave >> 2] = s;
+        const int4 pv = *reinterpret_cast<const int4 *>(prog);
+        const int p0 = __builtin_amdgcn_readfirstlane(pv.x), p1 = __builtin_amdgcn_readfirstlane(pv.y),
+                  p2 = __builtin_amdgcn_readfirstlane(pv.z), p3 = __builtin_amdgcn_readfirstlane(pv.w);
+        const int lo = min(min(p0, p1), min(p2, p3)), hi = max(max(p0, p1), max(p2, p3));
+        if (s <= lo) __builtin_amdgcn_s_setprio(3);
+        else if (s >= hi) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(1);
+      }
+#endif
+      // ---- bottom-BC switch (run_JansenNadeau_2018.py:233-254), vector code: lane 0 owns
+      // levels 0 and 1 of both columns and point 0 of the channel; the other lanes compute along
+      double bbot_b, bbot_n;
+      {
+        const bool c_south = (cbits & 1) != 0, c_nosouth = (cbits & 2) != 0, c_pb = (cbits & 4) != 0,
+                   c_pn = (cbits & 8) != 0;
+        const double bb0 = cb.b[0], bb1 = cb.b[1], bn0 = cn.b[0], bn1 = cn.b[1], bs0 = q.bs;
+        const bool from_north = c_pb && bn0 < bb1 && bn0 < bs0;
+        double nb = (s == 0) ? ws[S_BBOT0] : bb0;
+        nb = c_south ? bs0 : nb;         // bottom water coming in from the south
+        nb = c_nosouth ? bb1 : nb;       // no bottom water coming in: no-flux BBC
+        bbot_b = from_north ? bn0 : nb;  // bottom water coming in from the north
+        const bool from_basin = c_pn && bb0 < bn1;
+        bbot_n = from_basin ? bb0 : bn1;
+        const int kb_l = from_north ? 1 : (c_nosouth ? 0 : (c_south ? 1 : ksel_b));
+        const int kn_l = from_basin ? 1 : 0;
+        const int kb = __builtin_amdgcn_readfirstlane(kb_l),
+                  kn = __builtin_amdgcn_readfirstlane(kn_l);
+        if (__builtin_expect(kb != ksel_b || kn != ksel_n, 0)) {
+          JF_RARE(2)
+          ksel_b = kb;
+          ksel_n = kn;
+          return false;
+        }
+      }
+      // ---- basin.timestep / north.timestep, do_conv=True (:257-258)
+      // (both convective adjustments first: their rare branches then precede one straight block
+      // of arithmetic, whose scheduling fences keep one slot pair's tables live at a time)
+      jf_convect<P>(cb.b, vb, lds, ws + S_B, lane_o, nz);
+      jf_convect<P>(cn.b, vn, lds, ws + S_NN, lane_o, nz);
+      cb.b[0] = lane0 ? bbot_b : cb.b[0];  // column.py:232 (after convect: it may write level 0)
+      cn.b[0] = lane0 ? bbot_n : cn.b[0];
+      __builtin_amdgcn_sched_barrier(0);
+      jf_vertadvdiff<P, true>(cb, lds, ws + S_B, nullptr, lane_o, dt);
+      __builtin_amdgcn_sched_barrier(0);
+      jf_vertadvdiff<P, false>(cn, lds, ws + S_NN, wl + L::W_KN, lane_o, dt);
+      __builtin_amdgcn_sched_barrier(0);
+      return true;
+    };
+    if (ml_ok) {
+    for (; s < nsteps; ++s) {
+      // address bases the optimiser must not see through: it would hoist one derived address per
+      // access pattern out of the loop (dozens of registers, then spilled) instead of folding
+      // the constants into the instructions' offset fields
+      int lane_o = lane, woff = wave * L::PER_WAVE;
+      asm volatile("" : "+v"(lane_o), "+s"(woff));
+      const int a4 = lane_o << 2;
+      double *wl = lds + L::WAVE0 + woff, *ws = wl + L::W_S;
+      if (__builtin_expect(!columns_step(lane_o, wl, ws), 0)) break;
+      JF_RARE(0)
+      // ---- channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi) (:261), ml_step_reg's operations
+      {
+        const double *bb = wl + L::W_BB, *pm = wl + L::W_PM;
+#pragma unroll
+        for (int hh = 0; hh < P / 2; ++hh)
+          *reinterpret_cast<double2 *>(wl + L::W_BB + lane_o * P + 2 * hh) =
+              make_double2(cb.b[2 * hh], cb.b[2 * hh + 1]);
+        __builtin_amdgcn_wave_barrier();
+        // Psi_s = np.interp(bs, b_basin, Psi_mod) (:232).  A point is in the interval it was in
+        // one step earlier or -- every other step for some point of a member -- in the one next
+        // to it: that is settled with two table reads; the interpolation then reads its interval
+        // (like np.interp this takes b_basin as sorted); anything else searches like np.interp.
+        double ps;
+        {
+          const double x = q.bs;
+          const int j0 = q.jh;  // <= nz - 2
+          const double x0 = bb[j0], x1 = bb[j0 + 1];
+          int j = j0 + (x >= x1 ? 1 : 0) - (x < x0 ? 1 : 0);
+          j = j < 0 ? 0 : (j > nz - 2 ? nz - 2 : j);
+          const double lx = bb[j], hx = bb[j + 1], lf = pm[j], hf = pm[j + 1];
+          const double xlo = bb[0], xhi = bb[nz - 1];
+          const bool hit = (lx <= x) && (x < hx);
+          ps = interp_finish(x, j, lx, hx, lf, hf);
+          // np.interp: NaN first, then beyond the table's ends (x equal to the last node also
+          // returns the last value)
+          const bool isnan_x = x != x, above = x >= xhi, below = x < xlo;
+          if (below) ps = pm[0];
+          if (above) ps = pm[nz - 1];
+          if (isnan_x) ps = x;
+          q.jh = j;
+          const bool search = ml_act && !hit && !isnan_x && !above && !below;
+          if (__builtin_expect(__ballot(search) != 0ull, 0)) {
+            JF_RARE(3)
+            if (search) {  // np.interp's upper-bound search from scratch
+              int lo_i = 0, hi_i = nz;
+              while (lo_i < hi_i) {
+                const int mid = lo_i + ((hi_i - lo_i) >> 1);
+                if (x >= bb[mid])
+                  lo_i = mid + 1;
+                else
+                  hi_i = mid;
+              }
+              const int jb = lo_i - 1;
+              // (jb = -1 only when the basin column holds NaNs: stay inside the row)
+              const int jj = (jb == nz - 1) ? nz - 2 : (jb < 0 ? 0 : jb);
+              q.jh = jj;
+              ps = (jb == nz - 1) ? pm[nz - 1]
+                                  : interp_finish(x, jb, bb[jj], bb[jj + 1], pm[jj], pm[jj + 1]);
+            }
+          }
+        }
+        // argmin(bs): first minimum, a NaN wins (np.argmin); 0 when no point lies below point 0
+        int amin = 0;
+        {
+          const double v = ml_act ? q.bs : __builtin_inf();
+          const double v0 = lane_value(q.bs, 0);
+          if (__builtin_expect(__ballot(!(v >= v0)) != 0ull, 0)) {
+            JF_RARE(5)
+            const double mn = wave_min_f64(v);
+            const unsigned long long at_min = __ballot(ml_act && v == mn);
+            const unsigned long long nanm = __ballot(ml_act && v != v);
+            const int mi = at_min ? (int)__ffsll((long long)at_min) - 1 : 0;
+            amin = nanm ? (int)__ffsll((long long)nanm) - 1 : mi;
+          }
+        }
+        if (lane < amin || lane0) ps = 0.;  // :240-243
+        const bool upwell = (__ballot(ps > 0) & 2ull) != 0ull;  // set_boundary_conditions, :93-98
+        if (__builtin_expect(upwell && first_pos >= nz, 0)) {
+          ml_ok = false;  // IndexError in the reference; the mixed layer stops evolving
+          status = 1;
+          ++s;
+          break;  // the rest of the launch steps the columns only (loop below)
+        } else {
+          __builtin_amdgcn_sched_barrier(0);  // (fence: the constants below are read here, not earlier)
+          const double2 *K2 = reinterpret_cast<const double2 *>(lds + L::KML);
+          const double2 k0 = K2[0], k1 = K2[1], k2 = K2[2], k3 = K2[3], k4 = K2[4];
+          const double k_1ms = lds[L::KML + K_1MS];
+          const double2 ff = *reinterpret_cast<const double2 *>(wl + L::W_F + 2 * lane_o);
+          const double brest = wl[L::W_BR + lane_o];
+          const double bsouth = upwell ? bb[first_pos < nz ? first_pos : 0] : 0.;
+          double bs = q.bs;
+          // lane 0 takes the boundary value; the shifted copies are taken where lane 0's new
+          // value is (bs_dn, bl) or is not (bs_up, bu) part of them
+          const double bs_up = from_next_lane_z(bs);
+          bs = lane0 ? (upwell ? bsouth : bs_up) : bs;
+          const double bs_dn = from_prev_lane_z(bs);
+          // tendencies from surface flux / restoring and upwind advection (:250-259)
+          const double flux = ff.x + ff.y * (brest - bs);
+          double adv;
+          {
+            const double d = (ps < 0.) ? (bs_up - bs) : (bs - bs_dn);
+            const double num = -ps * 1e6 * d;
+            // num / h / L / dy, each quotient correctly rounded (k0..k4 = {1/h lo, 1/h | h,
+            // 1/L lo | 1/L, L | 1/dy lo, 1/dy | dy, s/2})
+            const double q1 = div_by_recip2(num, k1.x, k0.y, k0.x);
+            const double q2 = div_by_recip2(q1, k2.y, k2.x, k1.y);
+            const double t = div_by_recip2(q2, k4.x, k3.y, k3.x);
+            adv = (ml_int && ps != 0. && ps == ps) ? t : 0.;
+          }
+          bs = bs + dt * (flux + adv);  // every tendency uses the old bs
+          const double bu = from_next_lane_z(bs);
+          if (!upwell) bs = lane0 ? bu : bs;  // no-flux BC re-set (:264-266)
+          // Crank-Nicolson diffusion (:191-196): U x = V bs by parallel cyclic reduction
+          {
+            const double bl = from_prev_lane_z(bs);
+            const double sh = k4.y;
+            double r = bs;  // rows 0 and ny-1 of V are identity rows
+            if (ml_int) r = sh * bl + k_1ms * bs + sh * bu;
+            if (!ml_act) r = 0.;
+            bs = jf_pcr_solve(r, lds + L::PCR, lane_o, a4);
+          }
+          {
+            const double up = from_next_lane_z(bs);
+            const double v2 = upwell ? bsouth : up;  // final BC re-set (:274)
+            bs = lane0 ? v2 : bs;
+          }
+          q.bs = bs;
+          wl[L::W_PS + lane_o] = ps;
+          ps_valid = true;
+        }
+      }
+    }
+    } else {
+      for (; s < nsteps; ++s) {
+        int lane_o = lane, woff = wave * L::PER_WAVE;
+        asm volatile("" : "+v"(lane_o), "+s"(woff));
+        double *wl = lds + L::WAVE0 + woff, *ws = wl + L::W_S;
+        if (__builtin_expect(!columns_step(lane_o, wl, ws), 0)) break;
+      }
+    }
+  }
+
+  // ---- results
+  jf_kargs ka = jf_args();
+  const size_t by = (size_t)m * ny;
+  bool bad = false;
+  {
+    double *bout = ka->cols.b;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      if (i < nz) {
+        if (m_ok && hint_ok) {
+          bout[(size_t)m * nz + i] = cb.b[p];
+          bout[(size_t)(n + m) * nz + i] = cn.b[p];
+        }
+        bad |= !isfinite(cb.b[p]) || !isfinite(cn.b[p]);
+      }
+    }
+  }
+  if (lane < ny) {
+    bad |= !isfinite(q.bs);
+    if (m_ok && hint_ok) {
+      ka->ml.bs[by + lane] = q.bs;
+      double *Psi_s = ka->ml.Psi_s;
+      if (Psi_s && ps_valid) Psi_s[by + lane] = wl[L::W_PS + lane];
+    }
+  }
+  const bool anybad = __ballot(bad) != 0ull;
+  if (lane == 0 && m_ok) {
+    if (hint_ok && nsteps > 0) {
+      // Column.bbot after the last step = what that step imposed on level 0
+      double *bbot = const_cast<double *>(ka->cols.bbot);
+      int32_t *ksel = const_cast<int32_t *>(ka->cols.ksel);
+      bbot[m] = cb.b[0];
+      bbot[n + m] = cn.b[0];
+      ksel[m] = ksel_b;
+      ksel[n + m] = ksel_n;
+    }
+    int32_t *nonfinite = ka->cols.nonfinite;
+    if (nonfinite) {
+      nonfinite[m] = anybad ? 1 : 0;
+      nonfinite[n + m] = anybad ? 1 : 0;
+    }
+    int32_t *st = ka->ml.status;
+    if (st) st[m] = status | (anybad ? 2 : 0) | (hint_ok ? 0 : 16);
+  }
+  PM_WAVE_END(m_raw)
+}
+
+template <int P>
+static int launch_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st) {
+  const size_t lds = (size_t)JfLds<P>::TOTAL * sizeof(double);
+  const unsigned grid = (unsigned)((a.n + JF_WAVES - 1) / JF_WAVES);
+  hipLaunchKernelGGL((k_jn2018_fast<P>), dim3(grid), dim3(64 * JF_WAVES), lds, st, a, dt, nsteps);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
+bool jn2018_fast_applies(const pm_jn2018 &a) {
+  return (a.hints & PM_JN_UNIFORM_AREA) != 0 && a.ml.ny <= 64 && a.cols.nz <= 256 &&
+         a.cols.nz >= 4;
+}
+
+int launch_jn2018_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st) {
+  return a.cols.nz <= 128 ? launch_fast<2>(a, dt, nsteps, st) : launch_fast<4>(a, dt, nsteps, st);
+}
+
+}  // namespace pm
+#endif

@@ -9,6 +9,10 @@
 #include "psi_so.hip.h"
 #include "so_ml.hip.h"
 #include "comm.hip.h"
+#ifdef PM_PHASE_PROFILE
+#define PM_JF_IN_MAIN_TU
+#include "jn2018_fast.hip"
+#endif
 
 namespace pm {
 
@@ -412,6 +416,8 @@ int pm_jn2018_steps(const pm_jn2018 *jn, double dt, int32_t nsteps, pm_stream_t 
   PM_REQUIRE(nsteps >= 0, "nsteps < 0");
   if (a.n == 0 || nsteps == 0) return PM_OK;
   hipStream_t st = resolve_stream(stream);
+  const bool force_general = getenv("PYMOC_JN_GENERAL") != nullptr;  // A/B experiments
+  if (!force_general && jn2018_fast_applies(a)) return launch_jn2018_fast(a, dt, nsteps, st);
   switch ((c.nz + 63) / 64) {
     case 1: return launch_jn2018_steps<1>(a, dt, nsteps, st);
     case 2: return launch_jn2018_steps<2>(a, dt, nsteps, st);
@@ -552,6 +558,12 @@ extern "C" int pm_debug_prof(unsigned long long *out16) {
   unsigned long long zero[16] = {0};
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pm::pm_prof), sizeof(zero)) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(pm::pm_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+  return 0;
+}
+extern "C" int pm_debug_jf_rare(unsigned long long *out8) {
+  unsigned long long zero[72] = {0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pm::jf_rare), sizeof(zero)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(pm::jf_rare), zero, sizeof(zero)) != hipSuccess) return -1;
   return 0;
 }
 extern "C" int pm_debug_wave_times(unsigned long long *out, int n) {

@@ -454,6 +454,7 @@ __device__ __forceinline__ bool ml_step_reg(MlReg &q, const MlLds &w, const MlSt
   return true;
 }
 
+#ifndef PM_SO_ML_DEVICE_FUNCTIONS_ONLY  // (jn2018_fast.hip shares the device functions only)
 __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_so_ml_step(pm_so_ml a, double dt) {
   extern __shared__ double lds_all[];
   const int lane = threadIdx.x & 63;
@@ -539,6 +540,8 @@ __global__ __launch_bounds__(64 * ML_WAVES_PER_BLOCK) void k_so_ml_step(pm_so_ml
   }
 }
 
+#endif
+
 // Bottom boundary condition / BBL diffusivity switching of run_JansenNadeau_2018.py:233-254.
 // Columns are stored basin rows [0, n), north rows [n, 2n); coefficient set 0 = kappa,
 // set 1 = kappaeff.  Scalar form shared by the stand-alone kernel and the fused loop.
@@ -569,6 +572,7 @@ __device__ __forceinline__ void jn2018_bc(BcState &st, double PsiSO1, double Pb1
   }
 }
 
+#ifndef PM_SO_ML_DEVICE_FUNCTIONS_ONLY
 __global__ void k_jn2018_bc_switch(pm_jn2018_bc a) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= a.n) return;
@@ -585,6 +589,8 @@ __global__ void k_jn2018_bc_switch(pm_jn2018_bc a) {
   a.ksel[m] = st.ksel_b;
   a.ksel[a.n + m] = st.ksel_n;
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------
 // Fused JN2018 time loop: nsteps x [BC switch -> basin.timestep -> north.timestep ->
@@ -828,6 +834,7 @@ inline size_t ml_prop_bytes(int ny) {
   return ny <= 64 ? (size_t)PCR_ROWS * 64 * sizeof(double) : 0;
 }
 
+#ifndef PM_SO_ML_DEVICE_FUNCTIONS_ONLY
 inline int launch_so_ml(const pm_so_ml &a, double dt, hipStream_t st) {
   const size_t per_wave = ml_lds_bytes(a.nz, a.ny), prop = ml_prop_bytes(a.ny);
   int wpb = ML_WAVES_PER_BLOCK;
@@ -842,6 +849,8 @@ inline int launch_so_ml(const pm_so_ml &a, double dt, hipStream_t st) {
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
+
+#endif
 
 template <int P>
 int launch_jn2018_steps(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st) {
@@ -868,5 +877,9 @@ int launch_jn2018_steps(const pm_jn2018 &a, double dt, int nsteps, hipStream_t s
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
+
+// the residency-first rebuild of the fused loop (jn2018_fast.hip): uniform Area, ny <= 64
+bool jn2018_fast_applies(const pm_jn2018 &a);
+int launch_jn2018_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st);
 
 }  // namespace pm
