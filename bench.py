@@ -41,6 +41,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
+# what pymoc_amd.launch.child_env gives its ranks, for every other launcher
+# (torch.distributed.run) too; pymoc_amd._lib repeats it right before it loads the engine
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6   # fp64 vector: 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz

@@ -6,6 +6,12 @@ raises; if no HIP device is visible, the first call that needs one raises.
 import ctypes as C
 import os
 
+# dmabuf IPC (the only kind this platform's driver supports): RCCL and any cross-process
+# sharing of device memory need it, and the HSA runtime reads it when the engine is loaded --
+# so it is set here, before the dlopen below, whoever started this process (pymoc_amd.launch,
+# torch.distributed.run, a plain shell); an explicit setting by the caller wins
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpymoc_hip.so")
 

@@ -382,9 +382,12 @@ __device__ __forceinline__ int so_gm_adaptive(SoMesh w, double ua, double ub, in
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) added += __shfl_xor(added, o, 64);
     if (added == 0) break;                       // status 0
-    if (m + added > max_nodes || m + added > SO_BIG_CAP) {
-      if (m + added <= max_nodes) *status_bits |= 8;  // SciPy would refine further than we follow
-      break;                                     // (beyond max_nodes SciPy stops here too)
+    static_assert(SO_BIG_CAP >= 1000, "the general solver follows meshes up to max_nodes");
+    if (m + added > max_nodes) {
+      // solve_bvp stops here with status 1 ("maximum number of mesh nodes is exceeded") and
+      // returns the solution of this mesh: so do we, and say so (status bit 3)
+      *status_bits |= 8;
+      break;
     }
     __builtin_amdgcn_wave_barrier();
     // ---- G: new mesh (modify_mesh); chunk-wise prefix sum of 1 + cnt

@@ -41,6 +41,47 @@ class SO_ML(object):
     self._batch = None
     self._shape = None
 
+  # ---- the building blocks of advdiff as separate host functions, as in the reference
+  # (SO_ML.py:77-196): NumPy on self.bs / self.Psi_s, for callers that use them one by one.
+  # `advdiff` / `timestep` do the whole update in one kernel launch and do not call them.
+  def set_boundary_conditions(self, b_basin, Psi_b):
+    """Southern end of the channel (SO_ML.py:77-98): with upwelling next to the boundary
+    (Psi_s[1] > 0) it takes the buoyancy of the densest upwelling basin water, otherwise the
+    no-flux condition copies the neighbouring point."""
+    if self.Psi_s[1] > 0:
+      first_up = np.argwhere(Psi_b > 0)[0][0]
+      self.bs[0] = b_basin[first_up]
+    else:
+      self.bs[0] = self.bs[1]
+
+  def calc_advective_tendency(self, dy):
+    """Upwind meridional advection by Psi_s on the (uniform) grid (SO_ML.py:100-134):
+    -Psi_s 1e6 (one-sided difference against the flow) / h / L / dy at interior points."""
+    tend = 0. * self.y
+    psi, bs = self.Psi_s[1:-1], self.bs
+    south, north = psi < 0., psi > 0.   # flow direction decides which neighbour is upstream
+    inner = tend[1:-1]                  # a view: the boundary points keep their zeros
+    inner[south] = -psi[south] * 1e6 * (bs[2:][south] - bs[1:-1][south]) / self.h / self.L / dy
+    inner[north] = -psi[north] * 1e6 * (bs[1:-1][north] - bs[:-2][north]) / self.h / self.L / dy
+    return tend
+
+  def calc_diffusion_matrix(self, s):
+    """tridiag(-s/2, 1+s, -s/2) with identity rows at both ends (SO_ML.py:136-165): U for +s,
+    V for -s of the Crank-Nicolson step U bs_new = V bs."""
+    n = len(self.y)
+    M = (np.diag(np.full(n - 1, -s / 2.), -1) + np.diag(np.full(n, 1 + s), 0) +
+         np.diag(np.full(n - 1, -s / 2.), 1))
+    M[0, :2] = (1, 0)
+    M[-1, -2:] = (0, 1)
+    return M
+
+  def calc_implicit_diffusion(self, dy, dt):
+    """One Crank-Nicolson diffusion step of bs (SO_ML.py:167-196), the reference's way: dense
+    inverse of U.  (The kernel solves the same system by cyclic reduction / a Thomas sweep.)"""
+    s = self.Ks * dt / dy**2
+    U, V = self.calc_diffusion_matrix(s), self.calc_diffusion_matrix(-s)
+    return np.dot(np.dot(np.linalg.inv(U), V), self.bs)
+
   # one arena: in [bs | surflux | rest_mask | b_rest | b_basin | Psi_b]  out [bs | Psi_s | status]
   def advdiff(self, b_basin, Psi_b, dt):
     import ctypes as C

@@ -20,8 +20,11 @@ the moment the state is needed:
     `MAX_QUEUE` steps long, or the object is deleted.
 The queued steps are bit-identical to stepping one by one (the kernel's step-splitting
 invariance, tests/test_column_gpu.py).  The one observable difference to write-through:
-a variable that ALIASES the array and is read directly (not through `col.b` or another
-pymoc_amd object) between steps shows the last flushed state.  `LAZY = False` (or the
+a variable that ALIASES the array and is READ directly (not through `col.b` or another
+pymoc_amd object) between steps shows the last flushed state.  WRITES through such an alias
+are detected at the next `timestep` call (the array is compared with its state when the queue
+was opened) and applied after the steps queued before them, as the reference would -- except a
+write of the very value the entry already had, which leaves no trace.  `LAZY = False` (or the
 environment variable PYMOC_EAGER=1) restores a launch per call.
 For throughput use `pymoc_amd.ColumnBatch` / the ensemble drivers: state stays in HBM there.
 """
@@ -46,14 +49,19 @@ def flush_all():
       col._flush()
 
 
-def _static_token(fn):
-  """Cheap change detector for a kappa / Area callable: identity for user callables, the
-  VALUES for make_func closures over an array or a float (the reference re-evaluates them
-  every step, so an in-place edit of the aliased array counts)."""
+def _static_token(fn, z):
+  """Change detector for a kappa / Area callable: its VALUES on the grid.  The reference
+  evaluates kappa(z) and Area(z) in every step (column.py:122, :241-248), so anything that changes
+  what the callable returns counts -- an in-place edit of the array a make_func closure aliases,
+  a user callable reading a global or a closure variable the loop updates.  make_func closures
+  over a float or an array are recognised and compared without a call; every other callable is
+  called on z (O(nz) host work per timestep call)."""
   src = getattr(fn, "_pm_source", None)
   if isinstance(src, np.ndarray):
     return (id(fn), src.tobytes())
-  return (id(fn), src)
+  if src is not None:
+    return (id(fn), src)
+  return (id(fn), np.asarray(fn(z), dtype=np.float64).tobytes())
 
 
 class Column(object):
@@ -80,7 +88,7 @@ class Column(object):
     self.N2min = N2min
     self._arena = None
     self._static_tok = None
-    self._q = None  # queued identical timesteps: [count, wA, dt, do_conv, params]
+    self._q = None  # queued identical timesteps: [count, wA, dt, do_conv, params, b at opening]
     self._b = make_array(b, self.z, 'b')
     self.bz = np.gradient(self._b, z)
 
@@ -183,8 +191,8 @@ class Column(object):
       self._static_tok = params[4:]
 
   def _params(self):
-    return (self.bs, self.bbot, self.bzbot, self.N2min, _static_token(self.kappa),
-            _static_token(self.Area))
+    return (self.bs, self.bbot, self.bzbot, self.N2min, _static_token(self.kappa, self.z),
+            _static_token(self.Area, self.z))
 
   def _run(self, ops, do_conv, wA=None, dt=1., vdx_in=None, b_in=None, nsteps=1, params=None):
     z, nz, h = self.z, self.z.size, None
@@ -210,10 +218,11 @@ class Column(object):
         self._vdx_ptr if vdx_in is not None else None,
         self._bin_ptr if vdx_in is not None else None, float(dt), int(nsteps), int(ops), 0,
         None))
-    _lib.check(_lib.lib.pm_memcpy_d2h(self._b.ctypes.data if self._b.flags.c_contiguous and
-                                      self._b.dtype == np.float64 else self._out.ctypes.data,
+    direct = (self._b.flags.c_contiguous and self._b.flags.writeable and
+              self._b.dtype == np.float64 and self._b.size == nz)
+    _lib.check(_lib.lib.pm_memcpy_d2h(self._b.ctypes.data if direct else self._out.ctypes.data,
                                       self._arena.ptr, nz * 8, None))
-    if not (self._b.flags.c_contiguous and self._b.dtype == np.float64):
+    if not direct:
       self._b[...] = self._out
 
   def _flush(self):
@@ -221,9 +230,20 @@ class Column(object):
     q, self._q = self._q, None
     _pending.discard(self)
     if q is not None:
-      count, wA, dt, do_conv, params = q
+      count, wA, dt, do_conv, params, b0 = q
+      # A write into the array through an alias while steps were queued (`arr = col.b` once,
+      # `arr[k] = ...` inside the loop): the reference would have stepped first and then taken
+      # the write.  The queued steps run from the state the queue was opened with and the
+      # entries written since (those that differ from it) are re-applied on top.
+      edited = None
+      if not np.array_equal(self._b, b0, equal_nan=True):
+        edited = ~((self._b == b0) | (np.isnan(self._b) & np.isnan(b0)))
+        vals = self._b[edited].copy()
+        self._b[...] = b0
       # PM_OP_TIMESTEP without horadv inputs = convect + vertadvdiff on the fused fast path
       self._run(_lib.PM_OP_TIMESTEP, do_conv, wA=wA, dt=dt, nsteps=count, params=params)
+      if edited is not None:
+        self._b[edited] = vals
 
   # ---- the time-stepping API (column.py:210-348)
   def vertadvdiff(self, wA, dt, do_conv=False):
@@ -263,12 +283,14 @@ class Column(object):
     q = self._q
     if q is not None:
       if (q[0] < MAX_QUEUE and q[2] == dt and q[3] == do_conv and q[4] == params and
-          (q[1] is wA or np.array_equal(q[1], wA))):
+          (q[1] is wA or np.array_equal(q[1], wA)) and
+          np.array_equal(self._b, q[5], equal_nan=True)):  # (no write through an alias since)
         q[0] += 1
         return
       self._flush()
     # a new queue: coefficients are evaluated and uploaded now (the device is idle), wA is
     # snapshotted (the caller may reuse its buffer; the reference reads it during the call)
     self._sync_statics(params)
-    self._q = [1, np.array(wA, dtype=np.float64, copy=True), dt, bool(do_conv), params]
+    self._q = [1, np.array(wA, dtype=np.float64, copy=True), dt, bool(do_conv), params,
+               np.array(self._b, dtype=np.float64, copy=True)]
     _pending.add(self)

@@ -174,6 +174,36 @@ class Psi_SO(object):
     N2[-1] = (b[-1] - b[-2]) / dz[-1]
     return make_func(N2, self.z, 'N2')
 
+  # The two quadratic tapers of psi_SO.py:164-216 (host NumPy; the kernel applies the same
+  # expressions per level).  `H is None` means "no taper".
+  def calc_bottom_taper(self, H, z):
+    """Weight 1 - (depth into the layer of thickness H above the bottom z[0])^2 / H^2."""
+    if H is None:
+      return 1.
+    into = np.maximum(z[0] + H - z, 0.)
+    return 1. - into**2. / H**2.
+
+  def calc_top_taper(self, H, z, scalar=True):
+    """Weight 1 - (height into the layer of thickness H below the surface)^2 / H^2.  Without H:
+    1, or (scalar=False, the Ekman taper) ones with a 0 at the surface level."""
+    if H is not None:
+      into = np.maximum(z + H, 0)
+      return 1 - into**2. / H**2.
+    if scalar:
+      return 1.
+    taper = np.ones(np.size(z))
+    taper[-1] = 0.
+    return taper
+
+  def bc_GM(self, ya, yb):
+    """Boundary residuals of the GM boundary-value problem (psi_SO.py:245-275): the eddy
+    transport vanishes at bottom and surface, or (bvp_with_Ek) cancels the Ekman transport
+    there -- Psi_Ek is in Sv, the unknown in m^3/s."""
+    if not self.bvp_with_Ek:
+      return np.array([ya[0], yb[0]])
+    ek = self.Psi_Ek
+    return np.array([ya[0] + ek[0] * 1e6, yb[0] + ek[-1] * 1e6])
+
   def calc_Ekman(self):
     return self._run(_lib.PM_SO_OP_EKMAN)[3].copy()
 

@@ -84,6 +84,19 @@ class Psi_Thermwind(object):
     _lib.check(_lib.lib.pm_memcpy_d2h(out.ctypes.data, o, out.nbytes, None))
     return out
 
+  # ---- the boundary-value problem the reference hands to solve_bvp (psi_thermwind.py:72-123);
+  # host NumPy, kept for callers that inspect or reuse them (the device solve does not call them)
+  def bc(self, ya, yb):
+    """Boundary residuals: Psi vanishes at the bottom (ya) and at the surface (yb)."""
+    return np.array([ya[0], yb[0]])
+
+  def ode(self, z, y):
+    """First-order form of Psi'' = (b2 - b1)/f with y = (Psi, Psi'): rows (y[1], rhs)."""
+    from .column import flush_all
+    flush_all()  # b1 / b2 may alias the array of a Column with queued steps
+    inv_f = 1. / self.f
+    return np.vstack((y[1], inv_f * (self.b2(z) - self.b1(z))))
+
   def solve(self):
     from .. import _lib
     if self._b1_callable or self._b2_callable:
@@ -109,6 +122,9 @@ class Psi_Thermwind(object):
     s37 = 0.5 * (3. / 7.) ** 0.5
     rf = 1. / self.f
     cap = 1024
+    if z.size > cap:
+      raise ValueError("Psi_Thermwind.solve with callable profiles follows solve_bvp's mesh "
+                       "refinement on meshes of up to %d nodes; z has %d levels" % (cap, z.size))
     if getattr(self, "_mesh_arena", None) is None:
       # in : x | b1 | b2 | b1_mid | b2_mid | g | g_lob[2] | f      out: Psi | dPsi | rms
       self._mesh_arena = DeviceArray((12 * cap + 8,))

@@ -10,6 +10,7 @@ is covered on CPU (a test vehicle, not a compute fallback).
 """
 import ctypes as C
 import os
+import struct
 import time
 
 import numpy as np
@@ -71,31 +72,53 @@ def rendezvous_path(env=None, rendezvous_dir="/tmp"):
                                                for c in key))
 
 
+_TAG = struct.Struct("<qd")  # launcher pid (the parent all ranks of one launch share), time
+
+
 def publish_id(path, payload):
-  """Rank 0: replace whatever a crashed earlier run left at `path` with the new id."""
+  """Rank 0: replace whatever a crashed earlier run left at `path` with the new id, followed
+  by the pid of this rank's parent (the launcher: torch.distributed.run's agent or
+  pymoc_amd.launch start every rank of a launch from ONE process) and the time."""
   try:
     os.remove(path)
   except OSError:
     pass
   tmp = path + ".tmp%d" % os.getpid()
   with open(tmp, "wb") as f:
-    f.write(payload)
+    f.write(payload + _TAG.pack(os.getppid(), time.time()))
   os.replace(tmp, path)
 
 
-def wait_for_id(path, nbytes, started, timeout_s=300.0, stale_slack_s=30.0):
-  """Other ranks: wait for a complete id file that is not a leftover of an earlier run (a
-  file older than this process by more than `stale_slack_s` is stale: ranks of one launch
-  start within seconds of each other, and rank 0 replaces leftovers when it starts)."""
+def unique_key(env=None):
+  """True when the launcher gave this launch an id of its own (PYMOC_RUN_ID, or a
+  TORCHELASTIC_RUN_ID other than torch.distributed.run's static-rendezvous default 'none'):
+  the rendezvous path then cannot belong to an earlier launch."""
+  env = os.environ if env is None else env
+  return bool(env.get("PYMOC_RENDEZVOUS") or env.get("PYMOC_RUN_ID") or
+              env.get("TORCHELASTIC_RUN_ID", "none") != "none")
+
+
+def wait_for_id(path, nbytes, started, timeout_s=300.0, stale_slack_s=30.0, trust_path=None):
+  """Other ranks: wait for a complete id file that is not the leftover of a crashed earlier
+  launch.  A file is taken when (a) the path is unique to this launch (`unique_key`), or (b) it
+  was written by a child of this rank's own parent -- the launcher's pid travels with the id --
+  or, for spawners with one wrapper process per rank, (c) it is not older than this process by
+  more than `stale_slack_s` (ranks of a launch start within seconds; rank 0 replaces leftovers
+  when it starts).  Rule (b) is what `python -m torch.distributed.run` with its default run id
+  relies on: consecutive launches on one MASTER_PORT (the driver's N = 1, 2, 4, 8 series) have
+  different agents, so the id of a launch that died cannot be mistaken for this one's."""
+  trust = unique_key() if trust_path is None else trust_path
   t0 = time.time()
   while True:
     try:
       st = os.stat(path)
-      if st.st_size >= nbytes and st.st_mtime >= started - stale_slack_s:
+      if st.st_size >= nbytes + _TAG.size:
         with open(path, "rb") as f:
-          data = f.read(nbytes)
-        if len(data) == nbytes:
-          return data
+          data = f.read(nbytes + _TAG.size)
+        if len(data) == nbytes + _TAG.size:
+          ppid, _ = _TAG.unpack(data[nbytes:])
+          if trust or ppid == os.getppid() or st.st_mtime >= started - stale_slack_s:
+            return data[:nbytes]
     except OSError:
       pass
     if time.time() - t0 > timeout_s:

@@ -118,6 +118,44 @@ def test_psi_so_tau_array_and_wrapper_api(gpu):
   assert str(e.value) == "('bs', 'needs to be either function, numpy array, or float')"
 
 
+def test_reference_unit_tests_of_calc_ekman(gpu):
+  """tests/modules/test_psi_SO.py:144-203 re-expressed against the wrapper: constant wind,
+  a wind that varies with latitude (averaged north of each level's outcrop), the sill taper and
+  the Ekman-layer taper; and calc_Ekman agrees with the class's own taper helpers."""
+  S = gpu.Psi_SO(z=np.linspace(-4000, 0, 81), y=np.linspace(0, 2.0e6, 51),
+                 b=np.linspace(0.03, -0.001, 81), bs=np.linspace(0.05, 0.10, 51), tau=0.12)
+  full = (S.L * 0.12) / (S.f * S.rho)
+  want = np.full(81, full)
+  want[-1] = 0
+  assert np.all(np.around(want, 3) == np.around(S.calc_Ekman(), 3))
+  # wind varying with latitude: every 5th surface point is an outcrop of a level
+  b, bs = np.linspace(0.03, 0.01, 21), np.linspace(0.01, 0.02, 51)
+  y, z, tau = np.linspace(0, 2e6, 51), np.linspace(-4000, 0, 21), np.linspace(0.2, 0.12, 51)
+  V = gpu.Psi_SO(y=y, z=z, b=b, bs=bs, tau=tau)
+  tau_ave = np.zeros(21)
+  tau_ave[0:11] = tau[-1]
+  tau_ave[11:-1] = [np.mean(tau[-i * 5 - 1:]) for i in range(1, 10)]
+  assert np.all(np.around(V.calc_Ekman(), 3) == np.around(V.L * tau_ave / (V.f * V.rho), 3))
+  # sill taper: quadratic over the bottom 1000 m
+  S.Hsill = 1000.0
+  want = np.full(81, full)
+  want[:20] = [full * (1 - (-3000 - zz)**2 / 1.0e6) for zz in S.z[:20]]
+  want[-1] = 0
+  got = S.calc_Ekman()
+  assert np.all(np.around(want, 3) == np.around(got, 3))
+  assert np.allclose(got, np.full(81, full) * S.calc_bottom_taper(1000.0, S.z) *
+                     S.calc_top_taper(None, S.z, scalar=False), rtol=1e-13)
+  S.Hsill = None
+  # Ekman layer of 200 m: quadratic taper to the surface instead of the single zero
+  S.HEk = 200
+  want = np.full(81, full)
+  want[77:] = [full * (1 - (zz + 200.0)**2 / 4.0e4) for zz in S.z[77:]]
+  got = S.calc_Ekman()
+  assert np.all(np.around(want, 3) == np.around(got, 3))
+  assert np.allclose(got, np.full(81, full) * S.calc_top_taper(200, S.z, scalar=False), rtol=1e-13)
+  S.HEk = None
+
+
 def test_reference_unit_tests_of_calc_gm(gpu):
   """tests/modules/test_psi_SO.py:205-294 re-expressed against the wrapper."""
   S = gpu.Psi_SO(z=np.linspace(-4000, 0, 81), y=np.linspace(0, 2.0e6, 51),

@@ -101,15 +101,43 @@ def test_stale_id_file_is_ignored_and_replaced(tmp_path):
   import time
   path = str(tmp_path / "id")
   with open(path, "wb") as f:
-    f.write(b"S" * 128)
+    f.write(b"S" * 128 + sharding._TAG.pack(os.getppid() + 1, 0.))
   old = time.time() - 3600
   os.utime(path, (old, old))  # leftover of a crashed run, an hour old
   with pytest.raises(TimeoutError):
-    sharding.wait_for_id(path, 128, time.time(), timeout_s=0.3)
+    sharding.wait_for_id(path, 128, time.time(), timeout_s=0.3, trust_path=False)
   t = threading.Timer(0.2, sharding.publish_id, (path, b"N" * 128))
   t.start()
   assert sharding.wait_for_id(path, 128, time.time(), timeout_s=10) == b"N" * 128
   t.join()
+
+
+def test_id_of_another_launcher_is_stale_even_when_fresh(tmp_path):
+  """torch.distributed.run's static rendezvous gives every launch the run id 'none', and the
+  driver's N = 2, 4, 8 series reuses one MASTER_PORT: a launch that died seconds ago leaves a
+  FRESH file at the same path.  It carries the pid of ITS launcher, so a rank of the next launch
+  (another parent) does not take it once it is older than the start-up slack; the id written by
+  a sibling (same parent) is taken whatever its age, also by a rank that starts minutes late."""
+  import time
+  path = str(tmp_path / "id")
+  # (1) written 40 s ago by a rank whose launcher was another process
+  with open(path, "wb") as f:
+    f.write(b"S" * 128 + sharding._TAG.pack(os.getppid() + 1, time.time() - 40))
+  old = time.time() - 40
+  os.utime(path, (old, old))
+  with pytest.raises(TimeoutError):
+    sharding.wait_for_id(path, 128, time.time(), timeout_s=0.3, trust_path=False)
+  # (2) same age, written by a sibling: valid for a late starter
+  sharding.publish_id(path, b"N" * 128)
+  os.utime(path, (old, old))
+  assert sharding.wait_for_id(path, 128, time.time(), timeout_s=2, trust_path=False) == b"N" * 128
+  # (3) a path unique to the launch needs no test at all
+  with open(path, "wb") as f:
+    f.write(b"U" * 128 + sharding._TAG.pack(1, 0.))
+  os.utime(path, (old - 3600, old - 3600))
+  assert sharding.wait_for_id(path, 128, time.time(), timeout_s=2, trust_path=True) == b"U" * 128
+  assert sharding.unique_key({"PYMOC_RUN_ID": "ab12"}) and sharding.unique_key({"TORCHELASTIC_RUN_ID": "7"})
+  assert not sharding.unique_key({"TORCHELASTIC_RUN_ID": "none"}) and not sharding.unique_key({})
 
 
 def test_launcher_environment_and_exit_code(tmp_path):

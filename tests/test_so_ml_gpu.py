@@ -66,6 +66,46 @@ def test_so_ml_ragged_sizes_vs_oracle_bitwise(gpu, nz, ny):
     assert np.array_equal(ps[m], ops), (nz, ny, m)
 
 
+def test_reference_unit_test_of_advdiff(gpu):
+  """tests/modules/test_SO_ML.py:129-170 re-expressed against the wrapper (a cosine bs against
+  the analytic tendency, 5 %), and the kernel against the class's own host helpers composed in
+  advdiff's order (SO_ML.py:198-274)."""
+  dt = 60 * 86400
+  y = np.linspace(0, 2.0e6, 51)
+  Ks, L, h, surflux = 100, 4e6, 50, 5.9e3
+  dth = 2.0 * np.pi / 2.0e6
+  b_basin = np.asarray([0.02 * (n / 2.0e6)**2 for n in y])
+  bs = np.asarray([b_basin[-1] * np.cos(n * dth) for n in y])
+  conf = dict(y=y, Ks=Ks, h=h, L=L, surflux=surflux, rest_mask=0.0, b_rest=0.0,
+              v_pist=2.0 / 86400.0, bs=bs)
+  Psi_b = np.linspace(1e4, 2.0e4, 51)
+  ml = gpu.SO_ML(**conf)
+  dbs_dy = -dth * b_basin[-1] * np.sin(y * dth)
+  d2bs_dy2 = -dth**2 * b_basin[-1] * np.cos(y * dth)
+  db = -((Psi_b / (h * L)) * dbs_dy + Ks * d2bs_dy2 + surflux / h) * dt
+  b = -(ml.bs.copy() + db)
+  # the same step through the host helpers, in advdiff's order
+  hm = gpu.SO_ML(**dict(conf, bs=bs.copy()))
+  Psi_mod = Psi_b.copy()
+  ind = np.nonzero(Psi_mod)[0][0]
+  Psi_mod[:ind] = Psi_mod[ind]
+  hm.Psi_s = np.interp(hm.bs, b_basin, Psi_mod)
+  hm.Psi_s[:np.argmin(hm.bs)] = 0.
+  hm.Psi_s[0] = 0.
+  hm.set_boundary_conditions(b_basin, Psi_b)
+  flux = hm.surflux / hm.h + hm.rest_mask * hm.v_pist / hm.h * (hm.b_rest - hm.bs)
+  dy = y[1] - y[0]
+  hm.bs = hm.bs + dt * (flux + hm.calc_advective_tendency(dy))
+  if hm.Psi_s[1] <= 0:
+    hm.bs[0] = hm.bs[1]
+  hm.bs = hm.calc_implicit_diffusion(dy, dt)
+  hm.set_boundary_conditions(b_basin, Psi_b)
+  ml.advdiff(b_basin, Psi_b, dt)
+  assert all(np.abs(b[i] - ml.bs[i]) / b[i] < 0.05 for i in range(len(b)))
+  # (the scale of this test case is |bs| ~ 1e4: surflux / h x dt)
+  assert relerr(ml.bs, hm.bs) <= 1e-13 and relerr(ml.Psi_s, hm.Psi_s) <= 1e-14
+
+
 def test_so_ml_wrapper_api(gpu):
   g = load_golden("so_ml")
   Ks, h, L, v_pist = g["par"]

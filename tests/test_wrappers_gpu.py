@@ -168,6 +168,54 @@ def test_column_lazy_queue_is_bitwise_the_eager_sequence(gpu):
   assert np.array_equal(col.b, ref) and col._q is None
 
 
+def test_column_callable_depending_on_mutable_state_vs_oracle(gpu):
+  """A user callable whose OUTPUT changes while its identity does not (a closure over a scale
+  factor the loop updates): the reference evaluates kappa(z) and Area(z) in every step
+  (column.py:122, :241-248), so every step must see the current values -- lazy and eager."""
+  from pymoc_amd.modules import column as colmod
+  z = np.linspace(-4000., 0., 80)
+  b0 = 0.03 * np.exp(z / 300.) - 0.001
+  wA = 8e13 * 2e-8 * np.sin(np.pi * z / 4000.)
+  state = {"scale": 1.0, "area": 8e13}
+  kappa = lambda zz: state["scale"] * (2e-5 + 2e-4 * np.exp(-zz / 1000 - 4))  # noqa: E731
+  area = lambda zz: state["area"] + 0 * zz  # noqa: E731
+  for lazy in (True, False):
+    colmod.LAZY = lazy
+    try:
+      state.update(scale=1.0, area=8e13)
+      col = gpu.Column(z=z, kappa=kappa, Area=area, b=b0.copy(), bs=0.03, bbot=-0.001)
+      ref = b0.copy()
+      for ii in range(30):
+        if ii == 10:
+          state["scale"] = 2.5   # same function object, different values
+        if ii == 20:
+          state["area"] = 5e13
+        col.timestep(wA=wA, dt=86400. * 30)
+        ref = O.column_timestep(z, kappa(z), area(z), ref, wA, 86400. * 30, bs=0.03, bbot=-0.001)
+      assert np.array_equal(col.b, ref), lazy
+    finally:
+      colmod.LAZY = True
+
+
+def test_column_alias_write_between_queued_steps(gpu):
+  """`arr = col.b` once, then `arr[k] = ...` between timestep() calls: the write is applied
+  after the steps queued before it, as in the reference (where b is updated in place)."""
+  z = np.linspace(-4000., 0., 80)
+  b0 = 0.03 * np.exp(z / 300.) - 0.001
+  wA = 8e13 * 2e-8 * np.sin(np.pi * z / 4000.)
+  col = gpu.Column(z=z, kappa=2e-5, Area=8e13, b=b0.copy(), bs=0.03, bbot=-0.001)
+  arr = col.b
+  ref = b0.copy()
+  for ii in range(20):
+    if ii in (7, 13):
+      arr[40] = 0.011 + 1e-4 * ii   # through the alias, not through col.b
+      ref[40] = 0.011 + 1e-4 * ii
+    col.timestep(wA=wA, dt=86400. * 30)
+    ref = O.column_timestep(z, 2e-5 + 0 * z, 8e13 + 0 * z, ref, wA, 86400. * 30, bs=0.03,
+                            bbot=-0.001)
+  assert np.array_equal(col.b, ref) and col.b is arr
+
+
 def test_user_loop_like_example_twocol(gpu):
   """A loop written exactly like examples/example_twocol.py:85-96, with the drop-in classes."""
   m = configs.twocol_member(nz=80)
