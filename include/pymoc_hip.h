@@ -83,11 +83,28 @@ int pm_graph_destroy(pm_graph_t graph);
  */
 #define PM_COL_DO_CONV 1   /* per-column flag: timestep(do_conv=True)             */
 #define PM_COL_BZBOT 2     /* per-column flag: bzbot is not None (column.py:232)  */
+#define PM_COL_STATIC_IN_RANGE 4 /* per-column HINT: z, kappa, Area, d(A kappa)/dz of every
+                              coefficient set and bs / bbot / bzbot / N2min are finite and zero
+                              or of magnitude in [2^-200, 2^200] (Area and the grid spacings not
+                              zero).  The column kernels divide by static denominators with an
+                              exact 4-instruction sequence that is IEEE-identical inside that
+                              window; they test their operands and take IEEE division otherwise.
+                              With the hint the one-step streaming kernel tests only what
+                              changes from launch to launch (b, wA); without it, everything.   */
+#define PM_COL_UNIFORM_AREA 8 /* per-column HINT: Area(z) is constant in z (every reference script);
+                              the one-step streaming kernel then reads area[col][0] only.  Not
+                              verified (that would be the read it saves): a wrong hint gives the
+                              result for Area = area[col][0].                                   */
 
 #define PM_OP_CONVECT 1      /* run convect() on columns flagged PM_COL_DO_CONV   */
 #define PM_OP_VERTADVDIFF 2  /* run vertadvdiff(wA, dt, do_conv=flag)             */
 #define PM_OP_HORADV 4       /* run horadv(vdx_in, b_in, dt)                      */
 #define PM_OP_TIMESTEP 7     /* what Column.timestep does (horadv iff vdx given)  */
+#define PM_OP_WEFF 8         /* modifier: the `wA` argument holds weff = wA - d(A kappa)/dz of
+                                the coefficient set in use (pm_column_weff), which is all the step
+                                needs of the two (column.py:241); d(A kappa)/dz is then not read.
+                                wA is static between two overturning updates in every reference
+                                driver, so weff is too.                                          */
 
 typedef struct pm_columns {
   int32_t ncols;         /* independent columns in the batch                      */
@@ -117,6 +134,10 @@ typedef struct pm_columns {
 int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_in,
                     const double *b_in, double dt, int32_t nsteps, int32_t ops,
                     int32_t lanes_per_col, pm_stream_t stream);
+
+/* weff[ncols][nz] = wA - d(A kappa)/dz of each column's coefficient set in use (column.py:241),
+ * for pm_column_steps(..., ops | PM_OP_WEFF).                                                 */
+int pm_column_weff(const pm_columns *cols, const double *wA, double *weff, pm_stream_t stream);
 
 /* The work decomposition pm_column_steps would use for a batch of this shape: lanes
  * cooperating on one column (`lanes_per_col` = 0 lets the library choose) and levels held

@@ -17,9 +17,9 @@ LIB_PATH = os.path.join(_HERE, "libpymoc_hip.so")
 
 PM_OK, PM_EINVAL, PM_EHIP, PM_ENCCL, PM_ENODEV = 0, 1, 2, 3, 4
 
-PM_COL_DO_CONV, PM_COL_BZBOT = 1, 2
+PM_COL_DO_CONV, PM_COL_BZBOT, PM_COL_STATIC_IN_RANGE, PM_COL_UNIFORM_AREA = 1, 2, 4, 8
 PM_EQ_HFREE, PM_EQ_HAS_BBOT, PM_EQ_KAPPA_ARRAY, PM_EQ_PSI_ARRAY = 1, 2, 4, 8
-PM_OP_CONVECT, PM_OP_VERTADVDIFF, PM_OP_HORADV, PM_OP_TIMESTEP = 1, 2, 4, 7
+PM_OP_CONVECT, PM_OP_VERTADVDIFF, PM_OP_HORADV, PM_OP_TIMESTEP, PM_OP_WEFF = 1, 2, 4, 7, 8
 
 c_dp = C.c_void_p  # device pointers travel as plain addresses
 
@@ -164,6 +164,7 @@ SIGNATURES = {
     "pm_graph_destroy": (C.c_int, [C.c_void_p]),
     "pm_column_steps": (C.c_int, [C.POINTER(pm_columns), c_dp, c_dp, c_dp, C.c_double,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "pm_column_weff": (C.c_int, [C.POINTER(pm_columns), c_dp, c_dp, C.c_void_p]),
     "pm_column_kernel_shape": (C.c_int, [C.c_int32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pm_column_kernel_name": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

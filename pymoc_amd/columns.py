@@ -43,6 +43,14 @@ def dAkappa_dz(area, kappa, z):
   return np.gradient(area * kappa, z, axis=-1)
 
 
+def _in_fast_range(x):
+  """Elementwise: zero, or finite with magnitude in [2^-200, 2^200] -- the operand window of the
+  kernels' exact-division shortcut (csrc/common.hip.h: in_fast_div_range)."""
+  a = np.abs(np.asarray(x, dtype=np.float64))
+  with np.errstate(invalid="ignore"):
+    return (a == 0) | ((a >= 2.0**-200) & (a <= 2.0**200))
+
+
 class ColumnBatch(object):
   def __init__(self, z, kappa, area, b, bs=0.025, bbot=0.0, bzbot=None, N2min=1e-7,
                do_conv=False, kappa_alt=None, stream=None, report_nonfinite=True):
@@ -93,33 +101,61 @@ class ColumnBatch(object):
     # kernel keep it in scalar registers (pm_jn2018.hints)
     self.uniform_area = bool(np.all(area == area[:, :1]))
     self.kappa.upload(np.stack(ks), self.stream)
-    self.dAk.upload(np.stack([dAkappa_dz(area, k, self.z_host) for k in ks]), self.stream)
+    dAks = [dAkappa_dz(area, k, self.z_host) for k in ks]
+    self.dAk.upload(np.stack(dAks), self.stream)
+    # PM_COL_STATIC_IN_RANGE (include/pymoc_hip.h): the static operands of a column lie inside
+    # the window of the kernels' exact-division shortcut, so the one-step streaming kernel only
+    # has to test the state and the forcing
+    dz = np.diff(self.z_host)
+    ok = _in_fast_range(self.z_host).all() and _in_fast_range(dz).all() and (dz != 0).all()
+    self._static_ok = np.full(ncols, bool(ok))
+    for a in [area] + ks + dAks:
+      self._static_ok &= _in_fast_range(a).all(axis=1)
+    self._static_ok &= (area != 0).all(axis=1)
+    if hasattr(self, "_flags_host"):
+      self._upload_flags()
 
   def set_params(self, bs=None, bbot=None, bzbot=False, N2min=None, do_conv=None):
     """Per-column scalars; `bzbot=None` clears the bottom-stratification BC, the
     default `False` leaves it unchanged."""
     n = self.ncols
+    par = self.__dict__.setdefault("_par_ok", {})
     if bs is not None:
-      self.bs.upload(_per_col(bs, n), self.stream)
+      v = _per_col(bs, n)
+      self.bs.upload(v, self.stream)
+      par["bs"] = _in_fast_range(v)
     if bbot is not None:
-      self.bbot.upload(_per_col(bbot, n), self.stream)
+      v = _per_col(bbot, n)
+      self.bbot.upload(v, self.stream)
+      par["bbot"] = _in_fast_range(v)
     if N2min is not None:
-      self.N2min.upload(_per_col(N2min, n), self.stream)
-    touched = False
+      v = _per_col(N2min, n)
+      self.N2min.upload(v, self.stream)
+      par["N2min"] = _in_fast_range(v)
     if bzbot is None:
       self._flags_host &= ~_lib.PM_COL_BZBOT
-      touched = True
+      par.pop("bzbot", None)
     elif bzbot is not False:
-      self.bzbot.upload(_per_col(bzbot, n), self.stream)
+      v = _per_col(bzbot, n)
+      self.bzbot.upload(v, self.stream)
       self._flags_host |= _lib.PM_COL_BZBOT
-      touched = True
+      par["bzbot"] = _in_fast_range(v)
     if do_conv is not None:
       dc = _per_col(do_conv, n, dtype=bool)
       self._flags_host = np.where(dc, self._flags_host | _lib.PM_COL_DO_CONV,
                                   self._flags_host & ~_lib.PM_COL_DO_CONV).astype(np.int32)
-      touched = True
-    if touched:
-      self.flags.upload(self._flags_host, self.stream)
+    self._upload_flags()
+
+  def _upload_flags(self):
+    ok = self._static_ok.copy()
+    for v in self.__dict__.get("_par_ok", {}).values():
+      ok &= v
+    bit = np.int32(_lib.PM_COL_STATIC_IN_RANGE)
+    self._flags_host = np.where(ok, self._flags_host | bit, self._flags_host & ~bit).astype(np.int32)
+    bit = np.int32(_lib.PM_COL_UNIFORM_AREA)  # every column's Area is one number (set_static)
+    self._flags_host = (self._flags_host | bit if self.uniform_area
+                        else self._flags_host & ~bit).astype(np.int32)
+    self.flags.upload(self._flags_host, self.stream)
 
   def set_ksel(self, ksel):
     self.ksel.upload(_per_col(ksel, self.ncols, np.int32), self.stream)
@@ -170,9 +206,22 @@ class ColumnBatch(object):
                                     int(ops), int(bool(horadv)), buf, 96))
     return buf.value.decode()
 
+  def combine_forcing(self, wA, out=None):
+    """weff = wA - d(A kappa)/dz of each column's coefficient set in use, on the device
+    (`pm_column_weff`), for `steps(weff, ..., precombined=True)`: wA is static between two
+    overturning updates, so loops that step once per launch need not re-read d(A kappa)/dz."""
+    wA_d = self._dev(wA, "_wA")
+    out = DeviceArray((self.ncols, self.nz)) if out is None else out
+    d = self.descriptor()
+    check(lib.pm_column_weff(C.byref(d), wA_d.ptr, out.ptr, _sh(self.stream)))
+    return out
+
   def steps(self, wA, dt, nsteps=1, ops=_lib.PM_OP_TIMESTEP, vdx_in=None, b_in=None,
-            lanes_per_col=0):
-    """nsteps x (convect -> vertadvdiff -> horadv) with wA held fixed, one launch."""
+            lanes_per_col=0, precombined=False):
+    """nsteps x (convect -> vertadvdiff -> horadv) with wA held fixed, one launch.
+    precombined: `wA` is the output of `combine_forcing` (PM_OP_WEFF)."""
+    if precombined:
+      ops = ops | _lib.PM_OP_WEFF
     if vdx_in is not None and b_in is None:
       raise TypeError('b_in is needed if vdx_in is provided')  # column.py:348
     wA_d = self._dev(wA, "_wA")

@@ -154,9 +154,14 @@ __device__ __forceinline__ bool col_convect(double (&b)[P], const double (&z)[P]
         zconv = zg[jmax];
       }
     }
+    // (selects, not `if (ind[p])` blocks: with the blocks hipcc 7.2 lost slot 0's adjusted value
+    // on the IEEE path of k_column_stream -- an inf level survived convect in the release
+    // build and not in one with a printf next to it; test_operands_outside_..._streaming_kernel)
 #pragma unroll
-    for (int p = 0; p < P; ++p)
-      if (ind[p]) b[p] = bs + N2min * (z[p] - zconv);  // column.py:268
+    for (int p = 0; p < P; ++p) {
+      const double adj = bs + N2min * (z[p] - zconv);  // column.py:268
+      b[p] = ind[p] ? adj : b[p];
+    }
     return true;
   }
 #pragma unroll
@@ -221,6 +226,9 @@ __device__ __forceinline__ void col_convect_cached(double (&b)[P], const double 
 // UA: Area is constant in z -- r.area_u / rarea_u / rarea_lu replace the per-level arrays.
 // FLUXFMA: the select-free upwind flux (needs wn / wp, two more values per level, which the
 // register-starved fused JN2018 loop cannot afford).
+// DIV == 0 is also the REFERENCE-FAITHFUL form for any operand, finite or not: IEEE division,
+// compare-select flux, and boundary / padding levels left untouched by a select (the other
+// forms advance them with dt = 0, which turns a level next to an inf or NaN into NaN).
 template <int G, int P, int DIV, bool BC = true, bool WEFF = false, bool UA = false,
           bool FLUXFMA = (DIV == 2)>
 __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> &r,
@@ -378,7 +386,12 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
     // column.py:249.  Boundary / padding slots advance with dt = 0 (b + 0*x == b for the
     // finite x they hold) instead of a select, which the compiler would turn back into
     // one exec-masked block per slot and serialise the chains.
-    r.b[p] = r.b[p] + (interior ? dt : 0.0) * db_dt;
+    if constexpr (DIV == 0) {
+      const double nb = r.b[p] + dt * db_dt;
+      r.b[p] = interior ? nb : r.b[p];
+    } else {
+      r.b[p] = r.b[p] + (interior ? dt : 0.0) * db_dt;
+    }
   }
 }
 
@@ -395,6 +408,38 @@ __device__ __forceinline__ void col_horadv(ColRegs<P> &r, const double (&vdx)[P]
       r.b[p] = r.b[p] + dt * vdx[p] * db / r.area[p];
     }
   }
+}
+
+// True when every operand of this lane's levels lies in the window of the exact-division
+// shortcuts (common.hip.h: in_fast_div_range): the kernels combine it over the wave and take
+// the IEEE form (DIV = 0) otherwise.
+template <int P>
+__device__ __forceinline__ bool col_inputs_in_fast_range(const ColGrid<P> &g, const ColRegs<P> &r,
+                                                         const double (&wA)[P], double dt,
+                                                         double bs, double bbot, double bzbot,
+                                                         double N2min, int lg, int nz) {
+  bool ok = in_fast_div_range(dt) && in_fast_div_range(bs) && in_fast_div_range(bbot) &&
+            in_fast_div_range(bzbot) && in_fast_div_range(N2min);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const bool top = lg * P + p >= nz - 1;  // (dz is 0 at and above the top level)
+    ok = ok && in_fast_div_range(r.b[p]) && in_fast_div_range(wA[p]) &&
+         in_fast_div_range(r.dAk[p]) && in_fast_div_range(wA[p] - r.dAk[p]) &&
+         in_fast_div_range(r.kap[p]) && in_fast_div_range(r.area[p]) && r.area[p] != 0.0 &&
+         in_fast_div_range(g.z[p]) && (top || (in_fast_div_range(g.dz[p]) && g.dz[p] != 0.0)) &&
+         in_fast_div_range(g.dzc[p]) && g.dzc[p] != 0.0;
+  }
+  return ok;
+}
+
+// The part of that test that changes from launch to launch: the state and weff = wA - d(A
+// kappa)/dz (wA and d(A kappa)/dz enter the step only through their difference).
+template <int P>
+__device__ __forceinline__ bool col_state_in_fast_range(const ColRegs<P> &r, const double (&wA)[P]) {
+  bool ok = true;
+#pragma unroll
+  for (int p = 0; p < P; ++p) ok = ok && in_fast_div_range(r.b[p]) && in_fast_div_range(wA[p] - r.dAk[p]);
+  return ok;
 }
 
 // grid metrics of the batch into registers
@@ -598,6 +643,47 @@ __device__ __forceinline__ int conv_spec_run(const ColGrid<P> &g, ColRegs<P> &r,
   return ret >= 0 ? ret : nsteps;
 }
 
+// result of a column into HBM (16-byte stores for P == 2) and its non-finite flag
+template <int G, int P>
+__device__ __forceinline__ void col_store_result(const pm_columns &c, const ColRegs<P> &r,
+                                                 size_t base, int col, bool col_ok, int lg,
+                                                 int lane, int nz) {
+  bool bad = false;
+  bool stored = false;
+  if constexpr (P == 2) {
+    if ((nz & 1) == 0 && (((unsigned long long)(c.b + base)) & 15ull) == 0ull) {
+      if (lg * 2 < nz) {  // even nz: both levels of the pair are valid
+        if (col_ok) *reinterpret_cast<double2 *>(c.b + base + lg * 2) = make_double2(r.b[0], r.b[1]);
+        bad = !isfinite(r.b[0]) || !isfinite(r.b[1]);
+      }
+      stored = true;
+    }
+  }
+  if (!stored) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lg * P + p;
+      if (i < nz) {
+        if (col_ok) c.b[base + i] = r.b[p];
+        bad |= !isfinite(r.b[p]);
+      }
+    }
+  }
+  if (c.nonfinite) {
+    const unsigned long long m = __ballot(bad) & group_mask<G>(lane);
+    if (lg == 0 && col_ok) c.nonfinite[col] = (m != 0ull) ? 1 : 0;
+  }
+}
+
+// Pins a column's state in its registers between convect and the step that follows it: no
+// instruction, but the optimiser cannot merge across it (see k_column_stream: hipcc 7.2 lost a
+// convected slot in such a merge).  Used on the paths that are not instruction-count critical.
+template <int P>
+__device__ __forceinline__ void col_pin(double (&b)[P]) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) asm volatile("" : "+v"(b[p]));
+}
+
 // PLAIN: ops == PM_OP_TIMESTEP without horadv inputs -- the time loop then carries no
 // loop-invariant branches (they cost a lone wave ~15% of a step).
 template <int G, int P, int FAST, bool PLAIN>
@@ -617,6 +703,10 @@ __global__ __launch_bounds__(256) void k_column_steps(
   const int sel = c.ksel ? c.ksel[col] : 0;
   col_load_grid<P, FAST>(g, c, lg);
   col_load_static<P, FAST>(r, c, col, sel, lg);
+  if (ops & PM_OP_WEFF) {  // wA_g holds weff = wA - d(A kappa)/dz: weff - 0 = weff, exactly
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.dAk[p] = 0.0;
+  }
 
   double wA[P], vdx[P], bin[P];
   load_levels<P>(r.b, c.b + base, lg, nz);
@@ -632,6 +722,24 @@ __global__ __launch_bounds__(256) void k_column_steps(
   const double bbot = c.bbot[col];
   const double bzbot = use_bzbot ? c.bzbot[col] : 0.0;
   const double N2min = c.N2min[col];
+
+  if constexpr (FAST != 0) {
+    // operands outside the exact-division window (a column scaled by 2^-1000, an inf level, ...):
+    // the whole wave steps in the reference-faithful IEEE form
+    const bool fast_ok = col_inputs_in_fast_range<P>(g, r, wA, dt, bs, bbot, bzbot, N2min, lg, nz);
+    if (__builtin_expect(__ballot(!fast_ok) != 0ull, 0)) {
+      for (int s = 0; s < nsteps; ++s) {
+        if ((ops & PM_OP_CONVECT) && do_conv)
+          col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
+        col_pin<P>(r.b);
+        if (ops & PM_OP_VERTADVDIFF)
+          col_vertadvdiff<G, P, 0>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lg, nz);
+        if ((ops & PM_OP_HORADV) && vdx_g) col_horadv<P>(r, vdx, bin, dt, lg, nz);
+      }
+      col_store_result<G, P>(c, r, base, col, col_ok, lg, lane, nz);
+      return;
+    }
+  }
 
   if constexpr (PLAIN) {
     if (do_conv && use_bzbot) {
@@ -702,71 +810,86 @@ __global__ __launch_bounds__(256) void k_column_steps(
     for (int s = 0; s < nsteps; ++s) {
       if ((ops & PM_OP_CONVECT) && do_conv)
         col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
+      col_pin<P>(r.b);
       if (ops & PM_OP_VERTADVDIFF)
         col_vertadvdiff<G, P, FAST>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lg, nz);
       if ((ops & PM_OP_HORADV) && vdx_g) col_horadv<P>(r, vdx, bin, dt, lg, nz);
     }
   }
 
-  bool bad = false;
-  bool stored = false;
-  if constexpr (P == 2) {
-    if ((nz & 1) == 0 && (((unsigned long long)(c.b + base)) & 15ull) == 0ull) {
-      if (lg * 2 < nz) {  // even nz: both levels of the pair are valid
-        if (col_ok) *reinterpret_cast<double2 *>(c.b + base + lg * 2) = make_double2(r.b[0], r.b[1]);
-        bad = !isfinite(r.b[0]) || !isfinite(r.b[1]);
-      }
-      stored = true;
-    }
-  }
-  if (!stored) {
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int i = lg * P + p;
-      if (i < nz) {
-        if (col_ok) c.b[base + i] = r.b[p];
-        bad |= !isfinite(r.b[p]);
-      }
-    }
-  }
-  if (c.nonfinite) {
-    const unsigned long long m = __ballot(bad) & group_mask<G>(lane);
-    if (lg == 0 && col_ok) c.nonfinite[col] = (m != 0ull) ? 1 : 0;
-  }
+  col_store_result<G, P>(c, r, base, col, col_ok, lg, lane, nz);
 }
 
 // ------------------------------------------------------------------ streaming kernel
 // One or two steps per launch on a large ensemble (config 1 style loops, Psi refreshed every
-// step): the state cannot stay in registers across launches, every launch streams b, wA and
-// the three coefficient arrays in and b out -- 48 nz B per column-step, HBM is the roof.
-// k_column_steps pays per column what only depends on the shared grid (loading z, forming
-// dz / dzc, three IEEE divisions per level ~ 40 quarter-rate instructions); here a wave walks
-// through `cpw` consecutive columns, forms the grid metrics and their reciprocals ONCE, and
-// has the next column's loads in flight while it computes the current one.
+// step): the state cannot stay in registers across launches, every launch streams b, the
+// forcing and the coefficient arrays in and b out -- 32 nz ... 48 nz B per column-step (below),
+// HBM is the roof.  k_column_steps pays per column what only depends on the shared grid (loading
+// z, forming dz / dzc, three IEEE divisions per level ~ 40 quarter-rate instructions); here a
+// wave walks through `cpw` consecutive columns and forms the grid metrics and their reciprocals
+// ONCE.  What bounds the kernel is the number of bytes in flight: a column's loads take ~4 us
+// under load, so the wave keeps the loads of the next D columns in flight (a ring of D stages in
+// registers, indices static after unrolling) while it computes the current one; with one stage
+// (round 2) the 5-array form reached 4.8 TB/s, the 3-array form only 3.4.  The per-column
+// scalars (flags, coefficient set, bs, bbot, bzbot, N2min) are fetched for all the wave's
+// columns by ONE vector load each (lane i = i-th column) and handed out by v_readlane: a scalar
+// load per column sat between a column's flags and its vector loads.
+//   weff_in (PM_OP_WEFF): wA_g holds weff = wA - d(A kappa)/dz, d(A kappa)/dz is not read;
+//   PM_COL_UNIFORM_AREA:  Area(z) is one number, read with the scalars;
+// together 32 nz instead of 48 nz bytes per column-step.
 template <int P>
 struct ColStage {
   double b[P], wA[P], kap[P], area[P], dAk[P];
 };
 
+constexpr int STREAM_MAX_CPW = 64;  // columns per wave <= lanes (the scalars' vector load)
+
+// the wave's per-column scalars, lane i = column col0 + i
+struct StreamScalars {
+  int flags, sel;
+  double bs, bbot, bzbot, N2min, area0;
+  __device__ __forceinline__ void load(const pm_columns &c, int col0, int cend, int lane) {
+    const int col = col0 + lane < cend ? col0 + lane : cend - 1;
+    flags = c.flags ? c.flags[col] : 0;
+    sel = c.ksel ? c.ksel[col] : 0;
+    bs = c.bs[col];
+    bbot = c.bbot[col];
+    N2min = c.N2min[col];
+    bzbot = ((flags & PM_COL_BZBOT) != 0 && c.bzbot != nullptr) ? c.bzbot[col] : 0.0;
+    area0 = (flags & PM_COL_UNIFORM_AREA) ? c.area[(size_t)col * c.nz] : 0.0;
+  }
+};
+
 template <int P>
 __device__ __forceinline__ void col_stage_load(ColStage<P> &s, const pm_columns &c,
                                                const double *__restrict__ wA_g, int col,
-                                               int lane) {
+                                               int lane, bool weff_in, int flags, int sel,
+                                               double area0) {
   const int nz = c.nz;
-  const int sel = c.ksel ? c.ksel[col] : 0;
   const size_t base = (size_t)col * nz;
   const size_t sbase = ((size_t)sel * c.ncols + col) * nz;
   load_levels<P>(s.b, c.b + base, lane, nz);
   load_levels<P>(s.wA, wA_g + base, lane, nz);
   load_levels<P>(s.kap, c.kappa + sbase, lane, nz);
-  load_levels<P>(s.area, c.area + base, lane, nz);
-  load_levels<P>(s.dAk, c.dAkappa + sbase, lane, nz);
+  if ((flags & PM_COL_UNIFORM_AREA) == 0) {
+    load_levels<P>(s.area, c.area + base, lane, nz);
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p) s.area[p] = area0;
+  }
+  if (!weff_in) {
+    load_levels<P>(s.dAk, c.dAkappa + sbase, lane, nz);
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p) s.dAk[p] = 0.0;  // weff - 0 = weff, exactly
+  }
 }
 
-template <int P>
+template <int P, int D>
 __global__ __launch_bounds__(256) void k_column_stream(pm_columns c,
                                                        const double *__restrict__ wA_g,
-                                                       double dt, int nsteps, int cpw) {
+                                                       double dt, int nsteps, int cpw, bool dt_ok,
+                                                       bool weff_in) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
   const int col0 = __builtin_amdgcn_readfirstlane(wave * cpw);
@@ -774,59 +897,84 @@ __global__ __launch_bounds__(256) void k_column_stream(pm_columns c,
   if (col0 >= c.ncols) return;  // wave-uniform
   const int cend = col0 + cpw < c.ncols ? col0 + cpw : c.ncols;
 
+  StreamScalars sc;
+  sc.load(c, col0, cend, lane);
+  auto flags_of = [&](int k) { return __builtin_amdgcn_readlane(sc.flags, k); };
+  auto issue = [&](ColStage<P> &st, int col) {
+    const int k = col - col0;
+    col_stage_load<P>(st, c, wA_g, col, lane, weff_in, flags_of(k),
+                      __builtin_amdgcn_readlane(sc.sel, k), lane_value(sc.area0, k));
+  };
   ColGrid<P> g;
   col_load_grid<P, 1>(g, c, lane);
-  ColStage<P> nxt;
-  col_stage_load<P>(nxt, c, wA_g, col0, lane);
-  for (int col = col0; col < cend; ++col) {
-    ColRegs<P> r;
-    double wA[P];
+  ColStage<P> ring[D];
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      r.b[p] = nxt.b[p];
-      wA[p] = nxt.wA[p];
-      r.kap[p] = nxt.kap[p];
-      r.area[p] = nxt.area[p];
-      r.dAk[p] = nxt.dAk[p];
-      r.rarea[p] = r.rarea_l[p] = 0.;
-    }
-    if (col + 1 < cend) col_stage_load<P>(nxt, c, wA_g, col + 1, lane);  // prefetch
-    // the column's scalars: scalar loads (vector loads of a uniform address were tried -- the
-    // flags then sit in vector registers, the branches on them become divergent: 5 % slower)
-    const int flags = c.flags ? c.flags[col] : 0;
-    const bool do_conv = (flags & PM_COL_DO_CONV) != 0;
-    const bool use_bzbot = (flags & PM_COL_BZBOT) != 0 && c.bzbot != nullptr;
-    const double bs = c.bs[col], bbot = c.bbot[col], N2min = c.N2min[col];
-    const double bzbot = use_bzbot ? c.bzbot[col] : 0.0;
-    for (int s = 0; s < nsteps; ++s) {
-      if (do_conv) col_convect<64, P>(r.b, g.z, bs, N2min, lane, lane, nz, c.z);
-      col_vertadvdiff<64, P, 3>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lane, nz);
-    }
-    const size_t base = (size_t)col * nz;
-    bool bad = false;
-    bool stored = false;
-    if constexpr (P == 2) {
-      if ((nz & 1) == 0 && (((unsigned long long)(c.b + base)) & 15ull) == 0ull) {
-        if (lane * 2 < nz) {
-          *reinterpret_cast<double2 *>(c.b + base + lane * 2) = make_double2(r.b[0], r.b[1]);
-          bad = !isfinite(r.b[0]) || !isfinite(r.b[1]);
-        }
-        stored = true;
-      }
-    }
-    if (!stored) {
+  for (int d = 0; d < D; ++d)
+    if (col0 + d < cend) issue(ring[d], col0 + d);
+  for (int colb = col0; colb < cend; colb += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int col = colb + d;
+      if (col >= cend) break;  // wave-uniform
+      ColRegs<P> r;
+      double wA[P];
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const int i = lane * P + p;
-        if (i < nz) {
-          c.b[base + i] = r.b[p];
-          bad |= !isfinite(r.b[p]);
+        r.b[p] = ring[d].b[p];
+        wA[p] = ring[d].wA[p];
+        r.kap[p] = ring[d].kap[p];
+        r.area[p] = ring[d].area[p];
+        r.dAk[p] = ring[d].dAk[p];
+        r.rarea[p] = r.rarea_l[p] = 0.;
+      }
+      if (col + D < cend) issue(ring[d], col + D);  // keep D columns' loads in flight
+      const int k = col - col0;
+      const int flags = flags_of(k);
+      const bool do_conv = (flags & PM_COL_DO_CONV) != 0;
+      const bool use_bzbot = (flags & PM_COL_BZBOT) != 0 && c.bzbot != nullptr;
+      const double bs = lane_value(sc.bs, k), bbot = lane_value(sc.bbot, k),
+                   N2min = lane_value(sc.N2min, k), bzbot = lane_value(sc.bzbot, k);
+      // operands outside the exact-division window: this column steps in the IEEE form
+      // (PM_COL_STATIC_IN_RANGE: the caller vouches for the static operands, dt_ok for dt)
+      const bool fast_ok = ((flags & PM_COL_STATIC_IN_RANGE) != 0 && dt_ok)
+                               ? col_state_in_fast_range<P>(r, wA)
+                               : col_inputs_in_fast_range<P>(g, r, wA, dt, bs, bbot, bzbot, N2min,
+                                                             lane, nz);
+      const bool slow = __ballot(!fast_ok) != 0ull;
+      for (int s = 0; s < nsteps; ++s) {
+        if (do_conv) col_convect<64, P>(r.b, g.z, bs, N2min, lane, lane, nz, c.z);
+        col_pin<P>(r.b);
+        if (__builtin_expect(slow, 0))
+          col_vertadvdiff<64, P, 0>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lane, nz);
+        else
+          col_vertadvdiff<64, P, 3>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lane, nz);
+      }
+      const size_t base = (size_t)col * nz;
+      bool bad = false;
+      bool stored = false;
+      if constexpr (P == 2) {
+        if ((nz & 1) == 0 && (((unsigned long long)(c.b + base)) & 15ull) == 0ull) {
+          if (lane * 2 < nz) {
+            *reinterpret_cast<double2 *>(c.b + base + lane * 2) = make_double2(r.b[0], r.b[1]);
+            bad = !isfinite(r.b[0]) || !isfinite(r.b[1]);
+          }
+          stored = true;
         }
       }
-    }
-    if (c.nonfinite) {
-      const unsigned long long m = __ballot(bad);
-      if (lane == 0) c.nonfinite[col] = (m != 0ull) ? 1 : 0;
+      if (!stored) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int i = lane * P + p;
+          if (i < nz) {
+            c.b[base + i] = r.b[p];
+            bad |= !isfinite(r.b[p]);
+          }
+        }
+      }
+      if (c.nonfinite) {
+        const unsigned long long m = __ballot(bad);
+        if (lane == 0) c.nonfinite[col] = (m != 0ull) ? 1 : 0;
+      }
     }
   }
 }
@@ -837,10 +985,13 @@ inline int stream_cols_per_wave(int ncols) {
     const char *e = getenv("PYMOC_STREAM_CPW");  // experiments (profiles/): 0 = automatic
     return e ? atoi(e) : 0;
   }();
-  if (forced > 0) return forced;
-  const int waves_wanted = 1024 * 8 * 4;  // SIMDs x resident waves x rounds
+  if (forced > 0) return forced > STREAM_MAX_CPW ? STREAM_MAX_CPW : forced;
+  // few, long waves: two rounds of four resident waves per SIMD; a wave's ramp of D columns is
+  // paid once per cpw columns (measured at 262144 columns: 8 / 16 / 32 per wave -> 187 / 189 /
+  // 181 us with the forcing precombined)
+  const int waves_wanted = 1024 * 8;
   int cpw = ncols / waves_wanted;
-  return cpw < 1 ? 1 : (cpw > 8 ? 8 : cpw);
+  return cpw < 1 ? 1 : (cpw > 32 ? 32 : cpw);
 }
 
 // ------------------------------------------------------------------ dispatch
@@ -866,12 +1017,23 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
                         hipStream_t st) {
   const int cols_per_block = 256 / G;
   const unsigned grid = (unsigned)((c.ncols + cols_per_block - 1) / cols_per_block);
+  const bool weff_in = (ops & PM_OP_WEFF) != 0;  // wA holds wA - d(A kappa)/dz
+  ops &= ~PM_OP_WEFF;
   if constexpr (G == 64 && P <= 4) {
     const int cpw = stream_cols_per_wave(c.ncols);
     if (nsteps < 3 && ops == PM_OP_TIMESTEP && !vdx && cpw >= 2) {
       const unsigned waves = (unsigned)((c.ncols + cpw - 1) / cpw);
-      hipLaunchKernelGGL((k_column_stream<P>), dim3((waves + 3) / 4), dim3(256), 0, st, c, wA, dt,
-                         nsteps, cpw);
+      // dt inside the exact-division window (in_fast_div_range, host side)
+      const double adt = dt < 0 ? -dt : dt;
+      const bool dt_ok = dt == 0.0 || (adt >= 0x1p-200 && adt <= 0x1p200);
+      // stages of the load ring: three arrays per column with the forcing precombined, five
+      // without (the ring's registers bound the occupancy)
+      if (weff_in)
+        hipLaunchKernelGGL((k_column_stream<P, 3>), dim3((waves + 3) / 4), dim3(256), 0, st, c, wA,
+                           dt, nsteps, cpw, dt_ok, weff_in);
+      else
+        hipLaunchKernelGGL((k_column_stream<P, 2>), dim3((waves + 3) / 4), dim3(256), 0, st, c, wA,
+                           dt, nsteps, cpw, dt_ok, weff_in);
       PM_HIP(hipGetLastError());
       return PM_OK;
     }
@@ -879,13 +1041,13 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
   // the reciprocal path pays 3 true divisions per level up front: worth it from 3 steps on
   if (nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx)
     hipLaunchKernelGGL((k_column_steps<G, P, 2, true>), dim3(grid), dim3(256), 0, st, c, wA,
-                       vdx, bin, dt, nsteps, ops);
+                       vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0));
   else if (nsteps >= 3)
     hipLaunchKernelGGL((k_column_steps<G, P, 1, false>), dim3(grid), dim3(256), 0, st, c, wA,
-                       vdx, bin, dt, nsteps, ops);
+                       vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0));
   else
     hipLaunchKernelGGL((k_column_steps<G, P, 0, false>), dim3(grid), dim3(256), 0, st, c,
-                       wA, vdx, bin, dt, nsteps, ops);
+                       wA, vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0));
   PM_HIP(hipGetLastError());
   return PM_OK;
 }

@@ -105,6 +105,19 @@ __device__ __forceinline__ double div_by_recip2(double a, double d, double yh, d
   return q;
 }
 
+// Operand window of the two forms above.  With every input of a column step (state, forcing,
+// coefficients, grid spacings, dt) either zero or of magnitude in [2^-200, 2^200], every
+// quotient, product and residual of the step stays at least 2^-600 and at most 2^1000 in
+// magnitude or is exactly zero, so no fma of the division sequences rounds into the subnormal
+// range or overflows and the quotients are the IEEE ones.  Outside the window (and for
+// non-finite operands: inf * 0 in the sequences gives NaN where IEEE division gives inf) the
+// kernels take their IEEE-division path or flag the member; see col_inputs_in_fast_range.
+constexpr int FAST_DIV_EXP = 200;
+__device__ __forceinline__ bool in_fast_div_range(double x) {
+  const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;  // biased exponent
+  return (e >= 1023u - FAST_DIV_EXP && e <= 1023u + FAST_DIV_EXP) || x == 0.0;
+}
+
 // Phase clocks for profiling builds (make -B lib EXTRA=-DPM_PHASE_PROFILE; read and cleared
 // through pm_debug_prof).  PM_TICK(k) adds the cycles since the previous tick of this wave to
 // slot k of a per-wave accumulator; a kernel that uses it declares `PM_TICK_INIT` once and ends

@@ -294,7 +294,7 @@ int pm_column_kernel_name(int32_t ncols, int32_t nz, int32_t lanes_per_col, int3
   int G = 0, P = 0;
   const int rc = column_shape(ncols, nz, lanes_per_col, &G, &P);
   if (rc != PM_OK) return rc;
-  const bool plain = ops == PM_OP_TIMESTEP && !has_horadv;
+  const bool plain = (ops & ~PM_OP_WEFF) == PM_OP_TIMESTEP && !has_horadv;
   if (G == 64 && P <= 4 && nsteps < 3 && plain && stream_cols_per_wave(ncols) >= 2)
     snprintf(name, name_len, "k_column_stream<%d>", P);
   else  // mirrors launch_column_steps (column.hip.h)
@@ -315,10 +315,10 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
   PM_REQUIRE(c.z && c.b && c.kappa && c.area && c.dAkappa && c.bs && c.bbot && c.N2min,
              "pm_columns has a NULL required pointer");
   PM_REQUIRE(nsteps >= 0, "nsteps < 0");
-  PM_REQUIRE((ops & ~PM_OP_TIMESTEP) == 0, "unknown op bits 0x%x", ops);
+  PM_REQUIRE((ops & ~(PM_OP_TIMESTEP | PM_OP_WEFF)) == 0, "unknown op bits 0x%x", ops);
   PM_REQUIRE(!(ops & PM_OP_VERTADVDIFF) || wA, "wA is NULL");
   PM_REQUIRE(!vdx_in || b_in, "b_in is needed if vdx_in is provided");
-  if (c.ncols == 0 || nsteps == 0 || ops == 0) return PM_OK;
+  if (c.ncols == 0 || nsteps == 0 || (ops & PM_OP_TIMESTEP) == 0) return PM_OK;
   int G = 0, P = 0;
   const int src = column_shape(c.ncols, c.nz, lanes_per_col, &G, &P);
   if (src != PM_OK) return src;
@@ -328,6 +328,29 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
     case 32: return column_steps_g32(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
     default: return column_steps_g64(P, c, wA, vdx_in, b_in, dt, nsteps, ops, st);
   }
+}
+
+__global__ void k_column_weff(pm_columns c, const double *__restrict__ wA,
+                              double *__restrict__ weff) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t n = (size_t)c.ncols * c.nz;
+  if (i >= n) return;
+  const int col = (int)(i / c.nz);
+  const int sel = c.ksel ? c.ksel[col] : 0;
+  weff[i] = wA[i] - c.dAkappa[(size_t)sel * n + i];
+}
+
+int pm_column_weff(const pm_columns *cols, const double *wA, double *weff, pm_stream_t stream) {
+  PM_REQUIRE(cols, "cols is NULL");
+  const pm_columns &c = *cols;
+  PM_REQUIRE(c.ncols >= 0 && c.nz >= 2 && c.nsel >= 1 && c.nsel <= 2, "bad batch shape");
+  if (c.ncols == 0) return PM_OK;
+  PM_REQUIRE(c.dAkappa && wA && weff, "pm_column_weff has a NULL pointer");
+  const size_t n = (size_t)c.ncols * c.nz;
+  hipLaunchKernelGGL(k_column_weff, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     resolve_stream(stream), c, wA, weff);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
 }
 
 int pm_thermwind_residuals(int32_t m, const double *x, const double *y0, const double *y1,

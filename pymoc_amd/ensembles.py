@@ -43,9 +43,15 @@ def _vec(v, n):
 
 class ColumnThermwindEnsemble(object):
   """One column per member, thermal wind against b2 = 0 re-solved after EVERY step and
-  applied in z-space: wA = Psi * 1e6 (example_timestepping.py:73-80)."""
+  applied in z-space: wA = Psi * 1e6 (example_timestepping.py:73-80).
 
-  def __init__(self, cfg, n=None, stream=None, lanes_per_col=0):
+  Every model step is two launches (the column step, the thermal-wind solve), so a small
+  ensemble is bound by the host's launch rate: `use_graph` (default) captures GRAPH_STEPS steps
+  once into a hipGraph and replays it -- one host call per GRAPH_STEPS model steps; the kernels
+  and their order are the same, so are the results."""
+  GRAPH_STEPS = 32
+
+  def __init__(self, cfg, n=None, stream=None, lanes_per_col=0, use_graph=True):
     z = cfg['z']
     nz = z.size
     b0 = np.atleast_2d(cfg['b0'])
@@ -58,16 +64,30 @@ class ColumnThermwindEnsemble(object):
     self.tw = ThermwindBatch(z, n, f=cfg['f'], nb=1, stream=stream, z_dev=self.cols.z)
     self.b2 = DeviceArray.zeros((n, nz), stream=stream)
     self.wA = DeviceArray.zeros((n, nz), stream=stream)
+    self._use_graph, self._graph = bool(use_graph), None
     self._solve()
 
   def _solve(self):
     self.tw.update(self.cols.b, self.b2, ops=_lib.PM_TW_SOLVE | _lib.PM_TW_WA_PSI,
                    wA1=self.wA, nb=1)
 
+  def _step(self):
+    self.cols.steps(self.wA, self.dt, 1, lanes_per_col=self.lanes)
+    self._solve()
+
   def run(self, nsteps):
-    for _ in range(int(nsteps)):
-      self.cols.steps(self.wA, self.dt, 1, lanes_per_col=self.lanes)
-      self._solve()
+    from .device import Graph
+    remaining = int(nsteps)
+    while self._use_graph and remaining >= self.GRAPH_STEPS:
+      if self._graph is None:
+        with Graph.capture(self.stream) as cap:
+          for _ in range(self.GRAPH_STEPS):
+            self._step()
+        self._graph = cap.graph
+      self._graph.launch(self.stream)
+      remaining -= self.GRAPH_STEPS
+    for _ in range(remaining):
+      self._step()
 
   def state(self):
     return dict(b=self.cols.get_b(), Psi=self.tw.Psi.download(stream=self.stream))

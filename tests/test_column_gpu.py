@@ -233,3 +233,122 @@ def test_streaming_kernel_large_ensemble_bitwise(gpu, nz, nsteps):
                                    bzbot=None if np.isnan(bzbot[sl][j]) else bzbot[sl][j],
                                    N2min=c["N2min"][sl][j])
     assert np.array_equal(b[sl], ref), lo
+
+
+def _extreme_cases(c, N):
+  """Per-column edits of a config-2 ensemble that leave the window of the exact-division
+  shortcuts (common.hip.h: 2^-200 <= |x| <= 2^200 or 0): returns (b0, wA, bs, bbot, kinds)."""
+  rng = np.random.default_rng(17)
+  b0, wA, bs, bbot = c["b0"].copy(), c["wA"].copy(), c["bs"].copy(), np.array(c["bbot"], dtype=float) + np.zeros(N)
+  kinds = rng.integers(0, 8, N)
+  nz = b0.shape[1]
+  for m in range(N):
+    k = kinds[m]
+    if k == 1:    # the whole column scaled down by 2^-1000 (forcing too: CFL unchanged)
+      s = 2.0**-1000
+      b0[m] *= s; bs[m] *= s; bbot[m] *= s
+    elif k == 2:  # ... scaled up by 2^+900
+      s = 2.0**900
+      b0[m] *= s; bs[m] *= s; bbot[m] *= s
+    elif k == 3:  # an infinite interior level
+      b0[m, nz // 2] = np.inf
+    elif k == 4:  # a NaN next to the top, a -inf next to the bottom
+      b0[m, nz - 2] = np.nan
+      b0[m, 1] = -np.inf
+    elif k == 5:  # subnormal forcing
+      wA[m] *= 2.0**-1060
+    elif k == 6:  # buoyancy differences that round into the subnormal range
+      b0[m] = b0[m] * 2.0**-1015
+      bs[m] *= 2.0**-1015; bbot[m] *= 2.0**-1015
+  return b0, wA, bs, bbot, kinds
+
+
+@pytest.mark.parametrize("G", [16, 64])
+@pytest.mark.parametrize("nsteps", [1, 7, 40])
+def test_operands_outside_the_fast_division_window_bitwise(gpu, G, nsteps):
+  """VERDICT r2 'weak' item 1: the 4-instruction exact division and the select-free flux are
+  IEEE-identical only while quotients and residuals stay normal and finite.  Columns scaled
+  by 2^-1000 / 2^+900, with inf / NaN levels or subnormal forcing must still be BIT-identical to
+  the oracle (which divides with `/` and never touches boundary levels, like NumPy): the kernel
+  detects them per wave and steps in its IEEE form.  Neighbouring ordinary columns (also in
+  the same wave, G = 16) are unaffected."""
+  N = 192
+  c = configs.config2(N=N)
+  b0, wA, bs, bbot, kinds = _extreme_cases(c, N)
+  batch = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], b0, bs=bs, bbot=bbot, N2min=c["N2min"],
+                          do_conv=c["do_conv"])
+  with np.errstate(all="ignore"):
+    batch.steps(wA, c["dt"], nsteps, lanes_per_col=G)
+    got = batch.get_b()
+    for m in range(N):
+      ref = b0[m].copy()
+      for _ in range(nsteps):
+        ref = O.column_timestep(c["z"], c["kappa"][m], c["Area"][m], ref, wA[m], c["dt"],
+                                do_conv=bool(c["do_conv"][m]), bs=bs[m], bbot=bbot[m],
+                                N2min=c["N2min"][m])
+      assert np.array_equal(got[m], ref, equal_nan=True), (m, int(kinds[m]), G, nsteps)
+  nf = batch.get_nonfinite()
+  assert np.array_equal(nf != 0, ~np.isfinite(got).all(axis=1))
+  assert set(np.unique(kinds)) == set(range(8))
+
+
+def test_operands_outside_the_fast_division_window_streaming_kernel(gpu):
+  """The same through k_column_stream (one step per launch on a large ensemble)."""
+  N = 66000
+  c = configs.config2(N=N)
+  sel = np.arange(0, N, 997)
+  sub = {k: (v[sel] if isinstance(v, np.ndarray) and v.shape[:1] == (N,) else v) for k, v in c.items()}
+  b0s, wAs, bss, bbots, kinds = _extreme_cases(sub, sel.size)
+  b0, wA, bs = c["b0"].copy(), c["wA"].copy(), c["bs"].copy()
+  bbot = np.array(c["bbot"], dtype=float) + np.zeros(N)
+  b0[sel], wA[sel], bs[sel], bbot[sel] = b0s, wAs, bss, bbots
+  batch = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], b0, bs=bs, bbot=bbot, N2min=c["N2min"],
+                          do_conv=c["do_conv"])
+  assert batch.kernel_name(1).startswith("k_column_stream")
+  with np.errstate(all="ignore"):
+    batch.steps(wA, c["dt"], 1)
+    batch.steps(wA, c["dt"], 2)
+    got = batch.get_b()
+    for m in list(sel) + [1, 2, N - 1]:
+      ref = b0[m].copy()
+      for _ in range(3):
+        ref = O.column_timestep(c["z"], c["kappa"][m], c["Area"][m], ref, wA[m], c["dt"],
+                                do_conv=bool(c["do_conv"][m]), bs=bs[m], bbot=bbot[m],
+                                N2min=c["N2min"][m])
+      assert np.array_equal(got[m], ref, equal_nan=True), m
+
+
+@pytest.mark.parametrize("nsteps", [1, 2, 25])
+def test_precombined_forcing_and_uniform_area_bitwise(gpu, nsteps):
+  """PM_OP_WEFF (the caller hands weff = wA - d(A kappa)/dz, computed once per overturning
+  update by pm_column_weff) and the PM_COL_UNIFORM_AREA hint: the streaming kernel then moves
+  32 nz instead of 48 nz bytes per column-step.  Same bits as the plain call, on the streaming
+  kernel (1, 2 steps) and on the fused kernel (25), with both coefficient sets in use."""
+  N = 66000
+  c = configs.config2(N=N)
+  kap_alt = c["kappa"] * 1.7
+
+  def make():
+    b = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"], bs=c["bs"], bbot=c["bbot"],
+                        N2min=c["N2min"], do_conv=c["do_conv"], kappa_alt=kap_alt)
+    b.set_ksel((np.arange(N) % 3 == 0).astype(np.int32))
+    return b
+  plain, pre = make(), make()
+  assert pre.uniform_area and (pre._flags_host & 8).all() and (pre._flags_host & 4).all()
+  plain._flags_host &= ~np.int32(8 | 4)   # no hints: every array is read, every operand tested
+  plain.flags.upload(plain._flags_host)
+  wA = gpu.DeviceArray.from_host(c["wA"])
+  weff = pre.combine_forcing(wA)
+  for _ in range(3):
+    plain.steps(wA, c["dt"], nsteps)
+    pre.steps(weff, c["dt"], nsteps, precombined=True)
+  assert np.array_equal(plain.get_b(), pre.get_b())
+  for m in (0, 3, N - 1):
+    ref = c["b0"][m].copy()
+    kap = kap_alt[m] if m % 3 == 0 else c["kappa"][m]
+    for _ in range(3 * nsteps):
+      ref = O.column_timestep(c["z"], kap, c["Area"][m], ref, c["wA"][m], c["dt"],
+                              do_conv=bool(c["do_conv"][m]), bs=c["bs"][m],
+                              bbot=float(np.atleast_1d(c["bbot"])[m % np.size(c["bbot"])]),
+                              N2min=c["N2min"][m])
+    assert np.array_equal(pre.get_b()[m], ref), m

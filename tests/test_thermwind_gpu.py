@@ -141,6 +141,24 @@ def test_config1_trajectory(gpu):
     assert np.array_equal(st["Psi"][0], orc[s]["Psi"])
 
 
+def test_config1_ensemble_graph_replay_equals_step_by_step(gpu):
+  """The config-1 style loop (column step + thermal-wind solve every model step) replayed from a
+  hipGraph of 32 steps against one launch pair per step: same kernels, same order, same bits --
+  on an ensemble large enough for the one-step streaming kernel too."""
+  for n in (64, 20000):
+    c1 = configs.config1(nz=100)
+    rng = np.random.default_rng(n)
+    cfg = dict(c1, b0=c1["b0"][None] * (1 + 0.05 * rng.random((n, 1))))
+    a = gpu.ColumnThermwindEnsemble(cfg, use_graph=True)
+    b = gpu.ColumnThermwindEnsemble(cfg, use_graph=False)
+    a.run(75)   # two replays + 11 single steps
+    b.run(75)
+    sa, sb = a.state(), b.state()
+    assert a._graph is not None and b._graph is None
+    for k in sa:
+      assert np.array_equal(sa[k], sb[k]), (n, k)
+
+
 def test_twocol_trajectory_golden(gpu):
   """example_twocol physics, nz=100: 4800 steps vs the reference's snapshots; the engine
   is bit-identical to the oracle all the way."""
