@@ -277,7 +277,13 @@ typedef struct pm_so_ml {
   int32_t *status;         /* [n] out: 1 where the reference raises IndexError (Psi_b all
                               zero / no upwelling level; state left untouched), 2 non-finite
                               result, 16 (pm_jn2018_steps only) a wrong
-                              PM_JN_UNIFORM_AREA hint (may be NULL)                     */
+                              PM_JN_UNIFORM_AREA hint, 32 (pm_jn2018_steps' uniform-Area
+                              kernel only) an operand of the column steps -- state, forcing,
+                              coefficients, grid, dt -- outside the window [2^-200, 2^200] in
+                              which the kernel's 4-instruction division is IEEE-identical: the
+                              member was stepped, but is not guaranteed bit-identical to the
+                              reference's arithmetic; pm_column_steps tests the same and falls
+                              back to IEEE division instead (may be NULL)               */
 } pm_so_ml;
 
 int pm_so_ml_step(const pm_so_ml *ml, double dt, pm_stream_t stream);

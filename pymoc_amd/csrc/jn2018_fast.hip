@@ -359,7 +359,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
   JfCol<P> cb, cn;
   JfConv<P> vb, vn;
   int ksel_b, ksel_n;
-  bool hint_ok = true;
+  bool hint_ok = true, range_ok = in_fast_div_range(dt);
   {
     const pm_columns &c = a.cols;
     auto load_col = [&](JfCol<P> &r, JfConv<P> &v, int col, double *wsc) {
@@ -373,6 +373,13 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
         same = same && c.area[(size_t)col * nz + ic] == a0;
       }
       hint_ok = hint_ok && __ballot(!same) == 0ull;
+      {  // operands inside the exact-division window? (common.hip.h; flagged, not branched on)
+        bool ok = in_fast_div_range(a0) && a0 != 0.0 && in_fast_div_range(c.bs[col]) &&
+                  in_fast_div_range(c.N2min[col]) && in_fast_div_range(c.bbot[col]);
+#pragma unroll
+        for (int p = 0; p < P; ++p) ok = ok && (lane * P + p >= nz || in_fast_div_range(r.b[p]));
+        range_ok = range_ok && __ballot(!ok) == 0ull;
+      }
       if (lane == 0) {
         const double ra = 1.0 / a0;
         wsc[S_BS] = c.bs[col];
@@ -460,6 +467,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
   while (s < nsteps) {
     {
       jf_kargs ka = jf_args();
+      bool coef_ok = true;
       auto load_coef = [&](JfCol<P> &r, double *kap, int col, int sel) {
         const double *kappa = ka->cols.kappa, *dAk = ka->cols.dAkappa, *wA = ka->wA;
         const size_t sbase = ((size_t)sel * (2 * n) + col) * nz;
@@ -473,10 +481,12 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
           const double we = (i >= 1 && i <= nz - 2) ? w : 0.0;
           r.wn[p] = (we < 0.0) ? -we : 0.0;
           r.wp[p] = (we < 0.0) ? 0.0 : -we;
+          coef_ok = coef_ok && in_fast_div_range(we) && in_fast_div_range(r.kap[p]);
         }
       };
       load_coef(cb, nullptr, m, ksel_b);
       load_coef(cn, wl + L::W_KN, n + m, ksel_n);
+      range_ok = range_ok && __ballot(!coef_ok) == 0ull;
       __builtin_amdgcn_wave_barrier();
     }
     // BC switch + both columns of step s; false: a coefficient set changed (nothing done yet)
@@ -724,7 +734,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
       nonfinite[n + m] = anybad ? 1 : 0;
     }
     int32_t *st = ka->ml.status;
-    if (st) st[m] = status | (anybad ? 2 : 0) | (hint_ok ? 0 : 16);
+    if (st) st[m] = status | (anybad ? 2 : 0) | (hint_ok ? 0 : 16) | (range_ok ? 0 : 32);
   }
   PM_WAVE_END(m_raw)
 }

@@ -345,3 +345,21 @@ def test_config5_whole_baseline_ensemble_on_one_gpu(gpu):
   sp = part.state()
   for k in ("b_basin", "b_north", "bs_SO", "Psi_SO"):
     assert np.array_equal(sp[k], st[k][lo:lo + 4096], equal_nan=True), k
+
+
+def test_jn2018_fused_flags_operands_outside_the_division_window(gpu):
+  """The fused loop divides with the 4-instruction exact sequence only (no IEEE leg): a member
+  whose column operands leave the window in which that is IEEE-identical (common.hip.h) is
+  stepped but FLAGGED (status bit 5), the others are not."""
+  c = configs.config5(N=64)
+  e = gpu.JN2018Ensemble(c, fused=True)
+  e.run(36)
+  assert np.all(e.ml.status.download() & 32 == 0)
+  b = e.cols.get_b()
+  b[7] *= 2.0**-1000          # basin column of member 7
+  b[64 + 9, 50] = 2.0**300    # one level of the northern column of member 9
+  e.cols.set_b(b)
+  e.run(36)
+  st = e.ml.status.download()
+  lost = set(int(i) for i in e.nonfinite_members())  # (member 2 of this draw: the reference's own)
+  assert set(int(i) for i in np.nonzero(st & 32)[0]) - lost == {7, 9}
