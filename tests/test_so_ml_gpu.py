@@ -362,4 +362,5 @@ def test_jn2018_fused_flags_operands_outside_the_division_window(gpu):
   e.run(36)
   st = e.ml.status.download()
   lost = set(int(i) for i in e.nonfinite_members())  # (member 2 of this draw: the reference's own)
-  assert set(int(i) for i in np.nonzero(st & 32)[0]) - lost == {7, 9}
+  flagged = set(int(i) for i in np.nonzero(st & 32)[0])
+  assert {7, 9} <= flagged and flagged <= {7, 9} | lost
