@@ -194,12 +194,12 @@ def load_json(path):
     return {}
 
 
-def run_steps(batch, wA, dt, nsteps, per_launch, lanes):
+def run_steps(batch, wA, dt, nsteps, per_launch, lanes, arith="exact"):
   """Exactly nsteps steps as ceil(nsteps/per_launch) launches; returns launch count."""
   done, launches = 0, 0
   while done < nsteps:
     n = min(per_launch, nsteps - done)
-    batch.steps(wA, dt, n, lanes_per_col=lanes)
+    batch.steps(wA, dt, n, lanes_per_col=lanes, arith=arith)
     done += n
     launches += 1
   return launches
@@ -242,6 +242,22 @@ def bench_config2(args, env):
   kernel_ms = ev0.elapsed_ms(ev1)
   nonfinite = int(batch.get_nonfinite().sum())
   b_final = batch.get_b()
+  # the opt-in tolerance mode (PM_OP_CONTRACTED) on a copy of the same ensemble, same K launches
+  # (every rank runs it: no collective inside)
+  tol = pymoc_amd.ColumnBatch(cfg["z"], cfg["kappa"], cfg["Area"], cfg["b0"], bs=cfg["bs"],
+                              bbot=cfg["bbot"], N2min=cfg["N2min"], do_conv=cfg["do_conv"],
+                              stream=stream)
+  run_steps(tol, wA, dt, W * F, F, args.lanes, arith="contracted")
+  stream.sync()
+  ev2, ev3 = Event(), Event()
+  ev2.record(stream)
+  run_steps(tol, wA, dt, K * F, F, args.lanes, arith="contracted")
+  ev3.record(stream)
+  stream.sync()
+  tol_ms = ev2.elapsed_ms(ev3) / launches
+  tol_b = tol.get_b()
+  tol_err = float(np.max(np.abs(tol_b - b_final)) / np.max(np.abs(b_final)))
+  del tol
   if rank != 0:
     return None
 
@@ -289,6 +305,25 @@ def bench_config2(args, env):
                          "the roof; see roofline_hbm_regime for the regime where it is" % F},
       "nonfinite_columns": nonfinite,
       "checksum": float(np.sum(b_final)),
+      "contracted_mode": {
+          "what": "opt-in tolerance mode (PM_OP_CONTRACTED / ColumnBatch.steps(arith='contracted')): "
+                  "b_i += cu_i (b_{i+1}-b_i) + cl_i (b_i-b_{i-1}) with per-launch coefficients, "
+                  "one subtraction + two fma per level instead of the reference's 21-instruction "
+                  "operation order; NOT the headline (`value` is the bit-identical default mode)",
+          "column_timesteps_per_s": C * F / (tol_ms * 1e-3),
+          "kernel": batch.kernel_name(F, args.lanes, arith="contracted"),
+          "kernel_ms_per_launch": tol_ms,
+          "max_rel_diff_to_exact_mode": tol_err,
+          "tolerance": "<= 1e-12 relative to the reference over BASELINE's runs "
+                       "(tests/test_column_gpu.py::test_contracted_mode_vs_reference_goldens)",
+          "roofline": {"bound": "fp64-valu", "achieved": flop / (tol_ms * 1e-3) / 1e12,
+                       "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": flop / (tol_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                       "flop_model": "the same 14*(nz-2) algorithmic flop per column-step as the "
+                                     "exact mode (what the reference computes); the contracted "
+                                     "form ISSUES 5*(nz-2): frac_issued below",
+                       "frac_issued": 5.0 * (nz - 2) * C * F / (tol_ms * 1e-3) / 1e12 /
+                                      FP64_PEAK_TFLOPS}},
   }
   if not args.no_single_step:
     # one step per launch (b, wA and the static coefficients cross HBM/L2 every step): the
@@ -364,10 +399,10 @@ def make_ensemble(config, env, members, comm=None, n_total=None):
     kw.update(comm=comm, n_total=n_total)
   if config == 3:
     cfg = configs.config3(N=n_total, members=sl)
-    ens = pymoc_amd.TwoColEnsemble(cfg, diag_iters=240, **kw)
+    ens = pymoc_amd.TwoColEnsemble(cfg, diag_iters=240, arith=env.get("arith", "exact"), **kw)
   elif config == 4:
     cfg = dict(configs.config4(N=n_total, members=sl), bvp_refine=env.get("bvp_refine", 0))
-    ens = pymoc_amd.TwoColEnsemble(cfg, **kw)
+    ens = pymoc_amd.TwoColEnsemble(cfg, arith=env.get("arith", "exact"), **kw)
   else:
     cfg = configs.config5(N=n_total, members=sl)
     cfg["rest_mask"] = np.repeat(cfg["rest_mask"][None], members, axis=0)
@@ -596,6 +631,13 @@ def main():
           r8, ens = bench_coupled(4, args, dict(env, bvp_refine=8), SIZES[4]["members"],
                                   nsteps=SIZES[4]["nsteps"], warm_blocks=10, breakdown=False)
           res["fixed_mesh_R8_coupled_steps_per_s"] = r8["coupled_steps_per_s"]
+        if c in (3, 4):
+          # the columns in the opt-in tolerance mode (PM_OP_CONTRACTED; reference parity 1e-12 /
+          # 1e-11 instead of bit-identity to the oracle, tests/test_thermwind_gpu.py)
+          del ens
+          rc, ens = bench_coupled(c, args, dict(env, arith="contracted"), SIZES[c]["members"],
+                                  nsteps=SIZES[c]["nsteps"], warm_blocks=10, breakdown=False)
+          res["contracted_columns_coupled_steps_per_s"] = rc["coupled_steps_per_s"]
         if c in cpu:
           res["cpu_baseline"] = cpu[c]
         out["coupled"]["config%d" % c] = res

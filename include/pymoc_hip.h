@@ -105,6 +105,13 @@ int pm_graph_destroy(pm_graph_t graph);
                                 needs of the two (column.py:241); d(A kappa)/dz is then not read.
                                 wA is static between two overturning updates in every reference
                                 driver, so weff is too.                                          */
+#define PM_OP_CONTRACTED 16  /* modifier, OPT-IN tolerance mode: launches of >= 3 plain timesteps
+                                (one wave per column, nz <= 256) use the contracted update
+                                b_i += cu_i (b_{i+1}-b_i) + cl_i (b_i-b_{i-1}) with per-launch
+                                coefficients instead of the reference's operation order (3
+                                instead of 21 instructions per level).  Agrees with the reference
+                                to rounding (<= 1e-12 relative over BASELINE's runs), not bit for
+                                bit; without the flag every result is bit-identical to NumPy.    */
 
 typedef struct pm_columns {
   int32_t ncols;         /* independent columns in the batch                      */

@@ -20,6 +20,7 @@ PM_OK, PM_EINVAL, PM_EHIP, PM_ENCCL, PM_ENODEV = 0, 1, 2, 3, 4
 PM_COL_DO_CONV, PM_COL_BZBOT, PM_COL_STATIC_IN_RANGE, PM_COL_UNIFORM_AREA = 1, 2, 4, 8
 PM_EQ_HFREE, PM_EQ_HAS_BBOT, PM_EQ_KAPPA_ARRAY, PM_EQ_PSI_ARRAY = 1, 2, 4, 8
 PM_OP_CONVECT, PM_OP_VERTADVDIFF, PM_OP_HORADV, PM_OP_TIMESTEP, PM_OP_WEFF = 1, 2, 4, 7, 8
+PM_OP_CONTRACTED = 16
 
 c_dp = C.c_void_p  # device pointers travel as plain addresses
 

@@ -253,6 +253,25 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
   // bottom boundary condition (column.py:232-233); level 0 = lane 0, slot 0
   if (BC && lvl0 + lg * P == 0) r.b[0] = use_bzbot ? (bup[0] - bzbot * g.dz[0]) : bbot;
 
+  if constexpr (DIV == 4) {
+    // Contracted form (opt-in tolerance mode, PM_OP_CONTRACTED).  With weff, kappa, Area and
+    // the grid static over a launch, column.py:235-249 is linear in the state:
+    //   b_i += cu_i (b_{i+1} - b_i) + cl_i (b_i - b_{i-1}),
+    // with the per-launch coefficients of col_make_contracted in r.kap (cu) and r.dAk (cl),
+    // zero on boundary and padding levels: one subtraction and two fma per level instead of 21
+    // instructions.  Not the reference's operation order: agrees to rounding (1e-12 over the
+    // BASELINE runs, tests/test_column_gpu.py), not bit for bit.
+    double d_up[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) d_up[p] = bup[p] - r.b[p];
+    const double pd = from_prev_lane_z(d_up[P - 1]);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const double d_dn = (p > 0) ? d_up[p > 0 ? p - 1 : 0] : pd;
+      r.b[p] = __builtin_fma(r.kap[p], d_up[p], __builtin_fma(r.dAk[p], d_dn, r.b[p]));
+    }
+    return;
+  }
   // Every stage below is written across the P slots so that the in-order wave always has
   // P independent dependency chains in flight (one wave per SIMD is latency-bound).
   double bz[P];  // (b[i+1]-b[i])/dz[i]  (column.py:235)
@@ -457,7 +476,7 @@ __device__ __forceinline__ void col_load_grid(ColGrid<P> &g, const pm_columns &c
     g.z[p] = zc;
     g.dz[p] = c.z[iu] - zc;
     g.dzc[p] = 0.5 * (g.dz[p] + (zc - c.z[id]));
-    if constexpr (DIV != 0) {  // reciprocals only where div_by_recip will use them
+    if constexpr (DIV != 0 && DIV != 4) {  // reciprocals only where div_by_recip will use them
       g.rdz[p] = (i < nz - 1) ? 1.0 / g.dz[p] : 0.0;  // 0: bz above the top level is 0
       g.rdzc[p] = 1.0 / g.dzc[p];
     } else {
@@ -484,8 +503,34 @@ __device__ __forceinline__ void col_load_static(ColRegs<P> &r, const pm_columns 
   load_levels<P>(r.area, c.area + base, lg, nz, lvl0);
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    r.rarea[p] = DIV != 0 ? 1.0 / r.area[p] : 0.0;
+    r.rarea[p] = (DIV != 0 && DIV != 4) ? 1.0 / r.area[p] : 0.0;
     r.rarea_l[p] = DIV == 2 ? recip_lo(r.area[p], r.rarea[p]) : 0.0;
+  }
+}
+
+// Coefficients of the contracted step (col_vertadvdiff, DIV == 4) of a wave-owned column:
+//   cu_i = dt (kappa_i / (dzc_i dz_i)     + [weff_i <  0] (-weff_i) / (A_i dz_i))      -> r.kap
+//   cl_i = dt (-kappa_i / (dzc_i dz_{i-1}) + [weff_i >= 0] (-weff_i) / (A_i dz_{i-1})) -> r.dAk
+// (the diffusion and upwind-advection terms of column.py:235-249 collected by the difference they
+// multiply); zero on boundary and padding levels, which therefore stay put.
+template <int P>
+__device__ __forceinline__ void col_make_contracted(const ColGrid<P> &g, ColRegs<P> &r,
+                                                    const double (&wA)[P], double dt, int lane,
+                                                    int nz) {
+  const double dz_prev_lane = from_prev_lane_z(g.dz[P - 1]);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    const bool interior = i >= 1 && i <= nz - 2;
+    const double weff = wA[p] - r.dAk[p];
+    const double dz_up = interior ? g.dz[p] : 1.0;
+    const double dz_dn = interior ? ((p > 0) ? g.dz[p > 0 ? p - 1 : 0] : dz_prev_lane) : 1.0;
+    const double dzc = interior ? g.dzc[p] : 1.0, area = interior ? r.area[p] : 1.0;
+    const double wn = (weff < 0.0) ? -weff : 0.0, wp = (weff < 0.0) ? 0.0 : -weff;
+    const double cu = dt * (r.kap[p] / (dzc * dz_up) + wn / (area * dz_up));
+    const double cl = dt * (-r.kap[p] / (dzc * dz_dn) + wp / (area * dz_dn));
+    r.kap[p] = interior ? cu : 0.0;
+    r.dAk[p] = interior ? cl : 0.0;
   }
 }
 
@@ -740,6 +785,8 @@ __global__ __launch_bounds__(256) void k_column_steps(
       return;
     }
   }
+
+  if constexpr (FAST == 4) col_make_contracted<P>(g, r, wA, dt, lane, nz);  // (G == 64 only)
 
   if constexpr (PLAIN) {
     if (do_conv && use_bzbot) {
@@ -1018,7 +1065,8 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
   const int cols_per_block = 256 / G;
   const unsigned grid = (unsigned)((c.ncols + cols_per_block - 1) / cols_per_block);
   const bool weff_in = (ops & PM_OP_WEFF) != 0;  // wA holds wA - d(A kappa)/dz
-  ops &= ~PM_OP_WEFF;
+  const bool contracted = (ops & PM_OP_CONTRACTED) != 0;  // tolerance mode (one wave per column)
+  ops &= ~(PM_OP_WEFF | PM_OP_CONTRACTED);
   if constexpr (G == 64 && P <= 4) {
     const int cpw = stream_cols_per_wave(c.ncols);
     if (nsteps < 3 && ops == PM_OP_TIMESTEP && !vdx && cpw >= 2) {
@@ -1034,6 +1082,14 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
       else
         hipLaunchKernelGGL((k_column_stream<P, 2>), dim3((waves + 3) / 4), dim3(256), 0, st, c, wA,
                            dt, nsteps, cpw, dt_ok, weff_in);
+      PM_HIP(hipGetLastError());
+      return PM_OK;
+    }
+  }
+  if constexpr (G == 64 && P <= 4) {
+    if (contracted && nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx) {
+      hipLaunchKernelGGL((k_column_steps<G, P, 4, true>), dim3(grid), dim3(256), 0, st, c, wA, vdx,
+                         bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0));
       PM_HIP(hipGetLastError());
       return PM_OK;
     }

@@ -294,9 +294,11 @@ int pm_column_kernel_name(int32_t ncols, int32_t nz, int32_t lanes_per_col, int3
   int G = 0, P = 0;
   const int rc = column_shape(ncols, nz, lanes_per_col, &G, &P);
   if (rc != PM_OK) return rc;
-  const bool plain = (ops & ~PM_OP_WEFF) == PM_OP_TIMESTEP && !has_horadv;
+  const bool plain = (ops & ~(PM_OP_WEFF | PM_OP_CONTRACTED)) == PM_OP_TIMESTEP && !has_horadv;
   if (G == 64 && P <= 4 && nsteps < 3 && plain && stream_cols_per_wave(ncols) >= 2)
     snprintf(name, name_len, "k_column_stream<%d>", P);
+  else if (G == 64 && P <= 4 && nsteps >= 3 && plain && (ops & PM_OP_CONTRACTED))
+    snprintf(name, name_len, "k_column_steps<64,%d,4,true>", P);
   else  // mirrors launch_column_steps (column.hip.h)
     snprintf(name, name_len, "k_column_steps<%d,%d,%d,%s>", G, P,
              nsteps >= 3 ? (plain ? 2 : 1) : 0, (nsteps >= 3 && plain) ? "true" : "false");
@@ -315,7 +317,8 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
   PM_REQUIRE(c.z && c.b && c.kappa && c.area && c.dAkappa && c.bs && c.bbot && c.N2min,
              "pm_columns has a NULL required pointer");
   PM_REQUIRE(nsteps >= 0, "nsteps < 0");
-  PM_REQUIRE((ops & ~(PM_OP_TIMESTEP | PM_OP_WEFF)) == 0, "unknown op bits 0x%x", ops);
+  PM_REQUIRE((ops & ~(PM_OP_TIMESTEP | PM_OP_WEFF | PM_OP_CONTRACTED)) == 0,
+             "unknown op bits 0x%x", ops);
   PM_REQUIRE(!(ops & PM_OP_VERTADVDIFF) || wA, "wA is NULL");
   PM_REQUIRE(!vdx_in || b_in, "b_in is needed if vdx_in is provided");
   if (c.ncols == 0 || nsteps == 0 || (ops & PM_OP_TIMESTEP) == 0) return PM_OK;

@@ -137,17 +137,19 @@ class TwoColEnsemble(object):
   mapped to isopycnal space every MOC_up_iters steps."""
 
   def __init__(self, cfg, stream=None, lanes_per_col=0, comm=None, n_total=None,
-               diag_iters=None, keep_history=False):
+               diag_iters=None, keep_history=False, arith="exact"):
     """`comm` (a pymoc_amd.sharding communicator) makes this rank's members one shard of an
     `n_total`-member ensemble: stepping is unchanged (members never interact) and
     {b_basin, b_north, Psi, Psi_SO} are all-gathered on device buffers every `diag_iters`
-    steps (default cfg['Diag_iters']) and by `gather_diagnostics()` at the end of a run."""
+    steps (default cfg['Diag_iters']) and by `gather_diagnostics()` at the end of a run.
+    `arith="contracted"`: the columns step in the opt-in tolerance mode (ColumnBatch.steps)."""
     z = cfg['z']
     nz = z.size
     n = np.atleast_2d(cfg['b_basin0']).shape[0]
     self.n, self.nz = n, nz
     self.dt, self.M, self.nb = float(cfg['dt']), int(cfg['MOC_up_iters']), int(cfg['nb'])
     self.lanes = lanes_per_col
+    self.arith = arith
     self.stream = stream
     self.diag_iters = cfg.get('Diag_iters') if diag_iters is None else diag_iters
     self.diag = None
@@ -209,7 +211,7 @@ class TwoColEnsemble(object):
     while remaining > 0:
       nxt = self.ii if self.ii % self.M == 0 else (self.ii // self.M + 1) * self.M
       n = min(nxt - self.ii + 1, remaining)
-      self.cols.steps(self.wA, self.dt, n, lanes_per_col=self.lanes)
+      self.cols.steps(self.wA, self.dt, n, lanes_per_col=self.lanes, arith=self.arith)
       self.ii += n
       remaining -= n
       if (self.ii - 1) % self.M == 0:

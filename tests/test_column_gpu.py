@@ -352,3 +352,69 @@ def test_precombined_forcing_and_uniform_area_bitwise(gpu, nsteps):
                               bbot=float(np.atleast_1d(c["bbot"])[m % np.size(c["bbot"])]),
                               N2min=c["N2min"][m])
     assert np.array_equal(pre.get_b()[m], ref), m
+
+
+# ---- the opt-in tolerance mode (PM_OP_CONTRACTED, ColumnBatch.steps(arith="contracted")) ----
+CONTRACTED_RTOL = 1e-12  # max-norm, relative to max|reference| (SURVEY 8d's tolerance for K1)
+
+
+def _rel(a, ref):
+  return np.max(np.abs(a - ref)) / np.max(np.abs(ref))
+
+
+def test_contracted_mode_vs_reference_goldens(gpu):
+  """The contracted update b_i += cu_i (b_{i+1}-b_i) + cl_i (b_i-b_{i-1}) against the
+  reference's own numbers: every G1 single-column case over 3 steps (uniform / non-uniform
+  grids, convective adjustment, bottom-stratification BC), and the G8 / G17 config-2 members
+  over 200 and over the whole 1000 steps -- within 1e-12; the default mode stays bit-identical."""
+  g = load_golden("column_steps")
+  worst = 0.
+  for k in range(int(g["ncases"])):
+    p = "c%02d_" % k
+    dt, do_conv, bzbot, hor, bs, bbot, N2min = g[p + "par"]
+    if hor:
+      continue  # horadv launches are not "plain": they take the exact kernels
+    batch = gpu.ColumnBatch(g[p + "z"], g[p + "kappa"], g[p + "Area"], g[p + "b0"], bs=bs,
+                            bbot=bbot, bzbot=None if np.isnan(bzbot) else bzbot,
+                            N2min=N2min, do_conv=bool(do_conv))
+    assert batch.kernel_name(3, arith="contracted").endswith(",4,true>") or g[p + "z"].size > 256
+    batch.steps(g[p + "wA"], dt, 3, arith="contracted")
+    worst = max(worst, _rel(batch.get_b()[0], g[p + "b3"]))
+  assert worst <= CONTRACTED_RTOL, worst
+  c = configs.config2(N=1024)
+  for name in ("sweep", "sweep_full"):
+    gg = load_golden(name)
+    batch = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"], bs=c["bs"],
+                            bbot=c["bbot"], N2min=c["N2min"], do_conv=c["do_conv"])
+    batch.steps(c["wA"], c["dt"], int(gg["c2_nsteps"]), arith="contracted")
+    b = batch.get_b()
+    err = _rel(b[gg["c2_members"]], gg["c2_b"])
+    assert err <= CONTRACTED_RTOL, (name, err)
+    assert not np.array_equal(b[gg["c2_members"]], gg["c2_b"])  # (it IS another arithmetic)
+    assert batch.get_nonfinite().sum() == 0
+
+
+@pytest.mark.parametrize("nz", [17, 64, 100, 200, 256])
+def test_contracted_mode_ragged_sizes_and_splits(gpu, nz):
+  """Contracted vs exact on random columns with convection churn, several lane geometries; and
+  splitting a run into launches changes nothing but rounding (the coefficients are per launch)."""
+  rng = np.random.default_rng(nz)
+  ncols = 53
+  z = np.sort(rng.uniform(-4000, 0, nz))
+  z[-1] = 0.
+  kap = 1e-5 + 1e-4 * rng.random((ncols, nz))
+  area = 8e13 * (1 + 0.2 * rng.random((ncols, nz)))
+  dt = 0.3 * np.diff(z).min()**2 / kap.max()
+  b0 = np.sort(0.03 * rng.random((ncols, nz)), axis=1) + 1e-3 * rng.standard_normal((ncols, nz))
+  wA = area * 2e-8 * rng.standard_normal((ncols, 1)) * np.sin(np.pi * z / 4000.)[None]
+  kw = dict(bs=0.02 + 0.01 * rng.random(ncols), bbot=-0.001, N2min=2e-7,
+            do_conv=rng.random(ncols) < 0.5)
+  ex = gpu.ColumnBatch(z, kap, area, b0, **kw)
+  ct = gpu.ColumnBatch(z, kap, area, b0, **kw)
+  sp = gpu.ColumnBatch(z, kap, area, b0, **kw)
+  ex.steps(wA, dt, 120)
+  ct.steps(wA, dt, 120, arith="contracted")
+  for n in (50, 3, 67):
+    sp.steps(wA, dt, n, arith="contracted")
+  assert _rel(ct.get_b(), ex.get_b()) <= CONTRACTED_RTOL
+  assert _rel(sp.get_b(), ex.get_b()) <= CONTRACTED_RTOL
