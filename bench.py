@@ -267,8 +267,8 @@ def bench_config2(args, env):
   flop = flops_column_step(nz) * C * F
   alg_bytes = 24.0 * nz * C * F  # read b, read wA, write b per model step
   tf = flop / launch_s / 1e12
-  prof = load_json(os.path.join(ROOT, "profiles", "k1_counters.json"))
-  key = "column_steps_F%d_C%d_nz%d" % (F, C, nz)
+  prof = load_json(os.path.join(ROOT, "profiles", "r03", "counters.json"))
+  key = "c2/" + batch.kernel_name(F, args.lanes)
   out = {
       "metric": "column-timesteps/sec (ensemble) at nz=%d" % nz,
       "value": value, "unit": "column-timesteps/s", "n_gpus": world, "steps": K,
@@ -291,12 +291,20 @@ def bench_config2(args, env):
                         "arithmetic (the reference's, unfused, 3 divisions per level) cannot "
                         "use FMAs for its adds/multiplies" % (flops_column_step(nz), C, F),
           "issue_frac": (prof.get(key) or {}).get("issue_frac"),
-          "issue_frac_source": "VALU-issue cycles / wave cycles (SQ_ACTIVE_INST_VALU x 4 / "
-                               "SQ_WAVE_CYCLES), replayed from profiles/k1_counters.json "
-                               "(separate rocprofv3 --pmc pass, not measured in this run)",
+          "issue_frac_source": "share of a resident wave's life spent issuing vector "
+                               "instructions, SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both count "
+                               "quad-cycles); replayed from profiles/r03/counters.json entry '%s' "
+                               "(separate rocprofv3 --pmc pass on the 1024 x 100 x 1000 workload, "
+                               "not measured in this run)" % key,
           "traffic": (prof.get(key) or {}).get("hbm_bytes_per_launch"),
-          "traffic_source": "FETCH_SIZE+WRITE_SIZE per launch, gfx950-corrected, replayed "
-                            "from profiles/k1_counters.json (not measured in this run)",
+          "traffic_source": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch -- the guide's gfx950 "
+                            "corrections: FETCH_SIZE tallies 128-B requests at 64 B, WRITE_SIZE is "
+                            "exact; replayed from profiles/r03/counters.json (not measured in this "
+                            "run)",
+          "profiled_kernel_avg_us": (prof.get(key) or {}).get("avg_us"),
+          "profiled_kernel_avg_us_source": "rocprofv3 --kernel-trace --stats of `bench.py --config 2 "
+                                           "--no-coupled --no-single-step`: "
+                                           "profiles/r03/c2_kernel_stats.csv",
           "algorithmic_bytes_per_launch": alg_bytes,
           "algorithmic_hbm_GBps": alg_bytes / launch_s / 1e9,
           "why_not_hbm": "with %d steps fused per launch the state stays in registers: HBM "
@@ -473,17 +481,36 @@ def kernel_breakdown(config, cfg, ens, env, reps=20):
           "frac": tf / FP64_PEAK_TFLOPS, "kernel": dom, "kernel_ms_per_launch": ms,
           "flop_model": model, "traffic": None,
           "algorithmic_hbm_GBps": alg / (ms * 1e-3) / 1e9}
-  # instruction mix and vector-issue utilisation of the kernel on this config: SQ counters from
-  # a separate rocprofv3 --pmc run (profiles/collect_coupled_pmc_r02.sh), replayed
-  cnt = load_json(os.path.join(ROOT, "profiles", "coupled_counters.json")).get(
-      "config%d/%s" % (config, dom))
+  # instruction mix, issued fp64 flop and vector-issue utilisation of the kernel on this config:
+  # SQ counters from separate rocprofv3 --pmc runs of `bench.py --config N`
+  # (profiles/collect_r03.sh), replayed
+  allc = load_json(os.path.join(ROOT, "profiles", "r03", "counters.json"))
+  cnt = None
+  for kk, vv in allc.items():
+    if kk.startswith("c%d/" % config) and kk.split("/", 1)[1].startswith(
+        "k_jn2018" if dom == "k_jn2018_steps" else dom):
+      if cnt is None or vv.get("avg_us", 0) * vv.get("launches", 0) > cnt.get("avg_us", 0) * cnt.get("launches", 0):
+        cnt, roof["profiled_kernel"] = vv, kk
   if cnt:
     roof["valu_busy_frac"] = cnt["valu_busy"]
     roof["valu_insts_per_wave"] = cnt["valu_per_wave"]
     roof["salu_insts_per_wave"] = cnt["salu_per_wave"]
-    roof["counters_source"] = ("SQ_ACTIVE_INST_VALU x 4 / (kernel cycles x 1024 SIMDs) and "
-                               "SQ_INSTS_* / SQ_WAVES, replayed from profiles/coupled_counters.json "
-                               "(separate rocprofv3 --pmc pass, not measured in this run)")
+    roof["profiled_kernel_avg_us"] = cnt["avg_us"]
+    roof["issued_fp64_flop_per_launch"] = cnt["fp64_flop_issued_per_launch"]
+    roof["issued_frac"] = cnt["fp64_flop_issued_per_launch"] / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+    roof["counters_source"] = (
+        "replayed from profiles/r03/counters.json (separate rocprofv3 --pmc passes of `bench.py "
+        "--config %d`, not measured in this run): valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 / (kernel "
+        "cycles x 1024 SIMDs); issued fp64 flop = 64 x (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + TRANS_F64 + "
+        "2 FMA_F64) per launch, over THIS run's kernel time = issued_frac; kernel average under the "
+        "profiler: profiles/r03/c%d_kernel_stats.csv" % (config, config))
+    if dom == "k_psi_so":
+      # no closed-form flop count exists for the adaptive solve (mesh sizes and pass counts are
+      # data-dependent): the roofline figure of this kernel IS the counted one
+      roof["achieved"] = roof["issued_frac"] * FP64_PEAK_TFLOPS
+      roof["frac"] = roof["issued_frac"]
+      roof["flop_model"] = ("fp64 flop the kernel issued, counted by the SQ (see counters_source); "
+                            "the adaptive GM boundary-value solve has no closed-form count")
   return shares, roof
 
 
