@@ -323,6 +323,10 @@ int pm_jn2018_bc_switch(const pm_jn2018_bc *bc, pm_stream_t stream);
                                 reference script); a kernel variant then keeps it in scalar
                                 registers.  A wrong hint is detected: the launch fails the
                                 members' status with bit 4 (16) and leaves them untouched.  */
+#define PM_JN_CONTRACTED 2   /* OPT-IN tolerance mode of the uniform-Area kernel: the two columns
+                                step in the contracted form of PM_OP_CONTRACTED (agreement with
+                                the reference to rounding, not bit for bit; the mixed layer and
+                                the bottom-BC switch keep the reference's operation order)     */
 typedef struct pm_jn2018 {
   int32_t n, hints, reserved1, reserved2;
   pm_columns cols;

@@ -296,7 +296,28 @@ __device__ __forceinline__ double jf_pcr_solve(double r, const double *T, int la
   return div_by_recip2(r, br.x, br.y, T[(PCR_LEVELS + 1) * 128 + lane]);
 }
 
+// Contracted column step (opt-in tolerance mode, PM_JN_CONTRACTED): with weff, kappa, Area and
+// the grid static between coefficient-set switches, column.py:235-249 is
+//   b_i += cu_i (b_{i+1} - b_i) + cl_i (b_i - b_{i-1})
+// with cu in c.wn and cl in c.wp (load_coef; zero on boundary and padding levels): one
+// subtraction and two fma per level, no table reads.  K1's PM_OP_CONTRACTED in the fused loop.
 template <int P>
+__device__ __forceinline__ void jf_vertadvdiff_contracted(JfCol<P> &c) {
+  const double nb0 = from_next_lane_z(c.b[0]);
+  double d_up[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) d_up[p] = ((p < P - 1) ? c.b[p + 1 < P ? p + 1 : p] : nb0) - c.b[p];
+  const double pd = from_prev_lane_z(d_up[P - 1]);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const double d_dn = (p > 0) ? d_up[p > 0 ? p - 1 : 0] : pd;
+    c.b[p] = __builtin_fma(c.wn[p], d_up[p], __builtin_fma(c.wp[p], d_dn, c.b[p]));
+  }
+}
+
+// CT: the columns step in the contracted form (tolerance mode); otherwise every operation is
+// the reference's, in its order.
+template <int P, bool CT>
 __global__ __launch_bounds__(64 * JF_WAVES) JF_OCC_ATTR
 void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
   using L = JfLds<P>;
@@ -478,10 +499,24 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
           r.kap[p] = kappa[sbase + ic];
           if (kap) kap[jf_entry<P>(lane, p)] = r.kap[p];
           const double w = wA[(size_t)col * nz + ic] - dAk[sbase + ic];
-          const double we = (i >= 1 && i <= nz - 2) ? w : 0.0;
+          const bool interior = i >= 1 && i <= nz - 2;
+          const double we = interior ? w : 0.0;
           r.wn[p] = (we < 0.0) ? -we : 0.0;
           r.wp[p] = (we < 0.0) ? 0.0 : -we;
           coef_ok = coef_ok && in_fast_div_range(we) && in_fast_div_range(r.kap[p]);
+          if constexpr (CT) {
+            // cu = dt (kappa / (dzc dz) + wn / (A dz)), cl = dt (-kappa / (dzc dz') + wp / (A dz')),
+            // dz' = the spacing below the level (col_make_contracted, column.hip.h)
+            const int iq = interior ? i : 1;
+            const double dz_up = lds[L::T_DZ + jf_entry<P>(iq / P, iq % P)],
+                         dz_dn = lds[L::T_DZ + jf_entry<P>((iq - 1) / P, (iq - 1) % P)],
+                         dzc = lds[L::T_DZC + jf_entry<P>(iq / P, iq % P)];
+            const double area = ka->cols.area[(size_t)col * nz];
+            const double cu = dt * (r.kap[p] / (dzc * dz_up) + r.wn[p] / (area * dz_up));
+            const double cl = dt * (-r.kap[p] / (dzc * dz_dn) + r.wp[p] / (area * dz_dn));
+            r.wn[p] = interior ? cu : 0.0;
+            r.wp[p] = interior ? cl : 0.0;
+          }
         }
       };
       load_coef(cb, nullptr, m, ksel_b);
@@ -541,11 +576,16 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
       jf_convect<P>(cn.b, vn, lds, ws + S_NN, lane_o, nz);
       cb.b[0] = lane0 ? bbot_b : cb.b[0];  // column.py:232 (after convect: it may write level 0)
       cn.b[0] = lane0 ? bbot_n : cn.b[0];
-      __builtin_amdgcn_sched_barrier(0);
-      jf_vertadvdiff<P, true>(cb, lds, ws + S_B, nullptr, lane_o, dt);
-      __builtin_amdgcn_sched_barrier(0);
-      jf_vertadvdiff<P, false>(cn, lds, ws + S_NN, wl + L::W_KN, lane_o, dt);
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (CT) {
+        jf_vertadvdiff_contracted<P>(cb);
+        jf_vertadvdiff_contracted<P>(cn);
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+        jf_vertadvdiff<P, true>(cb, lds, ws + S_B, nullptr, lane_o, dt);
+        __builtin_amdgcn_sched_barrier(0);
+        jf_vertadvdiff<P, false>(cn, lds, ws + S_NN, wl + L::W_KN, lane_o, dt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       return true;
     };
     if (ml_ok) {
@@ -743,7 +783,12 @@ template <int P>
 static int launch_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st) {
   const size_t lds = (size_t)JfLds<P>::TOTAL * sizeof(double);
   const unsigned grid = (unsigned)((a.n + JF_WAVES - 1) / JF_WAVES);
-  hipLaunchKernelGGL((k_jn2018_fast<P>), dim3(grid), dim3(64 * JF_WAVES), lds, st, a, dt, nsteps);
+  if (a.hints & PM_JN_CONTRACTED)
+    hipLaunchKernelGGL((k_jn2018_fast<P, true>), dim3(grid), dim3(64 * JF_WAVES), lds, st, a, dt,
+                       nsteps);
+  else
+    hipLaunchKernelGGL((k_jn2018_fast<P, false>), dim3(grid), dim3(64 * JF_WAVES), lds, st, a, dt,
+                       nsteps);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }

@@ -22,7 +22,10 @@
 namespace pm {
 
 constexpr int TW_WAVES_PER_BLOCK = 4;
-constexpr int TW_JT = 2;  // isopycnal classes per lane per pass
+#ifndef TW_JT_N
+#define TW_JT_N 2
+#endif
+constexpr int TW_JT = TW_JT_N;  // isopycnal classes per lane per pass
 
 __device__ __forceinline__ double np_clip01(double v) {
   // np.clip(v, 0, 1) = minimum(maximum(v, 0), 1); both propagate NaN
@@ -81,7 +84,7 @@ struct PsibCell {
 // The psib row (nb doubles, read by Psibz) overlays the cells when the class passes' results
 // fit in registers (<= TW_HELD passes): they are written once the last pass has read the cells.
 // Only where it buys residency: nz > 128 (smaller grids keep 16 waves on a CU anyway).
-constexpr int TW_HELD = 4;
+constexpr int TW_HELD = 8 / TW_JT_N;  // (TW_JT_N = 1, 64-class passes: measured no faster)
 __host__ __device__ inline bool tw_overlay(int nz, int nb) {
   return nz > 128 && nb <= 64 * TW_JT * TW_HELD && nb <= TW_CELL * nz;
 }

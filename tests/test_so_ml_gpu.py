@@ -276,17 +276,21 @@ def test_config5_sweep_members_vs_reference(gpu, fused):
     assert relerr(st[k][idx], g["c5_long_" + k]) <= 1e-9, k
 
 
-def test_config5_full_length_sweep_vs_reference(gpu):
+@pytest.mark.parametrize("arith", ["exact", "contracted"])
+def test_config5_full_length_sweep_vs_reference(gpu, arith):
   """G17: BASELINE config 5 (4096 members, nz=200) over its configured 3600 steps, sampled
   every 72 steps against the 8 members run through the reference: 1e-10 up to each member's
   first Psib flip (measured; some members never flip), bounded after it (check_config5_full).
   The members the run loses are exactly the two the REFERENCE loses (2 and 1268, non-finite
-  from step 37 on; pinned in the fixture and in test_oracle_golden)."""
+  from step 37 on; pinned in the fixture and in test_oracle_golden).
+  arith="contracted": the columns of the fused loop in the opt-in tolerance mode
+  (PM_JN_CONTRACTED) are held to the SAME statement -- 1e-10 until a member's first flip (which
+  another rounding may bring earlier), the same bounds after it."""
   from test_oracle_golden import check_config5_full
   g = load_golden("sweep_full")
   c = configs.config5(N=4096)
   c["rest_mask"] = np.repeat(c["rest_mask"][None], 4096, axis=0)
-  ens = gpu.JN2018Ensemble(c)
+  ens = gpu.JN2018Ensemble(c, arith=arith)
   idx = g["c5_members"]
   steps = [int(t) for t in g["c5_steps"]]
   traj = [dict() for _ in idx]
@@ -298,8 +302,9 @@ def test_config5_full_length_sweep_vs_reference(gpu):
     for j, i in enumerate(idx):
       traj[j][t] = {k: st[k][i] for k in ("b_basin", "b_north", "bs_SO", "Psi_SO")}
   clean = [check_config5_full(traj[j], g, j) for j in range(len(idx))]
-  assert sum(t == 3600 for t in clean) >= 2, clean  # no drift where no Psib flip happens
-  assert np.median(clean) >= 1000, clean
+  print("config 5, %s: followed to 1e-10 until step" % arith, clean)
+  assert sum(t == 3600 for t in clean) >= (2 if arith == "exact" else 1), clean  # no drift where no Psib flip happens
+  assert np.median(clean) >= (1000 if arith == "exact" else 144), clean
   assert list(ens.nonfinite_members()) == list(g["c5_blowup_members"]) == [2, 1268]
   ens.run(72)  # the bench's 72 warm-up + 3600 steps
   assert list(ens.nonfinite_members()) == [2, 1268]
