@@ -274,19 +274,39 @@ __device__ __forceinline__ void jf_build_pcr(double *T, int ny, double s, int la
   T[(PCR_LEVELS + 1) * 128 + lane] = recip_lo(b, rb);
 }
 
-// x = U^-1 r by parallel cyclic reduction with the block's tables (ml_pcr_solve's recurrences)
+// r of the lane 32 away (lanes < 32: lane + 32, lanes >= 32: lane - 32) without an LDS round
+// trip: v_permlane32_swap (gfx950) exchanges the upper half of one register with the lower half
+// of another; swapping a copy of r with itself leaves {r.lo, r.lo} and {r.hi, r.hi}.
+__device__ __forceinline__ double jf_swap_halves(double r, bool low_half) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(r), __double2loint(r), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(r), __double2hiint(r), false, false);
+  // element 0 = {r.lo, r.lo} (per half), element 1 = {r.hi, r.hi}
+  return __hiloint2double(low_half ? hi[1] : hi[0], low_half ? lo[1] : lo[0]);
+}
+
+// x = U^-1 r by parallel cyclic reduction with the block's tables (ml_pcr_solve's recurrences).
+// A level needs r of the lanes k below and k above; a missing neighbour has a zero multiplier,
+// so any finite value may stand in for it.  k = 1 comes by DPP wave shifts and k = 32 by
+// v_permlane32_swap (no LDS round trip on the dependent chain); k = 2 ... 16 by ds_bpermute,
+// whose address is taken modulo 64 lanes (the constants fold into the offset field).
 __device__ __forceinline__ double jf_pcr_solve(double r, const double *T, int lane, int a4) {
 #pragma unroll
   for (int l = 0; l < PCR_LEVELS; ++l) {
     const int k = 1 << l;
-    // a missing neighbour has a zero multiplier, so the lane index may wrap (bpermute takes
-    // its address modulo 64 lanes; the constants fold into the instruction's offset field)
-    const int lo_i = a4 + (256 - 4 * k), hi_i = a4 + 4 * k;
     const double2 ag = *reinterpret_cast<const double2 *>(T + l * 128 + lane * 2);
-    const double r_lo = __hiloint2double(__builtin_amdgcn_ds_bpermute(lo_i, __double2hiint(r)),
-                                         __builtin_amdgcn_ds_bpermute(lo_i, __double2loint(r)));
-    const double r_hi = __hiloint2double(__builtin_amdgcn_ds_bpermute(hi_i, __double2hiint(r)),
-                                         __builtin_amdgcn_ds_bpermute(hi_i, __double2loint(r)));
+    double r_lo, r_hi;
+    if (k == 1) {
+      r_lo = from_prev_lane_z(r);
+      r_hi = from_next_lane_z(r);
+    } else if (k == 32) {
+      r_lo = r_hi = jf_swap_halves(r, lane < 32);
+    } else {
+      const int lo_i = a4 + (256 - 4 * k), hi_i = a4 + 4 * k;
+      r_lo = __hiloint2double(__builtin_amdgcn_ds_bpermute(lo_i, __double2hiint(r)),
+                              __builtin_amdgcn_ds_bpermute(lo_i, __double2loint(r)));
+      r_hi = __hiloint2double(__builtin_amdgcn_ds_bpermute(hi_i, __double2hiint(r)),
+                              __builtin_amdgcn_ds_bpermute(hi_i, __double2loint(r)));
+    }
     r = __builtin_fma(ag.y, r_hi, __builtin_fma(ag.x, r_lo, r));
     // (fence: a level's multipliers are read with its shuffles, not all 28 registers of them
     // before the first level)
