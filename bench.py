@@ -58,12 +58,16 @@ WORKLOAD = {
     2: "BASELINE configs[1]: ensemble of %d independent Columns nz=%d fp64 per GPU, static wA, "
        "do_conv on odd members, dt=30 d (pymoc_amd.configs.config2, seed 20240)",
     3: "BASELINE configs[2]: %d two-column + Psi_Thermwind members per GPU (example_twocol.py "
-       "physics, nz=%d, MOC_up_iters=24, nb=500; pymoc_amd.configs.config3, seed 20241)",
+       "physics, nz=%d, MOC_up_iters=24, nb=500; pymoc_amd.configs.config3, seed 20241; SURVEY 8d "
+       "parameter ranges NARROWED to where the reference itself stays finite: kappa_4k <= 2.5e-4, "
+       "fixture G18)",
     4: "BASELINE configs[3]: %d two-column + SO-channel members per GPU (example_twocol_plusSO.py"
        " physics, nz=%d, ny=40, c=0.1 GM boundary-value smoother; pymoc_amd.configs.config4, "
-       "seed 20242; GM boundary-value problem on scipy solve_bvp's adaptive mesh)",
+       "seed 20242; GM boundary-value problem on scipy solve_bvp's adaptive mesh; SURVEY 8d ranges "
+       "NARROWED to where the reference itself stays finite: A_basin >= 4.5e13, fixture G18)",
     5: "BASELINE configs[4]: %d run_JansenNadeau_2018.py members per GPU (nz=%d, dt=10 d, "
-       "ny=51, MOC_up_iters=36, nb=500; pymoc_amd.configs.config5, seed 20243)",
+       "ny=51, MOC_up_iters=36, nb=500; pymoc_amd.configs.config5, seed 20243; SURVEY 8d ranges "
+       "NARROWED to where the reference itself stays finite: db <= 8e-4, fixture G18)",
 }
 
 
