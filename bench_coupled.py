@@ -22,6 +22,9 @@ def main():
   ap.add_argument("--members", type=int, default=0, help="0 = the per-GPU size of SURVEY 8d")
   ap.add_argument("--steps", type=int, default=0)
   ap.add_argument("--no-graph", action="store_true")
+  ap.add_argument("--bvp-refine", type=int, default=0,
+                  help="config 4: 0 = solve_bvp's adaptive GM mesh (reference parity, as bench.py); "
+                       "R > 0 = fixed R-fold mesh")
   ap.add_argument("--unfused", action="store_true",
                   help="config 5: one launch per component and step instead of the fused loop")
   args = ap.parse_args()
@@ -37,7 +40,7 @@ def main():
       steps, warm, ncol = args.steps or 2400, 241, 2
     elif c == 4:
       n = args.members or 8192
-      cfg = dict(configs.config4(N=n), bvp_refine=8)
+      cfg = dict(configs.config4(N=n), bvp_refine=args.bvp_refine)
       ens = pymoc_amd.TwoColEnsemble(cfg)
       steps, warm, ncol = args.steps or 2400, 241, 2
     elif c == 6:  # two-basin topology, 3 columns per member

@@ -349,6 +349,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
   const int m = m_ok ? m_raw : a.n - 1;
   const int n = a.n, nz = a.cols.nz, ny = a.ml.ny;
   PM_WAVE_BEGIN
+  PM_TICK_INIT
   double *wl = lds + L::WAVE0 + wave * L::PER_WAVE;  // this wave's rows; wl[level] = basin b
   double *ws = wl + L::W_S;                           // this member's scalars
 
@@ -610,6 +611,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
     };
     if (ml_ok) {
     for (; s < nsteps; ++s) {
+      PM_TICK(6)
       // address bases the optimiser must not see through: it would hoist one derived address per
       // access pattern out of the loop (dozens of registers, then spilled) instead of folding
       // the constants into the instructions' offset fields
@@ -618,6 +620,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
       const int a4 = lane_o << 2;
       double *wl = lds + L::WAVE0 + woff, *ws = wl + L::W_S;
       if (__builtin_expect(!columns_step(lane_o, wl, ws), 0)) break;
+      PM_TICK(0)
       JF_RARE(0)
       // ---- channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi) (:261), ml_step_reg's operations
       {
@@ -670,6 +673,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
             }
           }
         }
+        PM_TICK(1)
         // argmin(bs): first minimum, a NaN wins (np.argmin); 0 when no point lies below point 0
         int amin = 0;
         {
@@ -692,6 +696,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
           ++s;
           break;  // the rest of the launch steps the columns only (loop below)
         } else {
+          PM_TICK(2)
           __builtin_amdgcn_sched_barrier(0);  // (fence: the constants below are read here, not earlier)
           const double2 *K2 = reinterpret_cast<const double2 *>(lds + L::KML);
           const double2 k0 = K2[0], k1 = K2[1], k2 = K2[2], k3 = K2[3], k4 = K2[4];
@@ -721,6 +726,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
           bs = bs + dt * (flux + adv);  // every tendency uses the old bs
           const double bu = from_next_lane_z(bs);
           if (!upwell) bs = lane0 ? bu : bs;  // no-flux BC re-set (:264-266)
+          PM_TICK(3)
           // Crank-Nicolson diffusion (:191-196): U x = V bs by parallel cyclic reduction
           {
             const double bl = from_prev_lane_z(bs);
@@ -738,6 +744,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
           q.bs = bs;
           wl[L::W_PS + lane_o] = ps;
           ps_valid = true;
+          PM_TICK(4)
         }
       }
     }
@@ -751,6 +758,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
     }
   }
 
+  PM_TICK_FLUSH
   // ---- results
   jf_kargs ka = jf_args();
   const size_t by = (size_t)m * ny;

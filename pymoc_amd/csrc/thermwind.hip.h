@@ -324,6 +324,17 @@ __device__ __forceinline__ void lane_blocked_scan(const double (&d)[P], double (
   for (int p = 0; p < P; ++p) pre[p] = (p == 0) ? e : e + run[p];
 }
 
+__device__ __forceinline__ void tw_pass_priority(int pass) {
+  if (pass <= 0)
+    __builtin_amdgcn_s_setprio(3);
+  else if (pass == 1)
+    __builtin_amdgcn_s_setprio(2);
+  else if (pass == 2)
+    __builtin_amdgcn_s_setprio(1);
+  else
+    __builtin_amdgcn_s_setprio(0);
+}
+
 // P <= 2 (nz <= 128): held to 128 registers, i.e. 4 waves per SIMD -- BASELINE's 4096-member
 // ensembles then run as ONE batch of resident waves.  (nz = 200 needs 135; capping it at 128
 // with 8 spilled registers, and laying the psib row over the cells so that 16 waves fit the
@@ -527,6 +538,10 @@ __attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermw
     }
   }
   for (int i0 = 0; i0 < (all_nan ? 0 : nb); i0 += 64 * TW_JT) {
+    // Issue priority falls with the pass: the SIMD's arbiter favours its oldest wave, so four
+    // members of equal cost finish 25 / 29 / 34 / 41 us after the launch and the last one runs
+    // alone; a wave that is a pass ahead yields to the ones behind and they finish together.
+    tw_pass_priority(i0 / (64 * TW_JT));
     double bg[TW_JT], res[TW_JT];
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) {
@@ -569,6 +584,7 @@ __attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermw
         for (int j = 0; j < TW_JT; ++j) held[q][j] = (q == ps) ? res[j] : held[q][j];
     }
   }
+  __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_wave_barrier();
   if (overlay && !all_nan) {  // the cells are dead: the psib row takes their place
 #pragma unroll
