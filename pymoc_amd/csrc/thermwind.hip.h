@@ -34,9 +34,12 @@ __device__ __forceinline__ double np_clip01(double v) {
   return v > 1. ? 1. : v;
 }
 
-// np.interp(x, bgrid, psib) for one query, bgrid = lin (ascending, uniform), psib in LDS
+// np.interp(x, bgrid, psib) for one query, bgrid = lin (ascending, uniform), psib in LDS.
+// The interval index starts from a guess, (x - start) * rstep with rstep ~ 1 / step, and is
+// then moved until bgrid[j] <= x < bgrid[j+1] holds with np.linspace's own node values, so the
+// guess only has to be close (a correctly rounded division here cost a sixth of Psibz).
 __device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
-                                                 const double *psib, int nb) {
+                                                 const double *psib, int nb, double rstep) {
   if (x != x) return x;
   const double lval = psib[0], rval = psib[nb - 1];
   if (nb == 1) return (x < lin.start) ? lval : ((x > lin.start) ? rval : psib[0]);
@@ -44,12 +47,25 @@ __device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
   if (x < lin.start) return lval;
   // largest j with bgrid[j] <= x
   int j;
+  double xj, xj1;
   if (lin.step > 0. && lin.step < 1e300) {
-    double q = (x - lin.start) / lin.step;
+    // (nb > 1 and step != 0 here: Linspace::at without its special cases)
+    auto at = [&](int i) { return i == nb - 1 ? lin.stop : (double)i * lin.step + lin.start; };
+    const double q = (x - lin.start) * rstep;
     j = (int)q;
     j = j < 0 ? 0 : (j > nb - 1 ? nb - 1 : j);
-    while (j > 0 && x < lin.at(j)) --j;
-    while (j < nb - 1 && x >= lin.at(j + 1)) ++j;
+    xj = at(j);
+    xj1 = at(j + 1 < nb ? j + 1 : nb - 1);
+    while (j > 0 && x < xj) {
+      --j;
+      xj1 = xj;
+      xj = at(j);
+    }
+    while (j < nb - 1 && x >= xj1) {
+      ++j;
+      xj = xj1;
+      xj1 = at(j + 1 < nb ? j + 1 : nb - 1);
+    }
   } else {
     int lo = 0, hi = nb;  // upper bound
     while (lo < hi) {
@@ -61,15 +77,16 @@ __device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
     }
     j = lo - 1;
     if (j < 0) return lval;
+    xj = lin.at(j);
+    xj1 = lin.at(j + 1 < nb ? j + 1 : nb - 1);
   }
   if (j == nb - 1) return psib[j];
-  const double xj = lin.at(j);
   if (xj == x) return psib[j];
   const double fj = psib[j], fj1 = psib[j + 1];
-  const double slope = (fj1 - fj) / (lin.at(j + 1) - xj);
+  const double slope = (fj1 - fj) / (xj1 - xj);
   double r = slope * (x - xj) + fj;
   if (r != r) {  // numpy: nan in one direction, try the other
-    r = slope * (x - lin.at(j + 1)) + fj1;
+    r = slope * (x - xj1) + fj1;
     if (r != r && fj == fj1) r = fj;
   }
   return r;
@@ -324,6 +341,33 @@ __device__ __forceinline__ void lane_blocked_scan(const double (&d)[P], double (
   for (int p = 0; p < P; ++p) pre[p] = (p == 0) ? e : e + run[p];
 }
 
+// Minimum / maximum over the wave by DPP moves (quad swaps, half-row and row mirrors) and four
+// v_readlane -- the shuffles of group_min / group_max are twelve dependent LDS round trips, 5 %
+// of a member's update.  v_min_f64 / v_max_f64: NaNs lose (the callers test for NaN apart).
+template <int CTRL>
+__device__ __forceinline__ double tw_dpp(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double tw_lane(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                          __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+template <bool MAX>
+__device__ __forceinline__ double tw_pick(double a, double b) {
+  return MAX ? __builtin_fmax(a, b) : __builtin_fmin(a, b);
+}
+template <bool MAX>
+__device__ __forceinline__ double tw_wave_reduce(double x) {
+  x = tw_pick<MAX>(x, tw_dpp<0xB1>(x));   // quad_perm [1,0,3,2]
+  x = tw_pick<MAX>(x, tw_dpp<0x4E>(x));   // quad_perm [2,3,0,1]
+  x = tw_pick<MAX>(x, tw_dpp<0x141>(x));  // row_half_mirror
+  x = tw_pick<MAX>(x, tw_dpp<0x140>(x));  // row_mirror: every lane holds its row's result
+  return tw_pick<MAX>(tw_pick<MAX>(tw_lane(x, 0), tw_lane(x, 16)),
+                      tw_pick<MAX>(tw_lane(x, 32), tw_lane(x, 48)));
+}
+
 __device__ __forceinline__ void tw_pass_priority(int pass) {
   if (pass <= 0)
     __builtin_amdgcn_s_setprio(3);
@@ -462,8 +506,8 @@ __attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermw
     }
   }
   // lanes past the last level hold copies of b[nz-1]: harmless for min/max
-  mn = group_min<64>(mn);
-  mx = group_max<64>(mx);
+  mn = tw_wave_reduce<false>(mn);
+  mx = tw_wave_reduce<true>(mx);
   if (__ballot(has_nan) != 0ull) mn = mx = __builtin_nan("");
   Linspace lin;
   lin.init(mn, mx, nb);
@@ -471,6 +515,9 @@ __attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermw
   PM_TICK(6)
   const bool range_ok = __builtin_fabs(mn) < 1e100 && __builtin_fabs(mx) < 1e100;
   const double Psi_up0 = from_next_lane(Psi[0]);
+  // min(bot) / max(top) of this lane's cells for the group ranges; (-inf, +inf) = "holds a cell
+  // that bars its group from the shortcuts"
+  double lane_gb = __builtin_inf(), lane_gt = -__builtin_inf();
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int k = lane * P + p;
@@ -492,12 +539,39 @@ __attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermw
       // NaN in the reference's `mask * udydz` (psi_thermwind.py:183-184), so such a cell bars
       // its group from both shortcuts like a degenerate cell does
       const bool ufin = __builtin_fabs(u) <= 1.7976931348623157e308;
-      cell[2] = double2{u, (regular && d > 0. && ufin) ? bot : -__builtin_inf()};
+      const bool plain = regular && d > 0. && ufin;
+      cell[2] = double2{u, plain ? bot : -__builtin_inf()};
+      lane_gb = plain ? __builtin_fmin(lane_gb, bot) : -__builtin_inf();
+      lane_gt = (plain && lane_gt != __builtin_inf()) ? __builtin_fmax(lane_gt, top) : __builtin_inf();
     }
   }
   __builtin_amdgcn_wave_barrier();
   PM_TICK(7)
   const int nc = nz - 1;
+  if constexpr (P == 1 || P == 2 || P == 4 || P == 8) {
+    // a group of 8 cells is 8 / P neighbouring lanes: reduce there (the loop below walks its
+    // 16 LDS reads per group one after the other: 5 % of a member's update)
+    double gb = lane_gb, gt = lane_gt;
+    if constexpr (P <= 4) {
+      gb = __builtin_fmin(gb, tw_dpp<0xB1>(gb));  // lanes 2i, 2i+1
+      gt = __builtin_fmax(gt, tw_dpp<0xB1>(gt));
+    }
+    if constexpr (P <= 2) {
+      gb = __builtin_fmin(gb, tw_dpp<0x4E>(gb));  // the quad
+      gt = __builtin_fmax(gt, tw_dpp<0x4E>(gt));
+    }
+    if constexpr (P == 1) {
+      gb = __builtin_fmin(gb, tw_dpp<0x141>(gb));  // row_half_mirror: the other quad of the eight
+      gt = __builtin_fmax(gt, tw_dpp<0x141>(gt));
+    }
+    constexpr int LPG = 8 / P;  // lanes per group
+    const int g = lane / LPG;
+    if (lane % LPG == 0 && g < ngrp) {
+      const bool ok = nb >= nz;
+      s_gbot[g] = ok ? gb : -__builtin_inf();
+      s_gtop[g] = ok ? gt : __builtin_inf();
+    }
+  } else
   for (int g = lane; g < ngrp; g += 64) {
     double gb = __builtin_inf(), gt = -__builtin_inf();
     bool ok = nb >= nz;
@@ -603,12 +677,13 @@ __attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermw
     return;
   }
   // ---- Psibz (psi_thermwind.py:203-208) and the drivers' wA coupling
+  const double rstep = 1.0 / lin.step;  // (only a starting guess is taken from it)
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int i = lane * P + p;
     if (i < nz && m_ok) {
-      const double p1 = interp_uniform(b1[p], lin, s_psib, nb);
-      const double p2 = interp_uniform(b2[p], lin, s_psib, nb);
+      const double p1 = interp_uniform(b1[p], lin, s_psib, nb, rstep);
+      const double p2 = interp_uniform(b2[p], lin, s_psib, nb, rstep);
       if (a.psibz1) a.psibz1[base + i] = p1;
       if (a.psibz2) a.psibz2[base + i] = p2;
       if (a.wA1) {  // (Psi_iso_b - SO.Psi) * 1e6   (example_twocol_plusSO.py:105)
