@@ -327,6 +327,15 @@ int pm_jn2018_bc_switch(const pm_jn2018_bc *bc, pm_stream_t stream);
                                 step in the contracted form of PM_OP_CONTRACTED (agreement with
                                 the reference to rounding, not bit for bit; the mixed layer and
                                 the bottom-BC switch keep the reference's operation order)     */
+#define PM_JN_SHARED_COEF 4  /* hint of the uniform-Area kernel: the kappa / dAkappa / Area rows of
+                                every basin column equal basin column 0's and those of every
+                                northern column equal northern column 0's (a parameter sweep
+                                over forcing and boundary values, as run_JansenNadeau_2018.py's
+                                parameters are: one kappa(z) for all members).  The kernel then
+                                reads only rows 0 and n -- they stay in L2 -- instead of six rows
+                                per member from HBM.  The CALLER vouches for it (verifying it on
+                                the device would read the rows it is meant to save); the Python
+                                driver compares the host arrays.                                */
 typedef struct pm_jn2018 {
   int32_t n, hints, reserved1, reserved2;
   pm_columns cols;

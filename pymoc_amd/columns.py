@@ -100,6 +100,12 @@ class ColumnBatch(object):
     # every column's Area is constant in z (all reference scripts): lets the fused JN2018
     # kernel keep it in scalar registers (pm_jn2018.hints)
     self.uniform_area = bool(np.all(area == area[:, :1]))
+    # rows [0, n/2) and [n/2, n) of a two-column ensemble each repeat one coefficient profile
+    # (a sweep over forcing / boundary values only): PM_JN_SHARED_COEF of the fused JN2018 kernel
+    h = ncols // 2
+    self.shared_halves = bool(ncols % 2 == 0 and h >= 1 and all(
+        np.array_equal(a[:h], np.broadcast_to(a[0], (h, nz))) and
+        np.array_equal(a[h:], np.broadcast_to(a[h], (h, nz))) for a in [area] + ks))
     self.kappa.upload(np.stack(ks), self.stream)
     dAks = [dAkappa_dz(area, k, self.z_host) for k in ks]
     self.dAk.upload(np.stack(dAks), self.stream)

@@ -402,17 +402,20 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
   JfConv<P> vb, vn;
   int ksel_b, ksel_n;
   bool hint_ok = true, range_ok = in_fast_div_range(dt);
+  const bool shared = (a.hints & PM_JN_SHARED_COEF) != 0;
   {
     const pm_columns &c = a.cols;
     auto load_col = [&](JfCol<P> &r, JfConv<P> &v, int col, double *wsc) {
       bool same = true;
-      const double a0 = c.area[(size_t)col * nz];
+      // (PM_JN_SHARED_COEF: the column kind's one coefficient row, resident in L2)
+      const size_t arow = (size_t)(shared ? (col < n ? 0 : n) : col) * nz;
+      const double a0 = c.area[arow];
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int i = lane * P + p;
         const int ic = i < nz ? i : nz - 1;
         r.b[p] = i < nz ? c.b[(size_t)col * nz + ic] : JF_PAD;
-        same = same && c.area[(size_t)col * nz + ic] == a0;
+        same = same && c.area[arow + ic] == a0;
       }
       hint_ok = hint_ok && __ballot(!same) == 0ull;
       {  // operands inside the exact-division window? (common.hip.h; flagged, not branched on)
@@ -512,7 +515,8 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
       bool coef_ok = true;
       auto load_coef = [&](JfCol<P> &r, double *kap, int col, int sel) {
         const double *kappa = ka->cols.kappa, *dAk = ka->cols.dAkappa, *wA = ka->wA;
-        const size_t sbase = ((size_t)sel * (2 * n) + col) * nz;
+        const bool shared_rows = (ka->hints & PM_JN_SHARED_COEF) != 0;
+        const size_t sbase = ((size_t)sel * (2 * n) + (shared_rows ? (col < n ? 0 : n) : col)) * nz;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           const int i = lane * P + p;
@@ -532,7 +536,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
             const double dz_up = lds[L::T_DZ + jf_entry<P>(iq / P, iq % P)],
                          dz_dn = lds[L::T_DZ + jf_entry<P>((iq - 1) / P, (iq - 1) % P)],
                          dzc = lds[L::T_DZC + jf_entry<P>(iq / P, iq % P)];
-            const double area = ka->cols.area[(size_t)col * nz];
+            const double area = ka->cols.area[(size_t)(shared_rows ? (col < n ? 0 : n) : col) * nz];
             const double cu = dt * (r.kap[p] / (dzc * dz_up) + r.wn[p] / (area * dz_up));
             const double cl = dt * (-r.kap[p] / (dzc * dz_dn) + r.wp[p] / (area * dz_dn));
             r.wn[p] = interior ? cu : 0.0;

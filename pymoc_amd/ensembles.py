@@ -250,15 +250,20 @@ class JN2018Ensemble(object):
   `use_graph` a whole MOC block is captured once into a hipGraph and replayed."""
 
   def __init__(self, cfg, stream=None, lanes_per_col=0, use_graph=False, fused=None,
-               comm=None, n_total=None, diag_iters=None, keep_history=False, arith="exact"):
+               comm=None, n_total=None, diag_iters=None, keep_history=False, arith="exact",
+               shared_coef=True):
     """`comm`, `n_total`, `diag_iters`: as for TwoColEnsemble; the gather happens where the
     script samples its diagnostics (`if ii % Diag_iters == 0`, right after the MOC update,
     run_JansenNadeau_2018.py:218-226; default Diag_iters = 10 MOC_up_iters, :99).
     `arith="contracted"`: the columns of the fused loop step in the opt-in tolerance mode
-    (PM_JN_CONTRACTED; uniform-Area ensembles with ny <= 64 -- others stay exact)."""
+    (PM_JN_CONTRACTED; uniform-Area ensembles with ny <= 64 -- others stay exact).
+    `shared_coef`: let the fused loop read ONE copy of kappa / d(A kappa)/dz / Area per column
+    kind when all members' profiles are identical (checked here on the host arrays;
+    PM_JN_SHARED_COEF); results are bit-identical either way."""
     if arith not in ("exact", "contracted"):
       raise ValueError("arith must be 'exact' or 'contracted'")
     self.arith = arith
+    self.shared_coef = bool(shared_coef)
     import ctypes as C
     from ._lib import pm_jn2018_bc
     z, y = cfg['z'], cfg['y']
@@ -349,6 +354,8 @@ class JN2018Ensemble(object):
     d.hints = _lib.PM_JN_UNIFORM_AREA if self.cols.uniform_area else 0
     if self.arith == "contracted":
       d.hints |= _lib.PM_JN_CONTRACTED
+    if self.shared_coef and self.cols.uniform_area and self.cols.shared_halves:
+      d.hints |= _lib.PM_JN_SHARED_COEF
     d.cols = self.cols.descriptor()
     d.wA, d.Psi_SO = self.wA.ptr, self.so.Psi.ptr
     d.Psi_res_b, d.Psi_res_n = self.tw.psibz1.ptr, self.tw.psibz2.ptr

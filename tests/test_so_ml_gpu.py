@@ -226,6 +226,43 @@ def test_jn2018_fused_equals_stepwise_other_shapes(gpu, nz, ny):
     assert np.array_equal(sa[k][ok], sb[k][ok]), (nz, ny, k)
 
 
+@pytest.mark.parametrize("arith", ["exact", "contracted"])
+def test_jn2018_fused_shared_coefficient_rows(gpu, arith):
+  """PM_JN_SHARED_COEF: when every member carries the same kappa / Area profiles the fused loop
+  reads one copy per column kind (rows 0 and n) -- bit-identical to reading each member's own
+  rows; a sweep whose members differ in kappa must not get the hint and equals the stepwise
+  launches as before."""
+  c = configs.config5(N=128)
+  c["rest_mask"] = np.repeat(c["rest_mask"][None], 128, axis=0)
+  a = gpu.JN2018Ensemble(c, arith=arith)                     # hint set by the driver
+  b = gpu.JN2018Ensemble(c, arith=arith, shared_coef=False)  # every member's own rows
+  assert a.cols.shared_halves and a.cols.uniform_area
+  for n in (1, 36, 72):
+    a.run(n)
+    b.run(n)
+    sa, sb = a.state(), b.state()
+    assert np.array_equal(a.nonfinite_members(), b.nonfinite_members())
+    for k in sa:
+      assert np.array_equal(sa[k], sb[k], equal_nan=True), (n, k)
+  # members with their own kappa: no hint, fused == stepwise
+  rng = np.random.default_rng(5)
+  c2 = dict(c)
+  f = 1.0 + 0.05 * rng.random(128)
+  c2["kappa"] = np.asarray(c["kappa"])[None, :] * f[:, None]
+  c2["kappaeff"] = np.asarray(c["kappaeff"])[None, :] * f[:, None]
+  d = gpu.JN2018Ensemble(c2, fused=True)
+  e = gpu.JN2018Ensemble(c2, fused=False)
+  assert not d.cols.shared_halves
+  d.run(80)
+  e.run(80)
+  sd, se = d.state(), e.state()
+  ok = np.ones(128, dtype=bool)
+  ok[e.nonfinite_members()] = False
+  assert np.array_equal(d.nonfinite_members(), e.nonfinite_members()) and ok.sum() >= 120
+  for k in sd:
+    assert np.array_equal(sd[k][ok], se[k][ok]), k
+
+
 def test_jn2018_fused_area_variants_and_hint_check(gpu):
   """The fused kernel has a uniform-Area variant (pm_jn2018.hints); with a basin area that
   varies in z the driver must pick the general variant (still bit-identical to the stepwise
