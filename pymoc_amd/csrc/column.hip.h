@@ -492,14 +492,35 @@ __device__ __forceinline__ void col_load_grid(ColGrid<P> &g, const pm_columns &c
 }
 
 // static coefficients of one column (coefficient set `sel`) into registers
+// `uniform_area` (wave-uniform; the column's PM_COL_UNIFORM_AREA hint): Area(z) is one number --
+// one broadcast load and one reciprocal instead of a row from HBM and a division per level;
+// `weff_in` (PM_OP_WEFF): the forcing already holds wA - d(A kappa)/dz, so that row is not read.
 template <int P, int DIV = 1>
 __device__ __forceinline__ void col_load_static(ColRegs<P> &r, const pm_columns &c,
-                                                int col, int sel, int lg, int lvl0 = 0) {
+                                                int col, int sel, int lg, int lvl0 = 0,
+                                                bool uniform_area = false, bool weff_in = false) {
   const int nz = c.nz;
   const size_t base = (size_t)col * nz;
   const size_t sbase = ((size_t)sel * c.ncols + col) * nz;
   load_levels<P>(r.kap, c.kappa + sbase, lg, nz, lvl0);
-  load_levels<P>(r.dAk, c.dAkappa + sbase, lg, nz, lvl0);
+  if (!weff_in) {
+    load_levels<P>(r.dAk, c.dAkappa + sbase, lg, nz, lvl0);
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.dAk[p] = 0.0;  // weff - 0 = weff, exactly
+  }
+  if (uniform_area) {
+    const double a0 = c.area[base];
+    const double ra = (DIV != 0 && DIV != 4) ? 1.0 / a0 : 0.0;
+    const double ral = DIV == 2 ? recip_lo(a0, ra) : 0.0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      r.area[p] = a0;
+      r.rarea[p] = ra;
+      r.rarea_l[p] = ral;
+    }
+    return;
+  }
   load_levels<P>(r.area, c.area + base, lg, nz, lvl0);
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -746,12 +767,11 @@ __global__ __launch_bounds__(256) void k_column_steps(
   ColGrid<P> g;
   ColRegs<P> r;
   const int sel = c.ksel ? c.ksel[col] : 0;
+  const int flags = c.flags ? c.flags[col] : 0;
   col_load_grid<P, FAST>(g, c, lg);
-  col_load_static<P, FAST>(r, c, col, sel, lg);
-  if (ops & PM_OP_WEFF) {  // wA_g holds weff = wA - d(A kappa)/dz: weff - 0 = weff, exactly
-#pragma unroll
-    for (int p = 0; p < P; ++p) r.dAk[p] = 0.0;
-  }
+  // (a wave holds one column when G == 64: the hint is then wave-uniform)
+  const bool ua = G == 64 && __builtin_amdgcn_readfirstlane(flags & PM_COL_UNIFORM_AREA) != 0;
+  col_load_static<P, FAST>(r, c, col, sel, lg, 0, ua, (ops & PM_OP_WEFF) != 0);
 
   double wA[P], vdx[P], bin[P];
   load_levels<P>(r.b, c.b + base, lg, nz);
@@ -760,7 +780,6 @@ __global__ __launch_bounds__(256) void k_column_steps(
   if (wA_g) load_levels<P>(wA, wA_g + base, lg, nz);
   if (vdx_g) load_levels<P>(vdx, vdx_g + base, lg, nz);
   if (bin_g) load_levels<P>(bin, bin_g + base, lg, nz);
-  const int flags = c.flags ? c.flags[col] : 0;
   const bool do_conv = (flags & PM_COL_DO_CONV) != 0;
   const bool use_bzbot = (flags & PM_COL_BZBOT) != 0 && c.bzbot != nullptr;
   const double bs = c.bs[col];
