@@ -54,11 +54,11 @@ class Stream(object):
 class ColumnBatch(object):
   def __init__(self, z, kappa, area, b, **kw):
     self.b = DeviceArray.from_host(b); self.n = self.b.shape[0]
-  def steps(self, wA, dt, n, lanes_per_col=0): pass
+  def steps(self, wA, dt, n, lanes_per_col=0, **kw): pass
   def get_nonfinite(self): return np.zeros(self.n, dtype=np.int32)
   def get_b(self): return self.b.a.copy()
   def kernel_shape(self, lanes): return 64, 2
-  def kernel_name(self, F, lanes): return "stub"
+  def kernel_name(self, F, lanes, **kw): return "stub"
 
 class Diag(object):
   def __init__(self, comm, n): self.comm, self.ngathers, self.bytes_per_rank, self.n = comm, 0, 8 * n, n
