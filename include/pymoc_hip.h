@@ -92,7 +92,7 @@ int pm_graph_destroy(pm_graph_t graph);
                               With the hint the one-step streaming kernel tests only what
                               changes from launch to launch (b, wA); without it, everything.   */
 #define PM_COL_UNIFORM_AREA 8 /* per-column HINT: Area(z) is constant in z (every reference script);
-                              the one-step streaming kernel then reads area[col][0] only.  Not
+                              the column kernels (G = 64) then read area[col][0] only.  Not
                               verified (that would be the read it saves): a wrong hint gives the
                               result for Area = area[col][0].                                   */
 
