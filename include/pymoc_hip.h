@@ -64,6 +64,10 @@ int pm_event_create(pm_event_t *event);
 int pm_event_destroy(pm_event_t event);
 int pm_event_record(pm_event_t event, pm_stream_t stream);
 int pm_event_sync(pm_event_t event);
+/* work submitted to `stream` after this call waits for `event` (hipStreamWaitEvent): lets two
+ * independent launches -- Psi_SO.solve and Psi_Thermwind of one overturning update -- run side
+ * by side on two streams and join before the columns step                                    */
+int pm_stream_wait_event(pm_stream_t stream, pm_event_t event);
 int pm_event_elapsed_ms(pm_event_t start, pm_event_t stop, float *ms);
 
 /* hipGraph capture of a launch sequence issued on `stream` */
@@ -105,6 +109,14 @@ int pm_graph_destroy(pm_graph_t graph);
                                 needs of the two (column.py:241); d(A kappa)/dz is then not read.
                                 wA is static between two overturning updates in every reference
                                 driver, so weff is too.                                          */
+#define PM_OP_WA_PSI 32      /* modifier for two-column ensembles (rows [0, ncols/2) basin, [ncols/2,
+                                ncols) north): the `wA` argument holds the isopycnal overturning
+                                Psi_iso [ncols][nz] in Sv and `b_in` (horadv's slot, no horadv with
+                                this modifier) Psi_SO [ncols/2][nz] or NULL; the kernel forms the
+                                drivers' forcing itself, wA_basin = (Psi_iso - Psi_SO) * 1e6,
+                                wA_north = -Psi_iso * 1e6 (example_twocol_plusSO.py:105-106) --
+                                what pm_thermwind_update's wA1 / wA2 outputs hold, without the
+                                thermal wind having to wait for Psi_SO.  Launches of >= 3 steps. */
 #define PM_OP_CONTRACTED 16  /* modifier, OPT-IN tolerance mode: launches of >= 3 plain timesteps
                                 (one wave per column, nz <= 256) use the contracted update
                                 b_i += cu_i (b_{i+1}-b_i) + cl_i (b_i-b_{i-1}) with per-launch
@@ -347,6 +359,12 @@ typedef struct pm_jn2018 {
 } pm_jn2018;
 
 int pm_jn2018_steps(const pm_jn2018 *jn, double dt, int32_t nsteps, pm_stream_t stream);
+
+/* Column forcing of the two-column drivers as an array (what PM_OP_WA_PSI forms inside the
+ * column kernel; for launches of fewer than 3 steps): wA[0:n] = (Psi_iso[0:n] - Psi_SO) * 1e6
+ * (Psi_SO may be NULL), wA[n:2n] = -Psi_iso[n:2n] * 1e6; Psi_iso, wA [2n][nz], Psi_SO [n][nz]. */
+int pm_twocol_forcing(int32_t n, int32_t nz, const double *Psi_iso, const double *Psi_SO,
+                      double *wA, pm_stream_t stream);
 
 /* Column forcing of the two-basin driver, examples/twobasin_NadeauJansen.py:103-105:
  *   wA_Atl = (Psi_iso_Atl + Psi_zonal_Atl - SO_Atl.Psi)*1e6

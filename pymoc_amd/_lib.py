@@ -21,6 +21,7 @@ PM_COL_DO_CONV, PM_COL_BZBOT, PM_COL_STATIC_IN_RANGE, PM_COL_UNIFORM_AREA = 1, 2
 PM_EQ_HFREE, PM_EQ_HAS_BBOT, PM_EQ_KAPPA_ARRAY, PM_EQ_PSI_ARRAY = 1, 2, 4, 8
 PM_OP_CONVECT, PM_OP_VERTADVDIFF, PM_OP_HORADV, PM_OP_TIMESTEP, PM_OP_WEFF = 1, 2, 4, 7, 8
 PM_OP_CONTRACTED = 16
+PM_OP_WA_PSI = 32
 
 c_dp = C.c_void_p  # device pointers travel as plain addresses
 
@@ -158,6 +159,9 @@ SIGNATURES = {
     "pm_event_destroy": (C.c_int, [C.c_void_p]),
     "pm_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pm_event_sync": (C.c_int, [C.c_void_p]),
+    "pm_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pm_twocol_forcing": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     "pm_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "pm_graph_begin_capture": (C.c_int, [C.c_void_p]),
     "pm_graph_end_capture": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

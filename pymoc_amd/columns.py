@@ -226,9 +226,12 @@ class ColumnBatch(object):
     return out
 
   def steps(self, wA, dt, nsteps=1, ops=_lib.PM_OP_TIMESTEP, vdx_in=None, b_in=None,
-            lanes_per_col=0, precombined=False, arith="exact"):
+            lanes_per_col=0, precombined=False, arith="exact", psi_forcing=None):
     """nsteps x (convect -> vertadvdiff -> horadv) with wA held fixed, one launch.
     precombined: `wA` is the output of `combine_forcing` (PM_OP_WEFF).
+    psi_forcing=(Psi_iso [ncols, nz], Psi_SO [ncols/2, nz] or None) instead of `wA` (two-column
+    ensembles, launches of >= 3 steps): the kernel forms wA_basin = (Psi_iso - Psi_SO) * 1e6 and
+    wA_north = -Psi_iso * 1e6 itself (PM_OP_WA_PSI, example_twocol_plusSO.py:105-106).
     arith: "exact" (default: the reference's operation order, bit-identical to NumPy) or
     "contracted" (opt-in tolerance mode, PM_OP_CONTRACTED: ~1e-13 relative, ~3x faster)."""
     if precombined:
@@ -239,6 +242,15 @@ class ColumnBatch(object):
       raise ValueError("arith must be 'exact' or 'contracted'")
     if vdx_in is not None and b_in is None:
       raise TypeError('b_in is needed if vdx_in is provided')  # column.py:348
+    if psi_forcing is not None:
+      if vdx_in is not None or precombined or wA is not None:
+        raise ValueError("psi_forcing replaces wA and excludes horadv / precombined forcing")
+      psi_iso, psi_so = psi_forcing
+      d = self.descriptor()
+      check(lib.pm_column_steps(C.byref(d), psi_iso.ptr, None, psi_so.ptr if psi_so is not None else None,
+                                float(dt), int(nsteps), int(ops | _lib.PM_OP_WA_PSI),
+                                int(lanes_per_col), _sh(self.stream)))
+      return
     wA_d = self._dev(wA, "_wA")
     vdx_d = self._dev(vdx_in, "_vdx")
     bin_d = self._dev(b_in, "_bin") if vdx_in is not None else None

@@ -778,8 +778,30 @@ __global__ __launch_bounds__(256) void k_column_steps(
 #pragma unroll
   for (int p = 0; p < P; ++p) wA[p] = vdx[p] = bin[p] = 0.0;
   if (wA_g) load_levels<P>(wA, wA_g + base, lg, nz);
+  if constexpr (PLAIN) {
+    if (ops & PM_OP_WA_PSI) {
+      // the two-column drivers' forcing from the overturning itself (example_twocol_plusSO.py:
+      // 105-106; pm_thermwind_update's wA1 / wA2 epilogue, same operations): basin rows
+      // (Psi_iso - Psi_SO) * 1e6, northern rows -Psi_iso * 1e6
+      const int half = c.ncols >> 1;
+      if (col < half) {
+        if (bin_g) {
+          double pso[P];
+          load_levels<P>(pso, bin_g + base, lg, nz);
+#pragma unroll
+          for (int p = 0; p < P; ++p) wA[p] = (wA[p] - pso[p]) * 1e6;
+        } else {
+#pragma unroll
+          for (int p = 0; p < P; ++p) wA[p] = wA[p] * 1e6;
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < P; ++p) wA[p] = (-wA[p]) * 1e6;
+      }
+    }
+  }
   if (vdx_g) load_levels<P>(vdx, vdx_g + base, lg, nz);
-  if (bin_g) load_levels<P>(bin, bin_g + base, lg, nz);
+  if (bin_g && !(ops & PM_OP_WA_PSI)) load_levels<P>(bin, bin_g + base, lg, nz);  // (WA_PSI: Psi_SO, read above)
   const bool do_conv = (flags & PM_COL_DO_CONV) != 0;
   const bool use_bzbot = (flags & PM_COL_BZBOT) != 0 && c.bzbot != nullptr;
   const double bs = c.bs[col];
@@ -1085,7 +1107,8 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
   const unsigned grid = (unsigned)((c.ncols + cols_per_block - 1) / cols_per_block);
   const bool weff_in = (ops & PM_OP_WEFF) != 0;  // wA holds wA - d(A kappa)/dz
   const bool contracted = (ops & PM_OP_CONTRACTED) != 0;  // tolerance mode (one wave per column)
-  ops &= ~(PM_OP_WEFF | PM_OP_CONTRACTED);
+  const int wa_psi = ops & PM_OP_WA_PSI;  // the kernel forms wA from Psi_iso / Psi_SO (>= 3 steps)
+  ops &= ~(PM_OP_WEFF | PM_OP_CONTRACTED | PM_OP_WA_PSI);
   if constexpr (G == 64 && P <= 4) {
     const int cpw = stream_cols_per_wave(c.ncols);
     if (nsteps < 3 && ops == PM_OP_TIMESTEP && !vdx && cpw >= 2) {
@@ -1108,7 +1131,7 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
   if constexpr (G == 64 && P <= 4) {
     if (contracted && nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx) {
       hipLaunchKernelGGL((k_column_steps<G, P, 4, true>), dim3(grid), dim3(256), 0, st, c, wA, vdx,
-                         bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0));
+                         bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
       PM_HIP(hipGetLastError());
       return PM_OK;
     }
@@ -1116,7 +1139,7 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
   // the reciprocal path pays 3 true divisions per level up front: worth it from 3 steps on
   if (nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx)
     hipLaunchKernelGGL((k_column_steps<G, P, 2, true>), dim3(grid), dim3(256), 0, st, c, wA,
-                       vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0));
+                       vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
   else if (nsteps >= 3)
     hipLaunchKernelGGL((k_column_steps<G, P, 1, false>), dim3(grid), dim3(256), 0, st, c, wA,
                        vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0));

@@ -225,6 +225,31 @@ int pm_event_record(pm_event_t event, pm_stream_t stream) {
   PM_HIP(hipEventRecord((hipEvent_t)event, resolve_stream(stream)));
   return PM_OK;
 }
+namespace pm {
+__global__ void k_twocol_forcing(size_t half, const double *__restrict__ psi_iso,
+                                 const double *__restrict__ psi_so, double *__restrict__ wA) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= 2 * half) return;
+  const double p = psi_iso[i];
+  // (the operations of k_thermwind's wA1 / wA2 epilogue and of PM_OP_WA_PSI)
+  wA[i] = i < half ? (psi_so ? (p - psi_so[i]) : p) * 1e6 : (-p) * 1e6;
+}
+}  // namespace pm
+int pm_twocol_forcing(int32_t n, int32_t nz, const double *Psi_iso, const double *Psi_SO,
+                      double *wA, pm_stream_t stream) {
+  PM_REQUIRE(n >= 0 && nz >= 1, "bad shape n=%d nz=%d", n, nz);
+  if (n == 0) return PM_OK;
+  PM_REQUIRE(Psi_iso && wA, "NULL pointer");
+  const size_t half = (size_t)n * nz;
+  hipLaunchKernelGGL(pm::k_twocol_forcing, dim3((unsigned)((2 * half + 255) / 256)), dim3(256), 0,
+                     resolve_stream(stream), half, Psi_iso, Psi_SO, wA);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+int pm_stream_wait_event(pm_stream_t stream, pm_event_t event) {
+  PM_HIP(hipStreamWaitEvent(resolve_stream(stream), (hipEvent_t)event, 0));
+  return PM_OK;
+}
 int pm_event_sync(pm_event_t event) {
   PM_HIP(hipEventSynchronize((hipEvent_t)event));
   return PM_OK;
@@ -294,7 +319,8 @@ int pm_column_kernel_name(int32_t ncols, int32_t nz, int32_t lanes_per_col, int3
   int G = 0, P = 0;
   const int rc = column_shape(ncols, nz, lanes_per_col, &G, &P);
   if (rc != PM_OK) return rc;
-  const bool plain = (ops & ~(PM_OP_WEFF | PM_OP_CONTRACTED)) == PM_OP_TIMESTEP && !has_horadv;
+  const bool plain =
+      (ops & ~(PM_OP_WEFF | PM_OP_CONTRACTED | PM_OP_WA_PSI)) == PM_OP_TIMESTEP && !has_horadv;
   if (G == 64 && P <= 4 && nsteps < 3 && plain && stream_cols_per_wave(ncols) >= 2)
     snprintf(name, name_len, "k_column_stream<%d>", P);
   else if (G == 64 && P <= 4 && nsteps >= 3 && plain && (ops & PM_OP_CONTRACTED))
@@ -317,10 +343,18 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
   PM_REQUIRE(c.z && c.b && c.kappa && c.area && c.dAkappa && c.bs && c.bbot && c.N2min,
              "pm_columns has a NULL required pointer");
   PM_REQUIRE(nsteps >= 0, "nsteps < 0");
-  PM_REQUIRE((ops & ~(PM_OP_TIMESTEP | PM_OP_WEFF | PM_OP_CONTRACTED)) == 0,
+  PM_REQUIRE((ops & ~(PM_OP_TIMESTEP | PM_OP_WEFF | PM_OP_CONTRACTED | PM_OP_WA_PSI)) == 0,
              "unknown op bits 0x%x", ops);
+  if (ops & PM_OP_WA_PSI) {
+    PM_REQUIRE(!vdx_in && !(ops & PM_OP_WEFF) && (ops & PM_OP_TIMESTEP) == PM_OP_TIMESTEP &&
+                   nsteps >= 3 && (c.ncols & 1) == 0,
+               "PM_OP_WA_PSI: plain timesteps (>= 3 per launch) of a two-column ensemble, no "
+               "horadv, no PM_OP_WEFF");
+    vdx_in = nullptr;
+  } else {
+    PM_REQUIRE(!vdx_in || b_in, "b_in is needed if vdx_in is provided");
+  }
   PM_REQUIRE(!(ops & PM_OP_VERTADVDIFF) || wA, "wA is NULL");
-  PM_REQUIRE(!vdx_in || b_in, "b_in is needed if vdx_in is provided");
   if (c.ncols == 0 || nsteps == 0 || (ops & PM_OP_TIMESTEP) == 0) return PM_OK;
   int G = 0, P = 0;
   const int src = column_shape(c.ncols, c.nz, lanes_per_col, &G, &P);

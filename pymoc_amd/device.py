@@ -17,6 +17,10 @@ class Stream(object):
   def sync(self):
     check(lib.pm_stream_sync(self.handle))
 
+  def wait(self, event):
+    """Work submitted to this stream from now on waits for `event` (hipStreamWaitEvent)."""
+    check(lib.pm_stream_wait_event(self.handle, event.handle))
+
   def __del__(self):
     try:
       if self.handle:
@@ -145,7 +149,22 @@ class DeviceArray(object):
       raise ValueError("copy size mismatch")
     check(lib.pm_memcpy_d2d(self.ptr, other.ptr, self.nbytes, _sh(stream)))
 
+  def view(self, first_row, nrows):
+    """Rows [first_row, first_row + nrows) of a 2-D array as an array of their own that does
+    not own the memory (the parent must outlive it)."""
+    v = object.__new__(DeviceArray)
+    v.shape = (int(nrows),) + self.shape[1:]
+    v.dtype = self.dtype
+    row = int(np.prod(self.shape[1:])) * self.dtype.itemsize
+    v.nbytes = int(nrows) * row
+    v.ptr = self.ptr + int(first_row) * row
+    v._parent = self
+    return v
+
   def free(self):
+    if getattr(self, "_parent", None) is not None:
+      self.ptr = 0
+      return
     if getattr(self, "ptr", 0):
       lib.pm_free(self.ptr)
       self.ptr = 0

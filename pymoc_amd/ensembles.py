@@ -137,8 +137,10 @@ class TwoColEnsemble(object):
   mapped to isopycnal space every MOC_up_iters steps."""
 
   def __init__(self, cfg, stream=None, lanes_per_col=0, comm=None, n_total=None,
-               diag_iters=None, keep_history=False, arith="exact"):
-    """`comm` (a pymoc_amd.sharding communicator) makes this rank's members one shard of an
+               diag_iters=None, keep_history=False, arith="exact", overlap_updates=True):
+    """`overlap_updates`: with an SO channel, Psi_SO.solve and the thermal wind of an update run
+    side by side on two streams (bit-identical results; see `_update`).
+    `comm` (a pymoc_amd.sharding communicator) makes this rank's members one shard of an
     `n_total`-member ensemble: stepping is unchanged (members never interact) and
     {b_basin, b_north, Psi, Psi_SO} are all-gathered on device buffers every `diag_iters`
     steps (default cfg['Diag_iters']) and by `gather_diagnostics()` at the end of a run.
@@ -181,6 +183,10 @@ class TwoColEnsemble(object):
                                          else cfg['bs_SO'], stream=stream)
     self._zero_so = (DeviceArray.zeros((n, nz), stream=stream)
                      if self.so is None and self.diag is not None else None)
+    self._overlap = self.so is not None and bool(overlap_updates)
+    if self._overlap:
+      from .device import Stream, Event
+      self._side, self._ev_fork, self._ev_join = Stream(), Event(), Event()
     self._update()  # AMOC.solve(); AMOC.Psibz() [; SO.solve()] on the initial profiles
 
   # device views
@@ -196,13 +202,41 @@ class TwoColEnsemble(object):
     return self.so.Psi if self.so is not None else None
 
   def _update(self):
-    # SO.solve() and AMOC.solve() both read basin.b only, so the SO update may run first
-    # and feed wAb = (Psi_iso_b - SO.Psi)*1e6 inside the thermal-wind launch
+    # SO.solve() and AMOC.solve() both read basin.b only.  With the SO channel the two launches
+    # run SIDE BY SIDE on two streams (each leaves the machine partly idle: together 174 us
+    # instead of 200 us per update of 8192 members) and the columns form
+    # wAb = (Psi_iso_b - SO.Psi)*1e6, wAN = -Psi_iso_n*1e6 themselves (PM_OP_WA_PSI) once both
+    # are done -- the same operations as the thermal-wind launch's wA1 / wA2 epilogue.
+    if self.so is not None and self._overlap:
+      self._ev_fork.record(self.stream)     # the columns' steps before this update
+      self._side.wait(self._ev_fork)
+      self.so.stream = self._side
+      self.so.update(self._b_basin, self.bs_SO)
+      self.so.stream = self.stream
+      self._ev_join.record(self._side)
+      self.tw.update(self._b_basin, self._b_north, ops=_TW_ALL, store_psib=False)
+      if self.stream is not None:
+        self.stream.wait(self._ev_join)
+      else:
+        from ._lib import check, lib
+        check(lib.pm_stream_wait_event(None, self._ev_join.handle))
+      return
     if self.so is not None:
       self.so.update(self._b_basin, self.bs_SO)
     self.tw.update(self._b_basin, self._b_north, ops=_TW_ALL, store_psib=False,
                    Psi_SO=self._psi_so(),
                    wA1=self.wA.ptr, wA2=self.wA.ptr + self._off)
+
+  def _steps(self, n):
+    if self.so is not None and self._overlap and n >= 3:
+      self.cols.steps(None, self.dt, n, lanes_per_col=self.lanes, arith=self.arith,
+                      psi_forcing=(self.tw.psibz, self.so.Psi))
+      return
+    if self.so is not None and self._overlap:  # a launch of 1-2 steps: the forcing as an array
+      from ._lib import check, lib
+      check(lib.pm_twocol_forcing(self.n, self.nz, self.tw.psibz.ptr, self.so.Psi.ptr,
+                                  self.wA.ptr, _sh(self.stream)))
+    self.cols.steps(self.wA, self.dt, n, lanes_per_col=self.lanes, arith=self.arith)
 
   def run(self, nsteps):
     """`for ii in range(nsteps): step both columns; if ii % MOC_up_iters == 0: update`,
@@ -211,7 +245,7 @@ class TwoColEnsemble(object):
     while remaining > 0:
       nxt = self.ii if self.ii % self.M == 0 else (self.ii // self.M + 1) * self.M
       n = min(nxt - self.ii + 1, remaining)
-      self.cols.steps(self.wA, self.dt, n, lanes_per_col=self.lanes, arith=self.arith)
+      self._steps(n)
       self.ii += n
       remaining -= n
       if (self.ii - 1) % self.M == 0:

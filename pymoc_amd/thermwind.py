@@ -28,8 +28,11 @@ class ThermwindBatch(object):
     self.Psi = DeviceArray.zeros((self.n, self.nz), stream=stream)
     self.bgrid = DeviceArray.zeros((self.n, self.nb), stream=stream)
     self.psib = DeviceArray.zeros((self.n, self.nb), stream=stream)
-    self.psibz1 = DeviceArray.zeros((self.n, self.nz), stream=stream)
-    self.psibz2 = DeviceArray.zeros((self.n, self.nz), stream=stream)
+    # Psi_iso of the basin and of the north in ONE [2n, nz] array (rows as a two-column
+    # ColumnBatch has them: ColumnBatch.steps(psi_forcing=...) reads it as the columns' forcing)
+    self.psibz = DeviceArray.zeros((2 * self.n, self.nz), stream=stream)
+    self.psibz1 = self.psibz.view(0, self.n)
+    self.psibz2 = self.psibz.view(self.n, self.n)
 
   @staticmethod
   def _ptr(x):

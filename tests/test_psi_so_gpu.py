@@ -445,3 +445,23 @@ def test_gm_adaptive_mesh_short_grids_vs_oracle(gpu, nz):
     if seen >= 4:
       break
   assert seen >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", ["exact", "contracted"])
+def test_twocol_so_updates_side_by_side_equal_serial_updates(gpu, arith):
+  """TwoColEnsemble with an SO channel runs Psi_SO.solve and the thermal wind of an update on two
+  streams and lets the column kernel form wA from Psi_iso / Psi_SO (PM_OP_WA_PSI): bit-identical
+  to the serial update with the thermal-wind launch's wA1 / wA2 epilogue, over whole and split
+  intervals (launches of 1-2 steps take the forcing from pm_twocol_forcing)."""
+  cfg = configs.config4(N=96)
+  a = gpu.TwoColEnsemble(cfg, arith=arith)
+  b = gpu.TwoColEnsemble(cfg, arith=arith, overlap_updates=False)
+  assert a._overlap and not b._overlap
+  for n in (1, 2, 23, 24, 25, 2, 1, 70):
+    a.run(n)
+    b.run(n)
+    sa, sb = a.state(), b.state()
+    for k in sb:
+      assert np.array_equal(sa[k], sb[k], equal_nan=True), (n, k)
+  assert np.array_equal(a.nonfinite_members(), b.nonfinite_members())
