@@ -118,6 +118,48 @@ struct JfConv {
   bool valid;                // a pattern has been established in this launch
 };
 
+// A lane's P consecutive levels of a row in HBM.  VEC (P = 2 or 4, rows of a multiple of P
+// levels, 16-byte aligned: decided by the launcher): 16-byte loads per lane instead of 8-byte
+// loads with stride 8 P (a launch's memory-bound prologue: 170 -> 162 us per 36-step launch);
+// lanes past the last level re-read the last P levels (callers mask them).
+template <int P, bool VEC>
+__device__ __forceinline__ void jf_load_row(double (&out)[P], const double *__restrict__ row,
+                                            int lane, int nz) {
+  if constexpr (VEC && (P == 4 || P == 2)) {
+    const int i0 = lane * P < nz - P ? lane * P : nz - P;
+#pragma unroll
+    for (int h = 0; h < P / 2; ++h) {
+      const double2 v = *reinterpret_cast<const double2 *>(row + i0 + 2 * h);
+      out[2 * h] = v.x;
+      out[2 * h + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      out[p] = row[i < nz ? i : nz - 1];
+    }
+  }
+}
+
+template <int P, bool VEC>
+__device__ __forceinline__ void jf_store_row(double *__restrict__ row, const double (&v)[P],
+                                             int lane, int nz) {
+  if constexpr (VEC && (P == 4 || P == 2)) {
+    if (lane * P < nz) {
+#pragma unroll
+      for (int h = 0; h < P / 2; ++h)
+        *reinterpret_cast<double2 *>(row + lane * P + 2 * h) = make_double2(v[2 * h], v[2 * h + 1]);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p;
+      if (i < nz) row[i] = v[p];
+    }
+  }
+}
+
 // two slots of a table: one 16-byte LDS read
 __device__ __forceinline__ double2 jf_pair(const double *T, int lane, int h) {
   return *reinterpret_cast<const double2 *>(T + (h * 64 + lane) * 2);
@@ -337,7 +379,7 @@ __device__ __forceinline__ void jf_vertadvdiff_contracted(JfCol<P> &c) {
 
 // CT: the columns step in the contracted form (tolerance mode); otherwise every operation is
 // the reference's, in its order.
-template <int P, bool CT>
+template <int P, bool CT, bool VEC>
 __global__ __launch_bounds__(64 * JF_WAVES) JF_OCC_ATTR
 void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
   using L = JfLds<P>;
@@ -410,12 +452,14 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
       // (PM_JN_SHARED_COEF: the column kind's one coefficient row, resident in L2)
       const size_t arow = (size_t)(shared ? (col < n ? 0 : n) : col) * nz;
       const double a0 = c.area[arow];
+      double rb[P], ra_[P];
+      jf_load_row<P, VEC>(rb, c.b + (size_t)col * nz, lane, nz);
+      jf_load_row<P, VEC>(ra_, c.area + arow, lane, nz);
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int i = lane * P + p;
-        const int ic = i < nz ? i : nz - 1;
-        r.b[p] = i < nz ? c.b[(size_t)col * nz + ic] : JF_PAD;
-        same = same && c.area[arow + ic] == a0;
+        r.b[p] = i < nz ? rb[p] : JF_PAD;
+        same = same && ra_[p] == a0;  // (lanes past the last level hold copies of real levels)
       }
       hint_ok = hint_ok && __ballot(!same) == 0ull;
       {  // operands inside the exact-division window? (common.hip.h; flagged, not branched on)
@@ -458,10 +502,12 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
     cbits = (PsiSO1 < 0 ? 1 : 0) | (PsiSO1 >= 0 ? 2 : 0) | (Pb1 > 0 ? 4 : 0) | (Pn1 < 0 ? 8 : 0);
     // ---- mixed layer: Psi_mod (SO_ML.py:228-230) is Psi_b with its leading zeros filled
     const double *Psi_b = a.Psi_SO + bz;
+    double rpso[P];
+    jf_load_row<P, VEC>(rpso, Psi_b, lane, nz);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = lane * P + p;
-      const double v = i < nz ? Psi_b[i] : 0.;
+      const double v = i < nz ? rpso[p] : 0.;
       const unsigned long long nzm = __ballot(i < nz && v != 0.), pm_ = __ballot(i < nz && v > 0.);
       if (nzm) {
         const int j = ((int)__ffsll((long long)nzm) - 1) * P + p;
@@ -477,7 +523,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = lane * P + p;
-      wl[L::W_PM + i] = (i < ml_ind || i >= nz) ? fillv : Psi_b[i];
+      wl[L::W_PM + i] = (i < ml_ind || i >= nz) ? fillv : rpso[p];
     }
     double f1 = 0., f2 = 0., br = 0.;
     if (lane < ny) {
@@ -517,13 +563,16 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
         const double *kappa = ka->cols.kappa, *dAk = ka->cols.dAkappa, *wA = ka->wA;
         const bool shared_rows = (ka->hints & PM_JN_SHARED_COEF) != 0;
         const size_t sbase = ((size_t)sel * (2 * n) + (shared_rows ? (col < n ? 0 : n) : col)) * nz;
+        double rk[P], rd[P], rw[P];
+        jf_load_row<P, VEC>(rk, kappa + sbase, lane, nz);
+        jf_load_row<P, VEC>(rd, dAk + sbase, lane, nz);
+        jf_load_row<P, VEC>(rw, wA + (size_t)col * nz, lane, nz);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           const int i = lane * P + p;
-          const int ic = i < nz ? i : nz - 1;
-          r.kap[p] = kappa[sbase + ic];
+          r.kap[p] = rk[p];
           if (kap) kap[jf_entry<P>(lane, p)] = r.kap[p];
-          const double w = wA[(size_t)col * nz + ic] - dAk[sbase + ic];
+          const double w = rw[p] - rd[p];
           const bool interior = i >= 1 && i <= nz - 2;
           const double we = interior ? w : 0.0;
           r.wn[p] = (we < 0.0) ? -we : 0.0;
@@ -769,17 +818,13 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
   bool bad = false;
   {
     double *bout = ka->cols.b;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int i = lane * P + p;
-      if (i < nz) {
-        if (m_ok && hint_ok) {
-          bout[(size_t)m * nz + i] = cb.b[p];
-          bout[(size_t)(n + m) * nz + i] = cn.b[p];
-        }
-        bad |= !isfinite(cb.b[p]) || !isfinite(cn.b[p]);
-      }
+    if (m_ok && hint_ok) {
+      jf_store_row<P, VEC>(bout + (size_t)m * nz, cb.b, lane, nz);
+      jf_store_row<P, VEC>(bout + (size_t)(n + m) * nz, cn.b, lane, nz);
     }
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (lane * P + p < nz) bad |= !isfinite(cb.b[p]) || !isfinite(cn.b[p]);
   }
   if (lane < ny) {
     bad |= !isfinite(q.bs);
@@ -815,12 +860,23 @@ template <int P>
 static int launch_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st) {
   const size_t lds = (size_t)JfLds<P>::TOTAL * sizeof(double);
   const unsigned grid = (unsigned)((a.n + JF_WAVES - 1) / JF_WAVES);
-  if (a.hints & PM_JN_CONTRACTED)
-    hipLaunchKernelGGL((k_jn2018_fast<P, true>), dim3(grid), dim3(64 * JF_WAVES), lds, st, a, dt,
-                       nsteps);
+  // 16-byte row accesses (jf_load_row): every row starts 16-byte aligned and holds whole lanes
+  auto al = [](const void *q) { return (((unsigned long long)q) & 15ull) == 0ull; };
+  const bool vec = a.cols.nz % P == 0 && al(a.cols.b) && al(a.cols.area) && al(a.cols.kappa) &&
+                   al(a.cols.dAkappa) && al(a.wA) && al(a.Psi_SO);
+  const bool ct = (a.hints & PM_JN_CONTRACTED) != 0;
+#define JF_LAUNCH(CT_, VEC_)                                                                  \
+  hipLaunchKernelGGL((k_jn2018_fast<P, CT_, VEC_>), dim3(grid), dim3(64 * JF_WAVES), lds, st, a, \
+                     dt, nsteps)
+  if (ct && vec)
+    JF_LAUNCH(true, true);
+  else if (ct)
+    JF_LAUNCH(true, false);
+  else if (vec)
+    JF_LAUNCH(false, true);
   else
-    hipLaunchKernelGGL((k_jn2018_fast<P, false>), dim3(grid), dim3(64 * JF_WAVES), lds, st, a, dt,
-                       nsteps);
+    JF_LAUNCH(false, false);
+#undef JF_LAUNCH
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
