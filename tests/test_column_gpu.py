@@ -354,6 +354,41 @@ def test_precombined_forcing_and_uniform_area_bitwise(gpu, nsteps):
     assert np.array_equal(pre.get_b()[m], ref), m
 
 
+@pytest.mark.parametrize("lanes", [16, 32, 64])
+@pytest.mark.parametrize("arith", ["exact", "contracted"])
+def test_forcing_formed_from_the_overturning_bitwise(gpu, lanes, arith):
+  """PM_OP_WA_PSI: the column kernel forms the two-column drivers' forcing itself,
+  wA_basin = (Psi_iso - Psi_SO) * 1e6 and wA_north = -Psi_iso * 1e6 (example_twocol_plusSO.py:
+  105-106), from the rows the thermal-wind and SO kernels leave in HBM: same bits as stepping with
+  that forcing as an array (NumPy here; pm_twocol_forcing on the device), with and without Psi_SO."""
+  if arith == "contracted" and lanes != 64:
+    pytest.skip("the tolerance mode runs one wave per column")
+  n = 300
+  c = configs.config2(N=2 * n)
+  rng = np.random.default_rng(11)
+  psi_iso = rng.standard_normal((2 * n, c["z"].size)) * 3.0
+  psi_so = rng.standard_normal((n, c["z"].size))
+  psi_iso[:, 0] = psi_iso[:, -1] = 0.0
+
+  def make():
+    return gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"], bs=c["bs"], bbot=c["bbot"],
+                           N2min=c["N2min"], do_conv=c["do_conv"])
+  d_iso, d_so = gpu.DeviceArray.from_host(psi_iso), gpu.DeviceArray.from_host(psi_so)
+  for so_h, so_d in ((psi_so, d_so), (None, None)):
+    wA = np.empty_like(psi_iso)
+    wA[:n] = ((psi_iso[:n] - so_h) if so_h is not None else psi_iso[:n]) * 1e6
+    wA[n:] = (-psi_iso[n:]) * 1e6
+    a, b = make(), make()
+    a.steps(None, c["dt"], 24, lanes_per_col=lanes, arith=arith, psi_forcing=(d_iso, so_d))
+    b.steps(gpu.DeviceArray.from_host(wA), c["dt"], 24, lanes_per_col=lanes, arith=arith)
+    assert np.array_equal(a.get_b(), b.get_b())
+    out = gpu.DeviceArray((2 * n, c["z"].size))
+    from pymoc_amd import _lib
+    _lib.check(_lib.lib.pm_twocol_forcing(n, c["z"].size, d_iso.ptr, so_d.ptr if so_d else None,
+                                          out.ptr, None))
+    assert np.array_equal(out.download(), wA)
+
+
 # ---- the opt-in tolerance mode (PM_OP_CONTRACTED, ColumnBatch.steps(arith="contracted")) ----
 CONTRACTED_RTOL = 1e-12  # max-norm, relative to max|reference| (SURVEY 8d's tolerance for K1)
 
