@@ -360,6 +360,61 @@ typedef struct pm_jn2018 {
 
 int pm_jn2018_steps(const pm_jn2018 *jn, double dt, int32_t nsteps, pm_stream_t stream);
 
+/* ------------------------------------------------------------------ whole coupled runs
+ * The reference's coupled drivers are loops "every MOC_up_iters steps refresh the overturning
+ * diagnostics, then step" (examples/example_twocol.py:85-96, run_JansenNadeau_2018.py:201-261).
+ * pm_twocol_run / pm_jn2018_run carry every member through MANY such intervals in ONE launch:
+ * a wavefront owns a member and runs the diagnostic phase and the stepping phase of each
+ * interval back to back (members never interact, so no launch boundary is needed between
+ * them).  The phases are the device functions of pm_psi_so_update, pm_thermwind_update and
+ * pm_jn2018_steps / pm_column_steps, so the result is bit-identical to issuing those calls in
+ * the drivers' order.  Schedule of one launch:
+ *     n_first steps;  then n_updates x [refresh the diagnostics; steps], where the last block
+ *     steps n_last (possibly 0) and the others m_steps.
+ * A driver ends a launch where it wants to look at the state (diagnostic output, RCCL gather). */
+typedef struct pm_run_schedule {
+  int32_t n_first, n_updates, m_steps, n_last;
+} pm_run_schedule;
+
+/* example_twocol.py:85-96: per member a basin column (row m of `cols`) and a northern column
+ * (row n + m), Psi_Thermwind solve / Psib / Psibz between them (`tw`: b1 = cols.b, b2 = cols.b +
+ * n nz; wA1 = wA, wA2 = wA + n nz; psibz1 / psibz2 / Psi are outputs; Psi_SO NULL), forcing
+ * wA[2n][nz] (in for the n_first steps, rewritten by every refresh).  Requires: Area constant in
+ * z, no bzbot, nz <= 256 with (7 nz' + 16 max(...)) doubles of LDS <= 160 KB (checked).
+ * status[n] (must be zeroed by the caller; bits are OR-ed in): 2 non-finite state, 16 columns this
+ * kernel cannot step (left untouched), 32 some interval stepped with IEEE divisions because an
+ * operand was outside the exact-division window (same guard as pm_column_steps).            */
+typedef struct pm_twocol_loop {
+  pm_columns cols;
+  pm_thermwind tw;
+  const double *wA;
+  double dt;
+  pm_run_schedule sched;
+  int32_t *status;
+} pm_twocol_loop;
+int pm_twocol_run(const pm_twocol_loop *run, pm_stream_t stream);
+
+/* run_JansenNadeau_2018.py:201-261: per interval PsiSO.solve (`so`: b = the basin rows of jn.cols,
+ * bs = jn.ml.bs, Psi = jn.Psi_SO), AMOC.solve / Psibz (`tw`: b1 / b2 = the basin / northern rows,
+ * Psi_SO = jn.Psi_SO, wA1 / wA2 = jn.wA rows, psibz1 / psibz2 = jn.Psi_res_b / Psi_res_n), then the
+ * fused step loop of pm_jn2018_steps.  `jn` as for pm_jn2018_steps with PM_JN_UNIFORM_AREA
+ * (ny <= 64, 4 <= nz <= 256); `so` without the boundary-value smoother (c = None).
+ * jn.ml.status as for pm_jn2018_steps, but OR-ed over the intervals (zero it first).        */
+typedef struct pm_jn2018_loop {
+  pm_jn2018 jn;
+  pm_thermwind tw;
+  pm_psi_so so;
+  double dt;
+  pm_run_schedule sched;
+} pm_jn2018_loop;
+int pm_jn2018_run(const pm_jn2018_loop *run, pm_stream_t stream);
+
+/* LDS bytes per block (16 members) the phases of a run kernel need for this shape: kind 0 =
+ * pm_twocol_run, 1 = pm_jn2018_run (ny: points of the mixed layer).  A launch is refused
+ * (PM_EINVAL) above 160 KB; a driver asks first and keeps its launch sequence otherwise.
+ * 0 = shape not supported at all.                                                           */
+int pm_run_lds_bytes(int32_t kind, int32_t nz, int32_t nb, int32_t ny, size_t *bytes);
+
 /* Column forcing of the two-column drivers as an array (what PM_OP_WA_PSI forms inside the
  * column kernel; for launches of fewer than 3 steps): wA[0:n] = (Psi_iso[0:n] - Psi_SO) * 1e6
  * (Psi_SO may be NULL), wA[n:2n] = -Psi_iso[n:2n] * 1e6; Psi_iso, wA [2n][nz], Psi_SO [n][nz]. */

@@ -129,6 +129,24 @@ class pm_jn2018(C.Structure):
   ]
 
 
+class pm_run_schedule(C.Structure):
+  """Mirror of `struct pm_run_schedule` (include/pymoc_hip.h)."""
+  _fields_ = [("n_first", C.c_int32), ("n_updates", C.c_int32), ("m_steps", C.c_int32),
+              ("n_last", C.c_int32)]
+
+
+class pm_twocol_loop(C.Structure):
+  """Mirror of `struct pm_twocol_loop` (include/pymoc_hip.h)."""
+  _fields_ = [("cols", pm_columns), ("tw", pm_thermwind), ("wA", c_dp), ("dt", C.c_double),
+              ("sched", pm_run_schedule), ("status", c_dp)]
+
+
+class pm_jn2018_loop(C.Structure):
+  """Mirror of `struct pm_jn2018_loop` (include/pymoc_hip.h)."""
+  _fields_ = [("jn", pm_jn2018), ("tw", pm_thermwind), ("so", pm_psi_so), ("dt", C.c_double),
+              ("sched", pm_run_schedule)]
+
+
 if not os.path.exists(LIB_PATH):
   raise ImportError(
       "pymoc_amd: %s is missing. Build it with `make lib` (hipcc --offload-arch=gfx950) "
@@ -180,6 +198,10 @@ SIGNATURES = {
     "pm_so_ml_step": (C.c_int, [C.POINTER(pm_so_ml), C.c_double, C.c_void_p]),
     "pm_jn2018_bc_switch": (C.c_int, [C.POINTER(pm_jn2018_bc), C.c_void_p]),
     "pm_jn2018_steps": (C.c_int, [C.POINTER(pm_jn2018), C.c_double, C.c_int32, C.c_void_p]),
+    "pm_twocol_run": (C.c_int, [C.POINTER(pm_twocol_loop), C.c_void_p]),
+    "pm_jn2018_run": (C.c_int, [C.POINTER(pm_jn2018_loop), C.c_void_p]),
+    "pm_run_lds_bytes": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.POINTER(C.c_size_t)]),
     "pm_twobasin_forcing": (C.c_int, [C.c_int32, C.c_int32] + [c_dp] * 9 + [C.c_void_p]),
     "pm_column_equi_pass": (C.c_int, [C.POINTER(pm_column_equi), C.c_void_p]),
     "pm_equi_column_scratch_doubles": (C.c_size_t, [C.c_int32]),

@@ -35,6 +35,7 @@
 #ifndef PM_JF_IN_MAIN_TU
 #define PM_SO_ML_DEVICE_FUNCTIONS_ONLY
 #endif
+#include <type_traits>
 #include "so_ml.hip.h"
 
 namespace pm {
@@ -283,6 +284,41 @@ __device__ __forceinline__ void jf_vertadvdiff(JfCol<P> &c, const double *lds, c
   }
 }
 
+// The same step in the reference-faithful form for ANY operand, finite or not (col_vertadvdiff's
+// DIV == 0, column.hip.h): IEEE divisions, the compare-select upwind flux of column.py:242-246,
+// boundary / padding levels left untouched by a select.  Taken by a wave whose operands leave
+// the window of the exact-division shortcuts (in_fast_div_range); never on the hot path.
+template <int P, bool KAPREG>
+__device__ __forceinline__ void jf_vertadvdiff_ieee(JfCol<P> &c, const double *lds,
+                                                    const double *ws, const double *kap, int lane,
+                                                    double dt, int nz) {
+  using L = JfLds<P>;
+  double bz[P];
+  const double nb0 = from_next_lane_z(c.b[0]);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    const double up = (p < P - 1) ? c.b[p + 1 < P ? p + 1 : p] : nb0;
+    const double qv = (up - c.b[p]) / lds[L::T_DZ + jf_entry<P>(lane, p)];  // column.py:235
+    bz[p] = (i < nz - 1) ? qv : 0.0;
+  }
+  const double pbz = from_prev_lane_z(bz[P - 1]);
+  const double area = ws[S_AREA];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    const double dn = (p > 0) ? bz[p > 0 ? p - 1 : 0] : pbz;
+    const double bzz = (bz[p] - dn) / lds[L::T_DZC + jf_entry<P>(lane, p)];  // :238
+    // weff < 0 exactly where wn holds -weff != 0 (load_coef); -weff is wn there, wp elsewhere
+    const bool neg = c.wn[p] != 0.0;
+    const double flx = (neg ? c.wn[p] : c.wp[p]) * (neg ? bz[p] : dn);  // :242-246
+    const double adv = flx / area;
+    const double kp = KAPREG ? c.kap[p] : kap[jf_entry<P>(lane, p)];
+    const double nb = c.b[p] + dt * (adv + kp * bzz);  // :245-249
+    c.b[p] = (i >= 1 && i <= nz - 2) ? nb : c.b[p];
+  }
+}
+
 // mixed-layer state of a lane (point j = lane); everything else about the point lives in the
 // wave's LDS rows
 struct JfMl {
@@ -377,26 +413,15 @@ __device__ __forceinline__ void jf_vertadvdiff_contracted(JfCol<P> &c) {
   }
 }
 
-// CT: the columns step in the contracted form (tolerance mode); otherwise every operation is
-// the reference's, in its order.
-template <int P, bool CT, bool VEC>
-__global__ __launch_bounds__(64 * JF_WAVES) JF_OCC_ATTR
-void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
+// The block's tables: grid metrics and their double-double reciprocals (col_load_grid's
+// operations), the mixed layer's PCR multipliers and metric constants.  Every thread of the block
+// calls it once; the caller's __syncthreads() publishes the tables.
+template <int P>
+__device__ __forceinline__ void jf_block_tables(const pm_jn2018 &a, double dt, double *lds,
+                                                int wave, int lane) {
   using L = JfLds<P>;
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int m_raw = blockIdx.x * JF_WAVES + wave;
-  const bool m_ok = m_raw < a.n;
-  const int m = m_ok ? m_raw : a.n - 1;
-  const int n = a.n, nz = a.cols.nz, ny = a.ml.ny;
-  PM_WAVE_BEGIN
-  PM_TICK_INIT
-  double *wl = lds + L::WAVE0 + wave * L::PER_WAVE;  // this wave's rows; wl[level] = basin b
-  double *ws = wl + L::W_S;                           // this member's scalars
-
-  // ---- block tables: grid metrics, double-double reciprocals (col_load_grid's operations)
-  for (int e = threadIdx.x; e < L::NZP; e += 64 * JF_WAVES) {
+  const int nz = a.cols.nz, ny = a.ml.ny;
+  for (int e = threadIdx.x; e < L::NZP; e += blockDim.x) {
     const double *z = a.cols.z;
     const int h = e >> 7, ln = (e >> 1) & 63, q = e & 1;
     const int i = ln * P + 2 * h + q;
@@ -418,26 +443,50 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
     lds[L::T_RDZCL + e] = interior ? recip_lo(dzc, rdzc) : 0.0;
   }
   if (wave == 0) {
-    const double ml_h = a.ml.h, ml_L = a.ml.L, dy = a.ml.y[1] - a.ml.y[0];
-    const double ms_s = a.ml.Ks * dt / (dy * dy);  // SO_ML.py:191
-    jf_build_pcr(lds + L::PCR, ny, ms_s, lane);
     if (lane < 16) reinterpret_cast<int *>(lds + L::PROG)[lane] = 0;
-    if (lane == 0) {
-      double *K = lds + L::KML;
-      const double rh = 1.0 / ml_h, rL = 1.0 / ml_L, rdy = 1.0 / dy;
-      K[K_H] = ml_h;
-      K[K_RH] = rh;
-      K[K_RHL] = recip_lo(ml_h, rh);
-      K[K_L] = ml_L;
-      K[K_RL] = rL;
-      K[K_RLL] = recip_lo(ml_L, rL);
-      K[K_DY] = dy;
-      K[K_RDY] = rdy;
-      K[K_RDYL] = recip_lo(dy, rdy);
-      K[K_SH] = ms_s / 2.;
-      K[K_1MS] = 1 - ms_s;
+    if (ny >= 3 && a.ml.y != nullptr) {  // (the two-column run kernel has no mixed layer)
+      const double ml_h = a.ml.h, ml_L = a.ml.L, dy = a.ml.y[1] - a.ml.y[0];
+      const double ms_s = a.ml.Ks * dt / (dy * dy);  // SO_ML.py:191
+      jf_build_pcr(lds + L::PCR, ny, ms_s, lane);
+      if (lane == 0) {
+        double *K = lds + L::KML;
+        const double rh = 1.0 / ml_h, rL = 1.0 / ml_L, rdy = 1.0 / dy;
+        K[K_H] = ml_h;
+        K[K_RH] = rh;
+        K[K_RHL] = recip_lo(ml_h, rh);
+        K[K_L] = ml_L;
+        K[K_RL] = rL;
+        K[K_RLL] = recip_lo(ml_L, rL);
+        K[K_DY] = dy;
+        K[K_RDY] = rdy;
+        K[K_RDYL] = recip_lo(dy, rdy);
+        K[K_SH] = ms_s / 2.;
+        K[K_1MS] = 1 - ms_s;
+      }
     }
   }
+}
+
+// One member's launch: `nsteps` x [BC switch -> both columns -> mixed layer] from the state in
+// HBM and back.  The body of k_jn2018_fast, and the stepping phase of the persistent run kernel
+// (coupled_run.hip: `wstride` = the wave's share of LDS there, `s0` = the steps the wave has
+// behind it, for the lag-based issue priority).  The kernel's argument block must START with the
+// pm_jn2018 (jf_args re-reads it there).  SYNC: the block's tables are being built by this very
+// block (k_jn2018_fast): a __syncthreads() after the member's own loads publishes them.
+// CT: the columns step in the contracted form (tolerance mode); otherwise every operation is
+// the reference's, in its order.
+template <int P, bool CT, bool VEC, bool SYNC>
+__device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int nsteps, int s0,
+                                              int m_raw, double *lds, int wstride, int wave,
+                                              int lane) {
+  using L = JfLds<P>;
+  const bool m_ok = m_raw < a.n;
+  const int m = m_ok ? m_raw : a.n - 1;
+  const int n = a.n, nz = a.cols.nz, ny = a.ml.ny;
+  PM_WAVE_BEGIN
+  PM_TICK_INIT
+  double *wl = lds + L::WAVE0 + wave * wstride;  // this wave's rows; wl[level] = basin b
+  double *ws = wl + L::W_S;                      // this member's scalars
 
   // ---- this member's columns: state into registers, scalars into the wave's LDS block
   JfCol<P> cb, cn;
@@ -545,7 +594,22 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
       ws[S_BBOT0] = a.cols.bbot[m];
     }
   }
-  __syncthreads();
+  if constexpr (SYNC)
+    __syncthreads();
+  else
+    __builtin_amdgcn_wave_barrier();
+  {  // the grid's part of the operand window (z, dz, dzc: col_inputs_in_fast_range, column.hip.h)
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = lane * P + p, e = jf_entry<P>(lane, p);
+      const double zv = lds[L::T_Z + e], dzv = lds[L::T_DZ + e], dzcv = lds[L::T_DZC + e];
+      ok = ok && (i >= nz || (in_fast_div_range(zv) &&
+                              (i >= nz - 1 || (in_fast_div_range(dzv) && dzv != 0.0)) &&
+                              in_fast_div_range(dzcv) && dzcv != 0.0));
+    }
+    range_ok = range_ok && __ballot(!ok) == 0ull;
+  }
   int status = ml_ok ? 0 : 1;
   bool ps_valid = false;
   const bool lane0 = lane == 0;
@@ -599,7 +663,7 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
       __builtin_amdgcn_wave_barrier();
     }
     // BC switch + both columns of step s; false: a coefficient set changed (nothing done yet)
-    auto columns_step = [&](int lane_o, double *wl, double *ws) -> bool {
+    auto columns_step = [&](auto ieee_c, int lane_o, double *wl, double *ws) -> bool {
 #ifndef JF_NO_PRIO_ROTATE
       // The SIMD's arbiter favours its oldest wave: left alone its four waves (waves w, w+4,
       // w+8, w+12 of the block) finish ~20 us apart and the last runs alone; with priorities
@@ -608,13 +672,14 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
       // counter and takes its priority from its rank: the one furthest behind issues first.
       {
         int *prog = reinterpret_cast<int *>(lds + L::PROG) + (wave & 3) * 4;
-        prog[wave >> 2] = s;
+        const int sg = s0 + s;  // steps behind this wave (over all launches of a persistent run)
+        prog[wave >> 2] = sg;
         const int4 pv = *reinterpret_cast<const int4 *>(prog);
         const int p0 = __builtin_amdgcn_readfirstlane(pv.x), p1 = __builtin_amdgcn_readfirstlane(pv.y),
                   p2 = __builtin_amdgcn_readfirstlane(pv.z), p3 = __builtin_amdgcn_readfirstlane(pv.w);
         const int lo = min(min(p0, p1), min(p2, p3)), hi = max(max(p0, p1), max(p2, p3));
-        if (s <= lo) __builtin_amdgcn_s_setprio(3);
-        else if (s >= hi) __builtin_amdgcn_s_setprio(0);
+        if (sg <= lo) __builtin_amdgcn_s_setprio(3);
+        else if (sg >= hi) __builtin_amdgcn_s_setprio(0);
         else __builtin_amdgcn_s_setprio(1);
       }
 #endif
@@ -653,6 +718,9 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
       if constexpr (CT) {
         jf_vertadvdiff_contracted<P>(cb);
         jf_vertadvdiff_contracted<P>(cn);
+      } else if constexpr (decltype(ieee_c)::value) {
+        jf_vertadvdiff_ieee<P, true>(cb, lds, ws + S_B, nullptr, lane_o, dt, nz);
+        jf_vertadvdiff_ieee<P, false>(cn, lds, ws + S_NN, wl + L::W_KN, lane_o, dt, nz);
       } else {
         __builtin_amdgcn_sched_barrier(0);
         jf_vertadvdiff<P, true>(cb, lds, ws + S_B, nullptr, lane_o, dt);
@@ -662,17 +730,23 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
       }
       return true;
     };
+    // The step loop in one of two forms (wave-uniform choice per entry): the exact-division
+    // shortcuts while every operand of the column steps lies in their window, else the IEEE form
+    // (true divisions, compare-select flux, boundary levels held by a select) -- the operand guard
+    // of K1 (column.hip.h), checked where K1 checks it: at the launch's start and when a
+    // coefficient set is loaded.  The tolerance mode (CT) has no such shortcut to guard.
+    auto run_leg = [&](auto ieee_c) {
     if (ml_ok) {
     for (; s < nsteps; ++s) {
       PM_TICK(6)
       // address bases the optimiser must not see through: it would hoist one derived address per
       // access pattern out of the loop (dozens of registers, then spilled) instead of folding
       // the constants into the instructions' offset fields
-      int lane_o = lane, woff = wave * L::PER_WAVE;
+      int lane_o = lane, woff = wave * wstride;
       asm volatile("" : "+v"(lane_o), "+s"(woff));
       const int a4 = lane_o << 2;
       double *wl = lds + L::WAVE0 + woff, *ws = wl + L::W_S;
-      if (__builtin_expect(!columns_step(lane_o, wl, ws), 0)) break;
+      if (__builtin_expect(!columns_step(ieee_c, lane_o, wl, ws), 0)) break;
       PM_TICK(0)
       JF_RARE(0)
       // ---- channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi) (:261), ml_step_reg's operations
@@ -803,12 +877,17 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
     }
     } else {
       for (; s < nsteps; ++s) {
-        int lane_o = lane, woff = wave * L::PER_WAVE;
+        int lane_o = lane, woff = wave * wstride;
         asm volatile("" : "+v"(lane_o), "+s"(woff));
         double *wl = lds + L::WAVE0 + woff, *ws = wl + L::W_S;
-        if (__builtin_expect(!columns_step(lane_o, wl, ws), 0)) break;
+        if (__builtin_expect(!columns_step(ieee_c, lane_o, wl, ws), 0)) break;
       }
     }
+    };
+    if (CT || range_ok)
+      run_leg(std::false_type{});
+    else
+      run_leg(std::true_type{});
   }
 
   PM_TICK_FLUSH
@@ -851,9 +930,23 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
       nonfinite[n + m] = anybad ? 1 : 0;
     }
     int32_t *st = ka->ml.status;
-    if (st) st[m] = status | (anybad ? 2 : 0) | (hint_ok ? 0 : 16) | (range_ok ? 0 : 32);
+    // (a persistent run ORs the intervals' flags together: its caller zeroes the array first)
+    if (st)
+      st[m] = (SYNC ? 0 : st[m]) | status | (anybad ? 2 : 0) | (hint_ok ? 0 : 16) |
+              (range_ok ? 0 : 32);
   }
   PM_WAVE_END(m_raw)
+}
+
+template <int P, bool CT, bool VEC>
+__global__ __launch_bounds__(64 * JF_WAVES) JF_OCC_ATTR
+void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  jf_block_tables<P>(a, dt, lds, wave, lane);
+  jf_member_run<P, CT, VEC, true>(a, dt, nsteps, 0, blockIdx.x * JF_WAVES + wave, lds,
+                                  JfLds<P>::PER_WAVE, wave, lane);
 }
 
 template <int P>
@@ -891,4 +984,6 @@ int launch_jn2018_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st
 }
 
 }  // namespace pm
+
+#include "coupled_run.hip.h"
 #endif

@@ -716,28 +716,11 @@ __device__ __forceinline__ int so_gm_adaptive_reg(const SoRegMesh &w, int nz, do
 // scans `status` for members whose mesh outgrew the register-resident solver (bit 3) and redoes
 // exactly those with the general solver (meshes up to solve_bvp's own 1000 nodes), so that the
 // result is solve_bvp's for ANY input; it exits at once when no member is flagged (~2 us).
+// One member's Psi_SO.solve: `s_y` = the wave's so_lds_doubles(...) doubles of LDS.  The body of
+// k_psi_so, and a diagnostic phase of the persistent run kernels (coupled_run.hip).
 template <int P, bool BVP, bool FIX = false>
-__global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a, int ops) {
-  extern __shared__ double lds_all[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int wave_id = blockIdx.x * (blockDim.x >> 6) + wave;
-  // FIX: every lane looks at one member's status, a ballot collects the flagged ones of 64
-  int scan_next = wave_id * 64, cur_base = 0;
-  unsigned long long pending = 0ull;
-  for (;;) {
-  int m_raw = wave_id;
-  if constexpr (FIX) {
-    while (pending == 0ull) {
-      if (scan_next >= a.n) return;  // wave-uniform: nothing left for this wave
-      cur_base = scan_next;
-      scan_next += gridDim.x * (blockDim.x >> 6) * 64;
-      const int mm = cur_base + lane;
-      pending = __ballot(mm < a.n && (a.status[mm] & 8) != 0);
-    }
-    m_raw = cur_base + __builtin_ctzll(pending);
-    pending &= pending - 1ull;
-  }
+__device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw, double *s_y,
+                                          int lane) {
   const bool m_ok = m_raw < a.n;
   const int m = m_ok ? m_raw : a.n - 1;
   const int nz = a.nz, ny = a.ny;
@@ -746,8 +729,6 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   const bool has_c = BVP;  // == (a.flags & PM_SO_HAS_C) != 0, checked by the launcher
   const bool tau_arr = (a.flags & PM_SO_TAU_ARRAY) != 0;
   const bool adaptive = has_c && a.bvp_refine <= 0;
-  const int per_wave = so_lds_doubles(nz, ny, has_c, adaptive, FIX);
-  double *s_y = lds_all + (size_t)wave * per_wave;
   double *s_bs = s_y + ny;
   double *s_tau = s_bs + ny;
   double *s_w = s_tau + ny;  // BVP workspace: T and N2 on the column grid
@@ -1134,8 +1115,35 @@ __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a,
   PM_TICK(10)
   PM_TICK_FLUSH
   PM_WAVE_END(m_raw)
-  if constexpr (!FIX) break;
-  __builtin_amdgcn_wave_barrier();  // the next flagged member reuses the wave's LDS
+}
+
+template <int P, bool BVP, bool FIX = false>
+__global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a, int ops) {
+  extern __shared__ double lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wave_id = blockIdx.x * (blockDim.x >> 6) + wave;
+  const int per_wave = so_lds_doubles(a.nz, a.ny, BVP, BVP && a.bvp_refine <= 0, FIX);
+  double *s_y = lds_all + (size_t)wave * per_wave;
+  // FIX: every lane looks at one member's status, a ballot collects the flagged ones of 64
+  int scan_next = wave_id * 64, cur_base = 0;
+  unsigned long long pending = 0ull;
+  for (;;) {
+    int m_raw = wave_id;
+    if constexpr (FIX) {
+      while (pending == 0ull) {
+        if (scan_next >= a.n) return;  // wave-uniform: nothing left for this wave
+        cur_base = scan_next;
+        scan_next += gridDim.x * (blockDim.x >> 6) * 64;
+        const int mm = cur_base + lane;
+        pending = __ballot(mm < a.n && (a.status[mm] & 8) != 0);
+      }
+      m_raw = cur_base + __builtin_ctzll(pending);
+      pending &= pending - 1ull;
+    }
+    so_member<P, BVP, FIX>(a, ops, m_raw, s_y, lane);
+    if constexpr (!FIX) break;
+    __builtin_amdgcn_wave_barrier();  // the next flagged member reuses the wave's LDS
   }
 }
 

@@ -395,7 +395,7 @@ int pm_thermwind_residuals(int32_t m, const double *x, const double *y0, const d
                            pm_stream_t stream) {
   PM_REQUIRE(m >= 2 && x && y0 && y1 && g && g_lob && rms, "bad mesh size or NULL pointer");
   hipStream_t st = resolve_stream(stream);
-  hipLaunchKernelGGL(k_thermwind_residuals, dim3((unsigned)((m - 1 + 127) / 128)), dim3(128), 0, st,
+  hipLaunchKernelGGL(k_thermwind_residuals<0>, dim3((unsigned)((m - 1 + 127) / 128)), dim3(128), 0, st,
                      (int)m, x, y0, y1, g, g_lob, rms);
   PM_HIP(hipGetLastError());
   return PM_OK;
@@ -484,6 +484,59 @@ int pm_jn2018_steps(const pm_jn2018 *jn, double dt, int32_t nsteps, pm_stream_t 
     case 3: return launch_jn2018_steps<3>(a, dt, nsteps, st);
     default: return launch_jn2018_steps<4>(a, dt, nsteps, st);
   }
+}
+
+int pm_run_lds_bytes(int32_t kind, int32_t nz, int32_t nb, int32_t ny, size_t *bytes) {
+  PM_REQUIRE(bytes && (kind == 0 || kind == 1), "bad arguments");
+  *bytes = run_lds_bytes(kind, nz, nb, ny);
+  return PM_OK;
+}
+
+int pm_twocol_run(const pm_twocol_loop *run, pm_stream_t stream) {
+  PM_REQUIRE(run, "run is NULL");
+  const pm_twocol_loop &r = *run;
+  const pm_columns &c = r.cols;
+  const pm_thermwind &t = r.tw;
+  PM_REQUIRE(t.n >= 0 && c.ncols == 2 * t.n && t.nz == c.nz, "inconsistent sizes n=%d ncols=%d",
+             t.n, c.ncols);
+  PM_REQUIRE(c.nz >= 4 && c.nz <= 256 && t.nb >= 1, "pm_twocol_run needs 4 <= nz <= 256 (nz=%d)", c.nz);
+  PM_REQUIRE(c.nsel >= 1 && c.nsel <= 2 && (c.nsel == 1 || c.ksel), "bad nsel / ksel");
+  const pm_run_schedule &s = r.sched;
+  PM_REQUIRE(s.n_first >= 0 && s.n_updates >= 0 && s.m_steps >= 0 && s.n_last >= 0, "bad schedule");
+  if (t.n == 0 || (s.n_first == 0 && s.n_updates == 0)) return PM_OK;
+  PM_REQUIRE(c.z && c.b && c.kappa && c.area && c.dAkappa && c.bs && c.bbot && c.N2min && c.flags,
+             "pm_twocol_loop.cols has a NULL required pointer");
+  PM_REQUIRE(t.z && t.b1 && t.b2 && t.f && t.Psi && t.wA1 && t.wA2 && r.wA,
+             "pm_twocol_loop.tw has a NULL required pointer");
+  PM_REQUIRE(!t.b1_mid && !t.b2_mid && !t.Psi_SO, "pm_twocol_run: array profiles, no SO channel");
+  return launch_twocol_run(r, resolve_stream(stream));
+}
+
+int pm_jn2018_run(const pm_jn2018_loop *run, pm_stream_t stream) {
+  PM_REQUIRE(run, "run is NULL");
+  const pm_jn2018_loop &r = *run;
+  const pm_jn2018 &a = r.jn;
+  const pm_columns &c = a.cols;
+  PM_REQUIRE(a.n >= 0 && c.ncols == 2 * a.n && a.ml.n == a.n && a.ml.nz == c.nz && r.tw.n == a.n &&
+                 r.tw.nz == c.nz && r.so.n == a.n && r.so.nz == c.nz && r.so.ny == a.ml.ny,
+             "inconsistent batch sizes n=%d", a.n);
+  PM_REQUIRE(jn2018_fast_applies(a), "pm_jn2018_run needs PM_JN_UNIFORM_AREA, ny <= 64, 4 <= nz <= 256");
+  PM_REQUIRE(c.nsel == 2 && c.ksel && c.z && c.b && c.kappa && c.area && c.dAkappa && c.bs &&
+                 c.bbot && c.N2min,
+             "pm_jn2018_loop.jn.cols has a NULL pointer or nsel != 2");
+  PM_REQUIRE(a.wA && a.Psi_SO && a.Psi_res_b && a.Psi_res_n, "pm_jn2018_loop.jn has a NULL pointer");
+  PM_REQUIRE(a.ml.y && a.ml.bs && a.ml.surflux && a.ml.rest_mask && a.ml.b_rest && a.ml.ny >= 3,
+             "pm_jn2018_loop.jn.ml has a NULL pointer");
+  PM_REQUIRE(r.tw.z && r.tw.b1 && r.tw.b2 && r.tw.f && r.tw.Psi && r.tw.nb >= 1 && !r.tw.b1_mid &&
+                 !r.tw.b2_mid,
+             "pm_jn2018_loop.tw has a NULL required pointer");
+  PM_REQUIRE(r.so.z && r.so.y && r.so.b && r.so.bs && r.so.tau && r.so.KGM && r.so.Psi &&
+                 r.so.Psi_Ek && r.so.Psi_GM && !(r.so.flags & PM_SO_HAS_C),
+             "pm_jn2018_loop.so has a NULL required pointer (or the boundary-value smoother)");
+  const pm_run_schedule &s = r.sched;
+  PM_REQUIRE(s.n_first >= 0 && s.n_updates >= 0 && s.m_steps >= 0 && s.n_last >= 0, "bad schedule");
+  if (a.n == 0 || (s.n_first == 0 && s.n_updates == 0)) return PM_OK;
+  return launch_jn2018_run(r, resolve_stream(stream));
 }
 
 int pm_twobasin_forcing(int32_t n, int32_t nz, const double *Psi_iso_Atl,

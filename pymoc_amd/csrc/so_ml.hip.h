@@ -881,5 +881,9 @@ int launch_jn2018_steps(const pm_jn2018 &a, double dt, int nsteps, hipStream_t s
 // the residency-first rebuild of the fused loop (jn2018_fast.hip): uniform Area, ny <= 64
 bool jn2018_fast_applies(const pm_jn2018 &a);
 int launch_jn2018_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st);
+// whole coupled runs in one launch (coupled_run.hip.h, compiled with jn2018_fast.hip)
+int launch_twocol_run(const pm_twocol_loop &r, hipStream_t st);
+int launch_jn2018_run(const pm_jn2018_loop &r, hipStream_t st);
+size_t run_lds_bytes(int kind, int nz, int nb, int ny);
 
 }  // namespace pm

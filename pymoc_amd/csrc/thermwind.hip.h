@@ -383,20 +383,17 @@ __device__ __forceinline__ void tw_pass_priority(int pass) {
 // ensembles then run as ONE batch of resident waves.  (nz = 200 needs 135; capping it at 128
 // with 8 spilled registers, and laying the psib row over the cells so that 16 waves fit the
 // LDS, both left config 5's 165 us unchanged.)
+// One member's update: `s_cell` = the wave's tw_lds_doubles(nz, nb) doubles of LDS.  The body of
+// k_thermwind, and the diagnostic phase of the persistent run kernels (coupled_run.hip), which
+// call it between two blocks of time steps of the same wave.
 template <int P, int BIG>
-__global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK)
-__attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermwind(pm_thermwind a,
-                                                                       int ops) {
-  extern __shared__ double lds_all[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int m_raw = blockIdx.x * (blockDim.x >> 6) + wave;
+__device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_raw,
+                                          double *s_cell, int lane) {
   const bool m_ok = m_raw < a.n;
   const int m = m_ok ? m_raw : a.n - 1;
   const int nz = a.nz, nb = a.nb;
   const int ngrp = (nz + 7) >> 3;
-  const int per_wave = tw_lds_doubles(nz, nb);
-  double *s_cell = lds_all + (size_t)wave * per_wave;  // [nz][TW_CELL] cells of the Psib sum
+  // s_cell: [nz][TW_CELL] cells of the Psib sum
   double *s_a = s_cell;                                // [nz]  G of the solve (before Psib)
   double *s_b = s_a + nz;                              // [nz]  I of the solve
   const bool overlay = P >= 3 && tw_overlay(nz, nb);
@@ -698,10 +695,23 @@ __attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermw
   PM_WAVE_END(m_raw)
 }
 
+template <int P, int BIG>
+__global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK)
+__attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermwind(pm_thermwind a,
+                                                                       int ops) {
+  extern __shared__ double lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m_raw = blockIdx.x * (blockDim.x >> 6) + wave;
+  const int per_wave = tw_lds_doubles(a.nz, a.nb);
+  tw_member<P, BIG>(a, ops, m_raw, lds_all + (size_t)wave * per_wave, lane);
+}
+
 // pm_thermwind_residuals: one thread per interval (a single member's mesh; the host owns
 // solve_bvp's mesh loop for CALLABLE profiles).  scipy _bvp.py: create_spline +
 // estimate_rms_residuals for y = (y0, y1), f = (y1, g); the mid-point residual of a converged
 // collocation solution is zero.
+template <int UNUSED = 0>  // (a template: the header is compiled into two translation units)
 __global__ void k_thermwind_residuals(int m, const double *x, const double *y0, const double *y1,
                                       const double *g, const double *g_lob, double *rms) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -36,6 +36,15 @@ def _rows(v, n, nz):
   return a
 
 
+def _run_fits(kind, nz, nb, ny):
+  """Do the phases of a persistent run kernel (kind 0: pm_twocol_run, 1: pm_jn2018_run) fit the
+  160 KB of LDS of a CU at 16 members per block?"""
+  import ctypes as C
+  nbytes = C.c_size_t(0)
+  _lib.check(_lib.lib.pm_run_lds_bytes(int(kind), int(nz), int(nb), int(ny), C.byref(nbytes)))
+  return 0 < nbytes.value <= 160 * 1024
+
+
 def _vec(v, n):
   a = np.asarray(v, dtype=np.float64)
   return np.full(n, a) if a.ndim == 0 else a
@@ -137,8 +146,15 @@ class TwoColEnsemble(object):
   mapped to isopycnal space every MOC_up_iters steps."""
 
   def __init__(self, cfg, stream=None, lanes_per_col=0, comm=None, n_total=None,
-               diag_iters=None, keep_history=False, arith="exact", overlap_updates=True):
-    """`overlap_updates`: with an SO channel, Psi_SO.solve and the thermal wind of an update run
+               diag_iters=None, keep_history=False, arith="exact", overlap_updates=True,
+               fused_run=None):
+    """`fused_run`: carry the members through whole stretches of the loop -- many [refresh the
+    overturning, MOC_up_iters steps] intervals -- in ONE launch of the persistent per-member
+    kernel (pm_twocol_run), ending a launch only where the diagnostics are gathered.  Same device
+    functions as the launch sequence, bit-identical results; needs: no SO channel, exact
+    arithmetic, Area constant in z, the phases' LDS within 160 KB.  None = off (measured slower
+    than the launch sequence on config 3: DESIGN.md section 6).
+    `overlap_updates`: with an SO channel, Psi_SO.solve and the thermal wind of an update run
     side by side on two streams (bit-identical results; see `_update`).
     `comm` (a pymoc_amd.sharding communicator) makes this rank's members one shard of an
     `n_total`-member ensemble: stepping is unchanged (members never interact) and
@@ -187,6 +203,15 @@ class TwoColEnsemble(object):
     if self._overlap:
       from .device import Stream, Event
       self._side, self._ev_fork, self._ev_join = Stream(), Event(), Event()
+    can_fuse = (self.so is None and arith == "exact" and self.cols.uniform_area and
+                not np.any(self.cols._flags_host & _lib.PM_COL_BZBOT) and
+                _run_fits(0, nz, self.nb, 0))
+    if fused_run and not can_fuse:
+      raise ValueError("fused_run needs: no SO channel, exact arithmetic, Area constant in z, no "
+                       "bzbot, 4 <= nz <= 256 and the phases' LDS within 160 KB")
+    self._fused_run = False if fused_run is None else bool(fused_run)
+    self.run_status = (DeviceArray.zeros((n,), np.int32, stream=stream) if self._fused_run
+                       else None)
     self._update()  # AMOC.solve(); AMOC.Psibz() [; SO.solve()] on the initial profiles
 
   # device views
@@ -238,9 +263,52 @@ class TwoColEnsemble(object):
                                   self.wA.ptr, _sh(self.stream)))
     self.cols.steps(self.wA, self.dt, n, lanes_per_col=self.lanes, arith=self.arith)
 
+  def _run_fused(self, nsteps):
+    """The same loop through pm_twocol_run: one launch per stretch that ends at a diagnostic
+    gather (or at the end of the run)."""
+    import ctypes as C
+    M, remaining = self.M, int(nsteps)
+    while remaining > 0:
+      ii = self.ii
+      k0 = ii if ii % M == 0 else (ii // M + 1) * M  # the next step followed by an update
+      last = ii + remaining - 1                       # last step of this run
+      sch = _lib.pm_run_schedule()
+      sch.m_steps = M
+      gather_at = None
+      if k0 > last:
+        sch.n_first, sch.n_updates, sch.n_last = remaining, 0, 0
+        end = last + 1
+      else:
+        sch.n_first = k0 - ii + 1
+        nu, k = 0, k0
+        while True:
+          nu += 1
+          if self.diag is not None and self.diag.due(k, self.diag_iters):
+            gather_at, tail = k, 0
+            break
+          if k + M > last:  # no further update inside this run
+            tail = last - k
+            break
+          k += M
+        sch.n_updates = nu
+        sch.n_last = tail
+        end = k + 1 + sch.n_last
+      d = _lib.pm_twocol_loop()
+      d.cols = self.cols.descriptor()
+      d.tw = self.tw.descriptor(self._b_basin, self._b_north, wA1=self.wA.ptr,
+                                wA2=self.wA.ptr + self._off, store_psib=False)
+      d.wA, d.dt, d.sched, d.status = self.wA.ptr, self.dt, sch, self.run_status.ptr
+      _lib.check(_lib.lib.pm_twocol_run(C.byref(d), _sh(self.stream)))
+      remaining -= end - ii
+      self.ii = end
+      if gather_at is not None:
+        self.gather_diagnostics(gather_at)
+
   def run(self, nsteps):
     """`for ii in range(nsteps): step both columns; if ii % MOC_up_iters == 0: update`,
     with the steps between two updates fused into one launch (wA is constant there)."""
+    if self._fused_run:
+      return self._run_fused(nsteps)
     remaining = int(nsteps)
     while remaining > 0:
       nxt = self.ii if self.ii % self.M == 0 else (self.ii // self.M + 1) * self.M
@@ -285,8 +353,13 @@ class JN2018Ensemble(object):
 
   def __init__(self, cfg, stream=None, lanes_per_col=0, use_graph=False, fused=None,
                comm=None, n_total=None, diag_iters=None, keep_history=False, arith="exact",
-               shared_coef=True):
-    """`comm`, `n_total`, `diag_iters`: as for TwoColEnsemble; the gather happens where the
+               shared_coef=True, fused_run=None):
+    """`fused_run`: whole stretches of the loop -- many [PsiSO.solve, AMOC.solve / Psibz,
+    MOC_up_iters steps] intervals -- in ONE launch of the persistent per-member kernel
+    (pm_jn2018_run), ending a launch only where diagnostics are sampled or gathered;
+    bit-identical to the launch sequence.  None = where it applies (the fused step loop's
+    conditions and the phases' LDS within 160 KB).
+    `comm`, `n_total`, `diag_iters`: as for TwoColEnsemble; the gather happens where the
     script samples its diagnostics (`if ii % Diag_iters == 0`, right after the MOC update,
     run_JansenNadeau_2018.py:218-226; default Diag_iters = 10 MOC_up_iters, :99).
     `arith="contracted"`: the columns of the fused loop step in the opt-in tolerance mode
@@ -341,6 +414,13 @@ class JN2018Ensemble(object):
     # fused: one launch per MOC block for the whole [BC switch, 2 columns, mixed layer] loop
     self._fused = (nz <= 256) if fused is None else bool(fused)
     self.recorder = None  # optional diagnostics.JN2018Diagnostics
+    can_fuse = (self._fused and self.cols.uniform_area and ny <= 64 and
+                _run_fits(1, nz, self.nb, ny))
+    if fused_run and not can_fuse:
+      raise ValueError("fused_run needs the fused step loop (Area constant in z, ny <= 64, "
+                       "4 <= nz <= 256) and the phases' LDS within 160 KB")
+    self._fused_run = can_fuse if fused_run is None else bool(fused_run)
+    self._updated_at = -1  # iteration whose MOC update has been done already (fused_run)
     self.diag_iters = (cfg.get('Diag_iters', 10 * self.M) if diag_iters is None
                        else diag_iters)
     self.diag = None
@@ -381,8 +461,13 @@ class JN2018Ensemble(object):
       self._step()
 
   def _fused_steps(self, nsteps):
-    from ._lib import check, lib, pm_jn2018, pm_so_ml
+    from ._lib import check, lib
     from .device import _sh
+    d = self._jn_descriptor()
+    check(lib.pm_jn2018_steps(self._C.byref(d), self.dt, int(nsteps), _sh(self.stream)))
+
+  def _jn_descriptor(self):
+    from ._lib import pm_jn2018, pm_so_ml
     d = pm_jn2018()
     d.n = self.n
     d.hints = _lib.PM_JN_UNIFORM_AREA if self.cols.uniform_area else 0
@@ -401,13 +486,59 @@ class JN2018Ensemble(object):
     ml.Ks, ml.h, ml.L, ml.v_pist = t.Ks, t.h, t.L, t.v_pist
     ml.status = t.status.ptr
     d.ml = ml
-    check(lib.pm_jn2018_steps(self._C.byref(d), self.dt, int(nsteps), _sh(self.stream)))
+    return d
+
+  def _stops_after_update(self, ii):
+    return ((self.recorder is not None and ii % self.recorder.Diag_iters == 0) or
+            (self.diag is not None and self.diag.due(ii, self.diag_iters)))
+
+  def _run_fused(self, nsteps):
+    """The loop through pm_jn2018_run: one launch per stretch that ends where the script samples
+    its diagnostics (right after a MOC update) or at the end of the run."""
+    from ._lib import check, lib
+    from .device import _sh
+    M, remaining = self.M, int(nsteps)
+    b_basin, b_north = self.cols.b.ptr, self.cols.b.ptr + self._off
+    while remaining > 0:
+      ii = self.ii
+      sch = _lib.pm_run_schedule()
+      sch.m_steps = M
+      fresh = self._updated_at == ii  # this iteration's update is behind us
+      sch.n_first = 0 if (ii % M == 0 and not fresh) else min(M - ii % M, remaining)
+      pos, rem = ii + sch.n_first, remaining - sch.n_first
+      blocks, stopped = [], False
+      while rem > 0:
+        if self._stops_after_update(pos):
+          blocks.append(0)
+          stopped = True
+          break
+        ns = min(M, rem)
+        blocks.append(ns)
+        pos += ns
+        rem -= ns
+      sch.n_updates, sch.n_last = len(blocks), (blocks[-1] if blocks else 0)
+      d = _lib.pm_jn2018_loop()
+      d.jn = self._jn_descriptor()
+      d.so = self.so.descriptor(b_basin, self.ml.bs)
+      d.tw = self.tw.descriptor(b_basin, b_north, Psi_SO=self.so.Psi, wA1=self.wA.ptr,
+                                wA2=self.wA.ptr + self._off,
+                                store_psib=self.recorder is not None)
+      d.dt, d.sched = self.dt, sch
+      check(lib.pm_memset(self.ml.status.ptr, 0, self.ml.status.nbytes, _sh(self.stream)))
+      check(lib.pm_jn2018_run(self._C.byref(d), _sh(self.stream)))
+      remaining -= pos - ii
+      self.ii = pos
+      if stopped:
+        self._updated_at = pos
+        self._after_update()
 
   def run(self, nsteps):
     from .device import Graph
+    if self._fused_run:
+      return self._run_fused(nsteps)
     remaining = int(nsteps)
     while remaining > 0 and self._fused:
-      if self.ii % self.M == 0:
+      if self.ii % self.M == 0 and self._updated_at != self.ii:
         self._update()
         self._after_update()
       n = min(self.M - self.ii % self.M, remaining)
@@ -425,7 +556,7 @@ class JN2018Ensemble(object):
         self.ii += self.M
         remaining -= self.M
         continue
-      if self.ii % self.M == 0:
+      if self.ii % self.M == 0 and self._updated_at != self.ii:
         self._update()
         self._after_update()
       self._step()

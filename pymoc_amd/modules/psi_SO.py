@@ -164,15 +164,18 @@ class Psi_SO(object):
     return self._run(_lib.PM_SO_OP_EKMAN, b=float(b) + 0 * self.z)[5, 0]
 
   def calc_N2(self):
+    """N^2 = db/dz on the model levels as an np.interp closure: the centred quotient
+    (b[i+1] - b[i-1]) / ((z[i+1] - z[i]) + (z[i] - z[i-1])) inside the column, the one-sided
+    quotient of the first / last interval at its two ends -- the arithmetic of psi_SO.py:142-162
+    (the kernel's s_N2 does the same per level, csrc/psi_so.hip.h)."""
     from .column import flush_all
     flush_all()
-    dz = self.z[1:] - self.z[:-1]
-    N2 = np.zeros(np.size(self.z))
-    b = self.b(self.z)
-    N2[1:-1] = (b[2:] - b[:-2]) / (dz[1:] + dz[:-1])
-    N2[0] = (b[1] - b[0]) / dz[0]
-    N2[-1] = (b[-1] - b[-2]) / dz[-1]
-    return make_func(N2, self.z, 'N2')
+    z = self.z
+    b = self.b(z)
+    h, db = np.diff(z), np.diff(b)
+    first, last = db[0] / h[0], db[-1] / h[-1]
+    inner = (b[2:] - b[:-2]) / (h[1:] + h[:-1])
+    return make_func(np.concatenate(([first], inner, [last])), z, 'N2')
 
   # The two quadratic tapers of psi_SO.py:164-216 (host NumPy; the kernel applies the same
   # expressions per level).  `H is None` means "no taper".

@@ -70,6 +70,11 @@ class PsiSOBatch(object):
     self.KGM.upload(np.full(self.n, k) if k.ndim == 0 else k, self.stream)
 
   def update(self, b, bs, ops=_lib.PM_SO_OP_SOLVE):
+    d = self.descriptor(b, bs)
+    check(lib.pm_psi_so_update(C.byref(d), int(ops), _sh(self.stream)))
+
+  def descriptor(self, b, bs):
+    """The pm_psi_so of an update of this batch (also a member of pm_jn2018_loop)."""
     o = self.opts
     d = pm_psi_so()
     d.n, d.nz, d.ny = self.n, self.nz, self.ny
@@ -89,4 +94,4 @@ class PsiSOBatch(object):
     d.Psi, d.Psi_Ek, d.Psi_GM = self.Psi.ptr, self.Psi_Ek.ptr, self.Psi_GM.ptr
     d.Ek_raw, d.GM_raw, d.ys = _ptr(self.Ek_raw), _ptr(self.GM_raw), _ptr(self.ys)
     d.status = self.status.ptr
-    check(lib.pm_psi_so_update(C.byref(d), int(ops), _sh(self.stream)))
+    return d

@@ -40,10 +40,9 @@ class ThermwindBatch(object):
       return None
     return x.ptr if isinstance(x, DeviceArray) else int(x)
 
-  def update(self, b1, b2, ops=_lib.PM_TW_SOLVE | _lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ,
-             Psi_SO=None, wA1=None, wA2=None, nb=None, store_psib=True):
-    """store_psib=False keeps `psib` / `bgrid` in the kernel's LDS only (the remap to the
-    columns' levels does not need them in HBM: 2 x 8 nb bytes per member and update saved)."""
+  def descriptor(self, b1, b2, Psi_SO=None, wA1=None, wA2=None, nb=None, store_psib=True):
+    """The pm_thermwind of an update of this batch (also a member of pm_twocol_loop /
+    pm_jn2018_loop, the persistent run kernels)."""
     d = pm_thermwind()
     d.n, d.nz, d.nb, d.reserved = self.n, self.nz, int(nb or self.nb), 0
     if d.nb > self.nb:
@@ -53,4 +52,11 @@ class ThermwindBatch(object):
     d.bgrid, d.psib = (self.bgrid.ptr, self.psib.ptr) if store_psib else (None, None)
     d.psibz1, d.psibz2 = self.psibz1.ptr, self.psibz2.ptr
     d.Psi_SO, d.wA1, d.wA2 = self._ptr(Psi_SO), self._ptr(wA1), self._ptr(wA2)
+    return d
+
+  def update(self, b1, b2, ops=_lib.PM_TW_SOLVE | _lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ,
+             Psi_SO=None, wA1=None, wA2=None, nb=None, store_psib=True):
+    """store_psib=False keeps `psib` / `bgrid` in the kernel's LDS only (the remap to the
+    columns' levels does not need them in HBM: 2 x 8 nb bytes per member and update saved)."""
+    d = self.descriptor(b1, b2, Psi_SO, wA1, wA2, nb, store_psib)
     check(lib.pm_thermwind_update(C.byref(d), int(ops), _sh(self.stream)))
