@@ -31,6 +31,11 @@ Sets:
   G17 sweep_full       sweep members over the configured run length of configs 2-5; the two
                        config-5 members the reference itself blows up on
   G18 range_evidence   the reference blowing up at the SURVEY 8d sweep values configs.py drops
+  G19 c5_conditioning  the REFERENCE against ITSELF on the config-5 sweep members: its distance
+                       from its own unperturbed run when an initial profile is moved by one ulp
+                       (the conditioning that bounds any config-5 trajectory claim), and the
+                       bottom cell's thickness b[1]-b[0] of both columns at every MOC update
+                       (the quantity whose sign Psib keys on: psi_thermwind.py:177-183)
   G14 thermwind_callable  Psi_Thermwind.solve with CALLABLE profiles (hazard H7: solve_bvp evaluates
                        them at its collocation midpoints and refines the mesh)
   G15 psi_so_callable  Psi_SO.solve with CALLABLE bs / tau (evaluated between grid points by the
@@ -767,6 +772,59 @@ def g17_sweep_full():
 
 
 # ------------------------------------------------------------------------ G18
+# ------------------------------------------------------------------------ G19
+def g19_config5_conditioning():
+  """What a config-5 trajectory claim can be measured against.
+
+  Psi_Thermwind.Psib (psi_thermwind.py:177-183) takes the bottom cell's bounds from the column
+  the transport comes from and divides by their difference; under the script's no-flux bottom BC
+  (run_JansenNadeau_2018.py:242-244: basin.bbot = basin.b[1]) that difference is ONE step's
+  increment of level 1 -- last-bit noise near equilibrium -- and its sign decides whether the
+  cell's transport is counted.  So the reference is ill-conditioned in its own inputs:
+    * `pert_dist[member][k][sample]`: the reference run with initial profile k moved by one ulp
+      (k = 0: b_basin0 up, 1: b_basin0 down, 2: b_north0 up, 3: bs_SO_init up), distance
+      max_field max|x - x0| / max|x0| from the UNPERTURBED reference run at the 72-step samples of
+      fixture G17 -- the envelope any other correct implementation's distance is compared with;
+    * `bottom_*[member][update]`: b[1]-b[0] and b[1] of both columns as the reference holds them
+      at every MOC update ii = 0, 36, ..., 3564, and `bottom_u0` = -(Psi[1]-Psi[0]) of that
+      update's thermal-wind solve (:175; u0 < 0 takes the NORTHERN column's bounds for the
+      bottom cell, :177-181): the branch (column, sign of its thickness) Psib takes for the
+      bottom cell at every update, for the teacher-forced window tests."""
+  c5 = configs.config5(N=4096)
+  pick = np.arange(0, 4096, 512)
+  M = int(c5['MOC_up_iters'])
+  stored = list(range(2 * M, 3600 + 1, 2 * M))
+  updates = list(range(0, 3600, M))
+  keys = ('b_basin', 'b_north', 'bs_SO', 'Psi_SO')
+  ulp_up = lambda a: np.nextafter(a, np.inf)  # noqa: E731
+  ulp_dn = lambda a: np.nextafter(a, -np.inf)  # noqa: E731
+  perts = [('b_basin0', ulp_up), ('b_basin0', ulp_dn), ('b_north0', ulp_up), ('bs_SO_init', ulp_up)]
+  dist = np.zeros((pick.size, len(perts), len(stored)))
+  bot = {k: np.zeros((pick.size, len(updates))) for k in
+         ('bottom_basin_d', 'bottom_basin_b1', 'bottom_north_d', 'bottom_north_b1', 'bottom_u0')}
+  for j, i in enumerate(pick):
+    m = configs.member(c5, i, 5)
+    s0 = ref_jn2018(m, 3600, set(stored) | set(updates[1:]))
+    for u, t in enumerate(updates):
+      Psi = s0[t + M]['Psi']  # the snapshot M steps later still holds this update's solve
+      bot['bottom_u0'][j, u] = -(Psi[1] - Psi[0])
+      bb = m['b_basin0'] if t == 0 else s0[t]['b_basin']
+      bn = m['b_north0'] if t == 0 else s0[t]['b_north']
+      bot['bottom_basin_d'][j, u], bot['bottom_basin_b1'][j, u] = bb[1] - bb[0], bb[1]
+      bot['bottom_north_d'][j, u], bot['bottom_north_b1'][j, u] = bn[1] - bn[0], bn[1]
+    for k, (field, move) in enumerate(perts):
+      mp = dict(m)
+      mp[field] = move(np.array(m[field], dtype=np.float64))
+      sp = ref_jn2018(mp, 3600, set(stored))
+      for ti, t in enumerate(stored):
+        dist[j, k, ti] = max(np.abs(sp[t][f] - s0[t][f]).max() / np.abs(s0[t][f]).max()
+                             for f in keys)
+    print("config 5 member", i, "reference vs itself + 1 ulp: max distance",
+          dist[j].max(axis=1), flush=True)
+  save("c5_conditioning", members=pick, steps=np.array(stored), updates=np.array(updates),
+       pert_fields=np.array([p[0] for p in perts]), pert_dist=dist, **bot)
+
+
 def _ref_blowup_step(run, nsteps, probe):
   """First 1-based step after which `probe()` is non-finite when `run(ii)` is stepped, or the
   step at which the reference raised (NaNs reaching brentq / solve_bvp raise ValueError)."""
@@ -1023,11 +1081,12 @@ def g9_twobasin():
 
 
 if __name__ == "__main__":
-  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+  which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
   table = dict(g1=[g1_column_steps], g2=[g2_config1], g3=[g3_thermwind], g4=[g4_twocol],
                g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
                g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column], g14=[g14_thermwind_callable], g15=[g15_psi_so_callable],
-               g16=[g16_thermwind_nonfinite], g17=[g17_sweep_full], g18=[g18_range_evidence])
+               g16=[g16_thermwind_nonfinite], g17=[g17_sweep_full], g18=[g18_range_evidence],
+               g19=[g19_config5_conditioning])
   for w in which:
     for fn in table[w]:
       fn()

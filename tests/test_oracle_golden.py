@@ -540,3 +540,124 @@ def test_range_evidence_reference_blows_up_outside_narrowed_ranges():
                             {int(g["c1_blowup_step"][1]) - 1, int(g["c1_blowup_step"][1])})
   n = int(g["c1_blowup_step"][1])
   assert np.isfinite(bad[n - 1]["b"]).all() and not np.isfinite(bad[n]["b"]).all()
+
+
+# ------------------------------- G19 config 5 against the reference's OWN conditioning
+def c5_envelope(gc):
+  """Running maximum over the samples of the worst distance of the reference from ITSELF when
+  one of its initial profiles is moved by one ulp (fixture G19, 8 members x 4 perturbations)."""
+  return np.maximum.accumulate(gc["pert_dist"].max(axis=(0, 1)))
+
+
+def check_config5_envelope(traj, g, gc, j):
+  """A trajectory's distance from the reference, sample by sample, against what the reference
+  does to itself under a one-ulp perturbation (factor 2: the perturbation runs are a sample of
+  the possible flips, not their supremum).  Returns the largest ratio distance / envelope."""
+  env = c5_envelope(gc)
+  assert list(gc["steps"]) == list(g["c5_steps"])
+  worst = 0.
+  for ti, t in enumerate(int(t) for t in g["c5_steps"]):
+    e = max(relerr(traj[t][k], g["c5_" + k][j][ti]) for k in C5_KEYS)
+    assert e <= max(1e-10, 2 * env[ti]), (j, t, e, env[ti])
+    worst = max(worst, e / env[ti])
+  return worst
+
+
+def c5_window_config(c, g):
+  """Teacher-forced windows: an ensemble whose members are (sweep member j, window k) pairs --
+  the parameters of member j, started from the REFERENCE's stored state at step 72 k (k = 0: the
+  cold start) -- and, per pair, (j, k).  Window k is compared with the reference's snapshot at
+  step 72 (k + 1).  (A restart needs b_basin, b_north, bs_SO only: the script re-decides
+  basin.bbot / kappa every step, run_JansenNadeau_2018.py:233-254.)"""
+  idx, nw = [int(i) for i in g["c5_members"]], len(g["c5_steps"])
+  rows = [(j, k) for j in range(len(idx)) for k in range(nw)]
+  cfg = dict(c)
+  for key in configs.PER_MEMBER[5]:
+    cfg[key] = np.stack([np.asarray(c[key])[idx[j]] for j, _ in rows])
+  for r, (j, k) in enumerate(rows):
+    if k > 0:
+      cfg["b_basin0"][r] = g["c5_b_basin"][j][k - 1]
+      cfg["b_north0"][r] = g["c5_b_north"][j][k - 1]
+      cfg["bs_SO0"][r] = g["c5_bs_SO"][j][k - 1]
+  cfg["members"] = np.arange(len(rows))
+  return cfg, rows
+
+
+def c5_bottom_branch(u0, b_basin, b_north):
+  """The branch Psi_Thermwind.Psib takes for the BOTTOM cell (psi_thermwind.py:175-183): which
+  column bounds the cell (u0 < 0: the northern one) and the sign of that column's b[1] - b[0],
+  the denominator of the cell's mask.  Under the no-flux bottom BC that thickness is one step's
+  increment of level 1 -- often +-1 ulp or exactly 0 -- so two correct implementations can take
+  different branches at an update: a "flip" (the reference parts from itself the same way)."""
+  north = u0 < 0
+  d = (b_north[1] - b_north[0]) if north else (b_basin[1] - b_basin[0])
+  return (bool(north), float(np.sign(d)))
+
+
+def check_config5_windows(rows, g, gc, mid, end, label=""):
+  """mid[r] / end[r]: {field: array} of window-member r after 36 / 72 steps (end also holds
+  'Psi' of the update at local step 36).  Every window whose second MOC update takes the
+  reference's branch for the bottom cell must reproduce the reference's next snapshot to 1e-10;
+  the others are counted and held to the reference's own conditioning."""
+  env_max = float(gc["pert_dist"].max())
+  flips, worst_clean, worst_flip = [], 0., 0.
+  for r, (j, k) in enumerate(rows):
+    u = 2 * k + 1  # the update inside the window: iteration 72 k + 36
+    ref = c5_bottom_branch(gc["bottom_u0"][j][u], [0., gc["bottom_basin_d"][j][u]],
+                           [0., gc["bottom_north_d"][j][u]])
+    Psi = end[r]["Psi"]
+    got = c5_bottom_branch(-(Psi[1] - Psi[0]), mid[r]["b_basin"], mid[r]["b_north"])
+    e = max(relerr(end[r][f], g["c5_" + f][j][k]) for f in C5_KEYS)
+    if got == ref:
+      assert e <= 1e-10, (label, "member", j, "window", k, e)
+      worst_clean = max(worst_clean, e)
+    else:
+      flips.append((j, k))
+      assert e <= 2 * env_max, (label, "member", j, "window", k, e)
+      worst_flip = max(worst_flip, e)
+  return flips, worst_clean, worst_flip
+
+
+def test_config5_reference_conditioning_fixture():
+  """What the fixture says about the REFERENCE: moved by one ulp in b_basin0 it ends 5e-3 ... 1e-2
+  from its own unperturbed run on every sampled member -- the scale any config-5 trajectory
+  tolerance has to be read against."""
+  gc = load_golden("c5_conditioning")
+  d = gc["pert_dist"]
+  assert d.shape == (8, 4, 50)
+  assert (d[:, 0, :].max(axis=1) >= 5e-3).all() and d.max() <= 2e-2
+  # the thickness of the NORTHERN column's bottom cell at the MOC updates: within 2 ulp of zero
+  # in 9 of 10 updates, exactly zero in half of them
+  r = np.abs(gc["bottom_north_d"]) / np.spacing(np.abs(gc["bottom_north_b1"]))
+  assert np.mean(r <= 2) >= 0.9 and np.mean(r == 0) >= 0.4
+
+
+def test_config5_oracle_inside_the_references_own_envelope():
+  """The oracle's full-length config-5 trajectories (8 sweep members x 3600 steps), sample by
+  sample, are no further from the reference than the reference is from itself under a one-ulp
+  perturbation."""
+  g, gc = load_golden("sweep_full"), load_golden("c5_conditioning")
+  c = configs.config5(N=4096)
+  steps = [int(t) for t in g["c5_steps"]]
+  worst = [check_config5_envelope(drivers.run_jn2018(configs.member(c, i, 5), 3600, steps), g, gc, j)
+           for j, i in enumerate(g["c5_members"])]
+  assert max(worst) <= 2.0, worst
+
+
+def test_config5_oracle_teacher_forced_windows():
+  """Restarted from the reference's stored state at each of the 50 sample steps and run for 72
+  steps (8 members x 50 windows): every window whose inner MOC update takes the reference's
+  branch for Psib's bottom cell reproduces the reference's next snapshot to 1e-10; the windows
+  that take the other branch are few and stay inside the reference's own conditioning."""
+  g, gc = load_golden("sweep_full"), load_golden("c5_conditioning")
+  c = configs.config5(N=4096)
+  cfg, rows = c5_window_config(c, g)
+  mid, end = [], []
+  for r in range(len(rows)):
+    s = drivers.run_jn2018(configs.member(cfg, r, 5), 72, {36, 72})
+    mid.append(s[36])
+    end.append(s[72])
+  flips, wc, wf = check_config5_windows(rows, g, gc, mid, end, "oracle")
+  print("oracle: %d of %d windows take another bottom-cell branch than the reference; worst clean "
+        "window %.2e, worst flip window %.2e" % (len(flips), len(rows), wc, wf))
+  assert len(flips) <= len(rows) // 4, flips

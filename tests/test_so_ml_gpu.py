@@ -340,11 +340,48 @@ def test_config5_full_length_sweep_vs_reference(gpu, arith):
       traj[j][t] = {k: st[k][i] for k in ("b_basin", "b_north", "bs_SO", "Psi_SO")}
   clean = [check_config5_full(traj[j], g, j) for j in range(len(idx))]
   print("config 5, %s: followed to 1e-10 until step" % arith, clean)
+  # ... and sample by sample no further from the reference than the reference is from ITSELF when
+  # an initial profile is moved by one ulp (fixture G19)
+  from test_oracle_golden import check_config5_envelope
+  gc = load_golden("c5_conditioning")
+  ratios = [check_config5_envelope(traj[j], g, gc, j) for j in range(len(idx))]
+  print("config 5, %s: largest distance / reference's own one-ulp envelope" % arith, ratios)
   assert sum(t == 3600 for t in clean) >= (2 if arith == "exact" else 1), clean  # no drift where no Psib flip happens
   assert np.median(clean) >= (1000 if arith == "exact" else 144), clean
   assert list(ens.nonfinite_members()) == list(g["c5_blowup_members"]) == [2, 1268]
   ens.run(72)  # the bench's 72 warm-up + 3600 steps
   assert list(ens.nonfinite_members()) == [2, 1268]
+
+
+@pytest.mark.parametrize("arith", ["exact", "contracted"])
+def test_config5_teacher_forced_windows_vs_reference(gpu, arith):
+  """The 3600 steps of config 5 pinned WINDOW BY WINDOW: the engine restarted
+  from the reference's stored state at each of the 50 sample steps of fixture G17 and run for 72
+  steps -- 8 sweep members x 50 windows = 400 members of one ensemble.  Every window whose inner
+  MOC update takes the reference's branch for the bottom cell of Psi_Thermwind.Psib
+  (psi_thermwind.py:177-183; fixture G19 holds the reference's branch at every update) must
+  reproduce the reference's next snapshot to 1e-10; windows taking the other branch ("flips") are
+  counted and must stay inside the reference's own one-ulp conditioning.  All 8 members, both
+  arithmetic modes."""
+  from test_oracle_golden import c5_window_config, check_config5_windows
+  g, gc = load_golden("sweep_full"), load_golden("c5_conditioning")
+  c = configs.config5(N=4096)
+  cfg, rows = c5_window_config(c, g)
+  cfg["rest_mask"] = np.repeat(c["rest_mask"][None], len(rows), axis=0)
+  ens = gpu.JN2018Ensemble(cfg, arith=arith)
+  ens.run(36)
+  s36 = ens.state()
+  ens.run(36)
+  s72 = ens.state()
+  assert ens.nonfinite_members().size == 0
+  mid = [{k: s36[k][r] for k in ("b_basin", "b_north")} for r in range(len(rows))]
+  end = [{k: s72[k][r] for k in ("b_basin", "b_north", "bs_SO", "Psi_SO", "Psi")}
+         for r in range(len(rows))]
+  flips, wc, wf = check_config5_windows(rows, g, gc, mid, end, arith)
+  print("config 5, %s: %d of %d teacher-forced windows take another bottom-cell branch than the "
+        "reference %s; worst clean window %.2e, worst flip window %.2e" %
+        (arith, len(flips), len(rows), flips[:8], wc, wf))
+  assert len(flips) <= len(rows) // 4, flips
 
 
 def test_config5_blowup_members_go_at_the_references_step(gpu):
