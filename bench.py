@@ -25,6 +25,12 @@ or plain `python bench.py --gpus N ...`, which starts the N ranks itself through
 pymoc_amd/launch.py (no torch anywhere in the product).  RCCL barrier + device sync on
 both sides of the timed region, max over ranks, rank 0 prints the line.
 
+The line is compact (numbers only; what every key means, the flop / byte models and where each
+figure can be recomputed from profiles/ is DESIGN.md section 6) and ENDS with the coupled
+configs' blocks "c3", "c4", "c5", so that a record keeping only the tail of the line still holds
+them.  Every coupled roofline is computed from the RUN-AVERAGE duration of the dominant kernel:
+HIP events around every launch of a full-length run (pymoc_amd.device.LaunchTimer).
+
 The CPU baselines (oracle/, the plain-C restatement of the reference's algorithm driven
 member by member like the reference's loops) are timed FIRST, before this process touches
 the GPU: on 1 core and on all cores this process may use (`multiprocessing`, fork).
@@ -54,22 +60,6 @@ SIZES = {  # per-GPU members and run length of each config (SURVEY.md section 8d
     4: dict(members=8192, nsteps=2400, ncol=2),
     5: dict(members=4096, nsteps=3600, ncol=2),
 }
-WORKLOAD = {
-    2: "BASELINE configs[1]: ensemble of %d independent Columns nz=%d fp64 per GPU, static wA, "
-       "do_conv on odd members, dt=30 d (pymoc_amd.configs.config2, seed 20240)",
-    3: "BASELINE configs[2]: %d two-column + Psi_Thermwind members per GPU (example_twocol.py "
-       "physics, nz=%d, MOC_up_iters=24, nb=500; pymoc_amd.configs.config3, seed 20241; SURVEY 8d "
-       "parameter ranges NARROWED to where the reference itself stays finite: kappa_4k <= 2.5e-4, "
-       "fixture G18)",
-    4: "BASELINE configs[3]: %d two-column + SO-channel members per GPU (example_twocol_plusSO.py"
-       " physics, nz=%d, ny=40, c=0.1 GM boundary-value smoother; pymoc_amd.configs.config4, "
-       "seed 20242; GM boundary-value problem on scipy solve_bvp's adaptive mesh; SURVEY 8d ranges "
-       "NARROWED to where the reference itself stays finite: A_basin >= 4.5e13, fixture G18)",
-    5: "BASELINE configs[4]: %d run_JansenNadeau_2018.py members per GPU (nz=%d, dt=10 d, "
-       "ny=51, MOC_up_iters=36, nb=500; pymoc_amd.configs.config5, seed 20243; SURVEY 8d ranges "
-       "NARROWED to where the reference itself stays finite: db <= 8e-4, fixture G18)",
-}
-
 
 # ------------------------------------------------------------------------- flop models
 def flops_column_step(nz):
@@ -158,21 +148,14 @@ def cpu_baseline(config, nz, budget_1=6.0, budget_all=6.0, max_workers=0):
     res = pool.map(_cpu_worker, jobs, chunksize=1)
   wall = time.perf_counter() - t0
   rate_all = sum(u / t for u, t in res)
-  what = {2: "the config-2 column batch stepped 250 steps at a time",
-          3: "full 2400-step example_twocol member runs",
-          4: "full 2400-step example_twocol_plusSO member runs (GM BVP on solve_bvp's adaptive mesh)",
-          5: "full 3600-step run_JansenNadeau_2018 member runs"}[config]
-  base = {"value": u1 / t1, "unit": unit, "cores": 1, "kind": "port",
-          "sample": "%s, members [0,%d) of the same ensemble, %.1f s on 1 core "
-                    "(oracle/pymoc_oracle.c gcc -O2 + oracle/drivers.py, member by member "
-                    "like the reference's loops)" % (what, min(n, 64), t1),
-          "coupled_steps_per_s": u1 / t1 / size["ncol"],
-          "all_cores": {"value": rate_all, "unit": unit, "cores": workers,
-                        "host_cores": os.cpu_count(), "usable_cores": cores,
-                        "coupled_steps_per_s": rate_all / size["ncol"],
-                        "sample": "%d forked workers x %.1f s, each on its own %d-member "
-                                  "slice (%.1f s wall incl. start-up)" %
-                                  (workers, budget_all, per, wall)}}
+  what = {2: "oracle C port, 250-step launches of the column batch",
+          3: "oracle, full 2400-step member runs",
+          4: "oracle, full 2400-step member runs (adaptive GM mesh)",
+          5: "oracle, full 3600-step member runs"}[config]
+  base = {"value": sig(u1 / t1), "unit": unit, "cores": 1, "kind": "port",
+          "sample": "%s, members [0,%d), %.1f s" % (what, min(n, 64), t1),
+          "all_cores": {"value": sig(rate_all), "cores": workers,
+                        "sample": "%d workers x %.1f s" % (workers, budget_all)}}
   return base
 
 
@@ -188,6 +171,14 @@ def time_calls(fn, reps, stream, Event, warm=2):
   e1.record(stream)
   stream.sync()
   return e0.elapsed_ms(e1) / reps
+
+
+def sig(x, n=5):
+  """n significant digits (keeps the JSON line short)."""
+  if x is None:
+    return None
+  x = float(x)
+  return x if not math.isfinite(x) else float("%.*g" % (n, x))
 
 
 def load_json(path):
@@ -210,6 +201,28 @@ def run_steps(batch, wA, dt, nsteps, per_launch, lanes, arith="exact"):
 
 
 # ------------------------------------------------------------------------- config 2
+WORKLOAD_SHORT = {
+    2: "BASELINE configs[1]: %d independent Columns x nz=%d fp64 per GPU, static wA, do_conv on odd "
+       "members, dt=30 d (pymoc_amd.configs.config2)",
+    3: "BASELINE configs[2]: %d example_twocol.py members per GPU, nz=%d, MOC_up_iters=24, nb=500 "
+       "(configs.config3; kappa_4k <= 2.5e-4: fixture G18)",
+    4: "BASELINE configs[3]: %d example_twocol_plusSO.py members per GPU, nz=%d, ny=40, c=0.1 GM BVP "
+       "on solve_bvp's adaptive mesh (configs.config4; A_basin >= 4.5e13: G18)",
+    5: "BASELINE configs[4]: %d run_JansenNadeau_2018.py members per GPU, nz=%d, dt=10 d, ny=51, "
+       "MOC_up_iters=36, nb=500 (configs.config5; db <= 8e-4: G18)",
+}
+
+
+def profile_counters():
+  """SQ / TCC counters of separate rocprofv3 --pmc passes, replayed (never measured in a bench
+  run): the newest profiles/rNN/counters.json."""
+  for r in ("r04", "r03"):
+    d = load_json(os.path.join(ROOT, "profiles", r, "counters.json"))
+    if d:
+      return d, r
+  return {}, None
+
+
 def bench_config2(args, env):
   pymoc_amd, configs, DeviceArray, Event = (env["pymoc_amd"], env["configs"],
                                             env["DeviceArray"], env["Event"])
@@ -271,91 +284,44 @@ def bench_config2(args, env):
   flop = flops_column_step(nz) * C * F
   alg_bytes = 24.0 * nz * C * F  # read b, read wA, write b per model step
   tf = flop / launch_s / 1e12
-  prof = load_json(os.path.join(ROOT, "profiles", "r03", "counters.json"))
-  key = "c2/" + batch.kernel_name(F, args.lanes)
+  prof, prof_round = profile_counters()
+  kname = batch.kernel_name(F, args.lanes)
+  cnt = prof.get("c2/" + kname) or {}
   out = {
       "metric": "column-timesteps/sec (ensemble) at nz=%d" % nz,
-      "value": value, "unit": "column-timesteps/s", "n_gpus": world, "steps": K,
-      "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
+      "value": sig(value, 6), "unit": "column-timesteps/s", "n_gpus": world, "steps": K,
+      "warmup": W, "ms_per_step": sig(elapsed * 1e3 / K), "higher_is_better": True,
       "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-      "config": {
-          "workload": WORKLOAD[2] % (C, nz), "columns_per_gpu": C, "nz": nz,
-          "model_steps_per_step": F,
-          "step": "one launch = %d Column.timestep calls of every column" % F,
-          "lanes_per_column": G, "levels_per_lane": P,
-          "parallelism": "ensemble sharded over %d GPU(s), RCCL all-gather of the final "
-                         "state" % world},
-      "roofline": {
-          "bound": "fp64-valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-          "frac": tf / FP64_PEAK_TFLOPS,
-          "kernel": batch.kernel_name(F, args.lanes),
-          "kernel_ms_per_launch": launch_s * 1e3, "launches": launches,
-          "flop_model": "14*(nz-2) = %d flop per column-step (SURVEY 8d), x %d columns x %d "
-                        "fused steps per launch; the peak counts an FMA as 2 flop, this "
-                        "arithmetic (the reference's, unfused, 3 divisions per level) cannot "
-                        "use FMAs for its adds/multiplies" % (flops_column_step(nz), C, F),
-          "issue_frac": (prof.get(key) or {}).get("issue_frac"),
-          "issue_frac_source": "share of a resident wave's life spent issuing vector "
-                               "instructions, SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both count "
-                               "quad-cycles); replayed from profiles/r03/counters.json entry '%s' "
-                               "(separate rocprofv3 --pmc pass on the 1024 x 100 x 1000 workload, "
-                               "not measured in this run)" % key,
-          "traffic": (prof.get(key) or {}).get("hbm_bytes_per_launch"),
-          "traffic_source": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch -- the guide's gfx950 "
-                            "corrections: FETCH_SIZE tallies 128-B requests at 64 B, WRITE_SIZE is "
-                            "exact; replayed from profiles/r03/counters.json (not measured in this "
-                            "run)",
-          "profiled_kernel_avg_us": (prof.get(key) or {}).get("avg_us"),
-          "profiled_kernel_avg_us_source": "rocprofv3 --kernel-trace --stats of `bench.py --config 2 "
-                                           "--no-coupled --no-single-step`: "
-                                           "profiles/r03/c2_kernel_stats.csv",
-          "algorithmic_bytes_per_launch": alg_bytes,
-          "algorithmic_hbm_GBps": alg_bytes / launch_s / 1e9,
-          "why_not_hbm": "with %d steps fused per launch the state stays in registers: HBM "
-                         "sees the compulsory 48*nz B per column per LAUNCH, so the "
-                         "algorithmic 24*nz B per column-step is not traffic and HBM is not "
-                         "the roof; see roofline_hbm_regime for the regime where it is" % F},
-      "nonfinite_columns": nonfinite,
-      "checksum": float(np.sum(b_final)),
-      "contracted_mode": {
-          "what": "opt-in tolerance mode (PM_OP_CONTRACTED / ColumnBatch.steps(arith='contracted')): "
-                  "b_i += cu_i (b_{i+1}-b_i) + cl_i (b_i-b_{i-1}) with per-launch coefficients, "
-                  "one subtraction + two fma per level instead of the reference's 21-instruction "
-                  "operation order; NOT the headline (`value` is the bit-identical default mode)",
-          "column_timesteps_per_s": C * F / (tol_ms * 1e-3),
-          "kernel": batch.kernel_name(F, args.lanes, arith="contracted"),
-          "kernel_ms_per_launch": tol_ms,
-          "max_rel_diff_to_exact_mode": tol_err,
-          "tolerance": "<= 1e-12 relative to the reference over BASELINE's runs "
-                       "(tests/test_column_gpu.py::test_contracted_mode_vs_reference_goldens)",
-          "roofline": {"bound": "fp64-valu", "achieved": flop / (tol_ms * 1e-3) / 1e12,
-                       "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": flop / (tol_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                       "flop_model": "the same 14*(nz-2) algorithmic flop per column-step as the "
-                                     "exact mode (what the reference computes); the contracted "
-                                     "form ISSUES 5*(nz-2): frac_issued below",
-                       "frac_issued": 5.0 * (nz - 2) * C * F / (tol_ms * 1e-3) / 1e12 /
-                                      FP64_PEAK_TFLOPS}},
+      "config": {"workload": WORKLOAD_SHORT[2] % (C, nz), "columns_per_gpu": C, "nz": nz,
+                 "model_steps_per_step": F, "kernel": kname,
+                 "parallelism": "ensemble sharded over %d GPU(s), RCCL all-gather of the final "
+                                "state" % world},
+      "roofline": {"bound": "fp64-valu", "achieved": sig(tf), "peak": FP64_PEAK_TFLOPS,
+                   "unit": "TFLOP/s", "frac": sig(tf / FP64_PEAK_TFLOPS, 4),
+                   "traffic": cnt.get("hbm_bytes_per_launch"), "kernel_us": sig(launch_s * 1e6),
+                   "issue_frac": cnt.get("issue_frac"), "counters": prof_round,
+                   "alg_bytes": alg_bytes, "alg_hbm_GBps": sig(alg_bytes / launch_s / 1e9)},
+      "nonfinite": nonfinite, "checksum": float(np.sum(b_final)),
+      "contracted": {"value": sig(C * F / (tol_ms * 1e-3)), "kernel_us": sig(tol_ms * 1e3),
+                     "frac": sig(flop / (tol_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+                     "max_rel_diff": sig(tol_err, 3)},
   }
   if not args.no_single_step:
     # one step per launch (b, wA and the static coefficients cross HBM/L2 every step): the
     # regime of BASELINE config 1 and of user loops that refresh Psi every step
     ms1 = time_calls(lambda: batch.steps(wA, dt, 1, lanes_per_col=args.lanes), 2000, stream,
                      Event, warm=200)
-    out["single_step_launches"] = {
-        "ms_per_step": ms1, "column_timesteps_per_s": C / (ms1 * 1e-3),
-        "hbm_GBps_if_streamed": 48.0 * nz * C / (ms1 * 1e-3) / 1e9,
-        "note": "launch-latency-bound at %d columns" % C}
+    out["single_step_us"] = sig(ms1 * 1e3)
   if not args.no_single_step and world == 1 and C == 1024 and nz == 100:
     # the SAME kernel where HBM does bind: one step per launch on an ensemble far beyond the
-    # caches (262144 columns: 1.26 GB cross HBM per launch)
+    # caches (262144 columns: 0.84 ... 1.26 GB cross HBM per launch)
     Cb = 262144
     cb = configs.config2(N=Cb, nz=nz)
     big = pymoc_amd.ColumnBatch(cb["z"], cb["kappa"], cb["Area"], cb["b0"], bs=cb["bs"],
                                 bbot=cb["bbot"], N2min=cb["N2min"], do_conv=cb["do_conv"],
                                 stream=stream)
     wAb = DeviceArray.from_host(cb["wA"], stream=stream)
-    # the C-ABI default first: no hints, every array streamed
+    # the C-ABI default first: no hints, every array streamed (48 nz B per column-step)
     hints = big._flags_host.copy()
     big._flags_host = (hints & ~np.int32(pymoc_amd._lib.PM_COL_UNIFORM_AREA)).astype(np.int32)
     big.flags.upload(big._flags_host, stream)
@@ -363,50 +329,33 @@ def bench_config2(args, env):
                      Event, warm=3)
     big._flags_host = hints
     big.flags.upload(hints, stream)
-    # the same step with the forcing precombined once per overturning update (weff = wA -
-    # d(A kappa)/dz, PM_OP_WEFF) and Area read as one number per column (PM_COL_UNIFORM_AREA):
-    # b and weff and kappa in, b out = 32 nz B per column-step
+    # forcing precombined once per overturning update (PM_OP_WEFF) + uniform Area:
+    # b, weff, kappa in, b out = 32 nz B per column-step
     weffb = big.combine_forcing(wAb)
     msw = time_calls(lambda: big.steps(weffb, dt, 1, lanes_per_col=args.lanes, precombined=True),
                      20, stream, Event, warm=3)
-    real = 32.0 * nz * Cb
-    mix = load_json(os.path.join(ROOT, "profiles", "hbm_mix.json"))
-    gbps = real / (msw * 1e-3) / 1e9
-    out["roofline_hbm_regime"] = {
-        "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": gbps / HBM_PEAK_GBPS,
-        "workload": "the same kernel, ONE step per launch on %d columns x nz=%d, forcing "
-                    "precombined per overturning update (PM_OP_WEFF), uniform Area" % (Cb, nz),
-        "bytes_model": "32*nz B per column-step: b, weff = wA - d(A kappa)/dz and kappa in, b out "
-                       "(SURVEY 8d's 24*nz + the one coefficient array the step cannot do "
-                       "without)",
-        "kernel": big.kernel_name(1, args.lanes), "kernel_ms_per_launch": msw,
-        "column_timesteps_per_s": Cb / (msw * 1e-3),
-        "algorithmic_frac": 24.0 * nz * Cb / (msw * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-        "algorithmic_frac_note": "SURVEY 8d's algorithmic 24*nz B per column-step over the same "
-                                 "time, as a fraction of the HBM peak",
-        "all_arrays_streamed": {
-            "bytes_model": "48*nz B per column-step: b, wA, kappa, Area, d(A kappa)/dz in, b out "
-                           "(no hints; the C-ABI default)",
-            "kernel_ms_per_launch": msb, "achieved": 48.0 * nz * Cb / (msb * 1e-3) / 1e9,
-            "frac": 48.0 * nz * Cb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "column_timesteps_per_s": Cb / (msb * 1e-3)},
-        "achievable": mix.get("five_reads_one_write_GBps"),
-        "achievable_source": "plain 5-reads + 1-write streaming kernel of the 48*nz footprint "
-                             "(profiles/ubench/stream5.hip), replayed from "
-                             "profiles/hbm_mix.json, not measured in this run"}
+    gbps = 32.0 * nz * Cb / (msw * 1e-3) / 1e9
+    cs = prof.get("c2s/" + big.kernel_name(1, args.lanes)) or {}
+    out["hbm_regime"] = {
+        "bound": "hbm", "achieved": sig(gbps), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": sig(gbps / HBM_PEAK_GBPS, 4), "traffic": cs.get("hbm_bytes_per_launch"),
+        "columns": Cb, "bytes_per_column_step": 32 * nz, "kernel": big.kernel_name(1, args.lanes),
+        "kernel_us": sig(msw * 1e3), "value": sig(Cb / (msw * 1e-3)),
+        "alg24_frac": sig(24.0 * nz * Cb / (msw * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "all_streamed_48nz": {"kernel_us": sig(msb * 1e3),
+                              "frac": sig(48.0 * nz * Cb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
     del big, wAb, weffb
   return out
 
 
 # ---------------------------------------------------------------------- configs 3, 4, 5
-def make_ensemble(config, env, members, comm=None, n_total=None):
+def make_ensemble(config, env, members, comm=None, n_total=None, **kw):
   pymoc_amd, configs = env["pymoc_amd"], env["configs"]
   rank, world, stream = env["rank"], env["world"], env["stream"]
   n_total = n_total or members
   lo = rank * members if comm is not None else 0
   sl = (lo, lo + members)
-  kw = dict(stream=stream)
+  kw = dict(kw, stream=stream)
   if comm is not None:
     kw.update(comm=comm, n_total=n_total)
   if config == 3:
@@ -422,109 +371,68 @@ def make_ensemble(config, env, members, comm=None, n_total=None):
   return cfg, ens
 
 
-def kernel_breakdown(config, cfg, ens, env, reps=20):
-  """Event-timed cost of each kernel of the coupled loop on the ensemble's current state,
-  and the roofline figure of the dominant one."""
-  Event, stream = env["Event"], env["stream"]
-  from pymoc_amd import _lib
-  n, nz, M = ens.n, ens.nz, ens.M
-  tw_ops = _lib.PM_TW_SOLVE | _lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ
-  parts = {}
-  if config in (3, 4):
-    off = ens._off
-    parts["k_thermwind"] = (time_calls(
-        lambda: ens.tw.update(ens.cols.b.ptr, ens.cols.b.ptr + off, ops=tw_ops,
-                              store_psib=False, Psi_SO=ens._psi_so(), wA1=ens.wA.ptr,
-                              wA2=ens.wA.ptr + off), reps, stream, Event), 1)
-    if ens.so is not None:
-      parts["k_psi_so"] = (time_calls(lambda: ens.so.update(ens.cols.b.ptr, ens.bs_SO), reps,
-                                      stream, Event), 1)
-    parts["k_column_steps"] = (time_calls(
-        lambda: ens.cols.steps(ens.wA, ens.dt, M, lanes_per_col=ens.lanes), reps, stream,
-        Event), 1)
-  else:
-    off = ens._off
-    parts["k_thermwind"] = (time_calls(
-        lambda: ens.tw.update(ens.cols.b.ptr, ens.cols.b.ptr + off, ops=tw_ops,
-                              store_psib=False, Psi_SO=ens.so.Psi, wA1=ens.wA.ptr,
-                              wA2=ens.wA.ptr + off), reps, stream, Event), 1)
-    parts["k_psi_so"] = (time_calls(lambda: ens.so.update(ens.cols.b.ptr, ens.ml.bs), reps,
-                                    stream, Event), 1)
-    parts["k_jn2018_steps"] = (time_calls(lambda: ens._fused_steps(M), reps, stream, Event), 1)
-  total = sum(ms * cnt for ms, cnt in parts.values())
-  shares = {k: {"ms_per_moc_interval": ms * cnt, "share": ms * cnt / total}
-            for k, (ms, cnt) in parts.items()}
-  dom = max(parts, key=lambda k: parts[k][0] * parts[k][1])
-  ms = parts[dom][0]
-  ny = getattr(ens, "ny", 0)
-  if dom == "k_thermwind":
-    flop = n * flops_thermwind_update(nz, ens.nb)
-    alg = n * 64.0 * nz
-    model = ("12 nz + 6 nb (nz-1) + 20 nz = %d flop per member and update (SURVEY 8d: solve, "
-             "Psib, Psibz), x %d members" % (flops_thermwind_update(nz, ens.nb), n))
-  elif dom == "k_column_steps":
-    flop = 2 * n * M * flops_column_step(nz)
-    alg = 2 * n * M * 24.0 * nz
-    model = "14*(nz-2) flop per column-step x %d columns x %d fused steps" % (2 * n, M)
-  elif dom == "k_jn2018_steps":
-    flop = n * M * (2 * flops_column_step(nz) + flops_so_ml_step(ny))
-    alg = n * M * (2 * 24.0 * nz + 8.0 * (2 * nz + 2 * ny))
-    model = ("per coupled step 2 x 14 (nz-2) (columns) + 30 ny (mixed layer) = %d flop, x %d "
-             "members x %d fused steps" % (2 * flops_column_step(nz) + flops_so_ml_step(ny), n, M))
-  elif dom == "k_psi_so":
-    # outcrop latitudes / Ekman / tapers ~60 nz; the adaptive GM boundary-value solve: per mesh
-    # pass and interval three collocation elements (~60 flop each), the residual estimate (~150)
-    # and scans + chunk Thomas (~70) = ~400, on meshes growing 100 -> ~190 nodes over ~5.5 passes
-    # (measured on this config: profiles/r02) -- an ESTIMATE of useful work, not a count
-    flop = n * (60.0 * nz + 400.0 * 5.5 * 0.5 * (nz + 1.9 * nz))
-    alg = n * 8.0 * (3 * nz + ny)
-    model = ("estimate: 60 nz + 400 flop x ~5.5 adaptive mesh passes x ~1.45 nz intervals = %d "
-             "flop per member and update, x %d members" % (flop / n, n))
-  tf = flop / (ms * 1e-3) / 1e12
-  roof = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-          "frac": tf / FP64_PEAK_TFLOPS, "kernel": dom, "kernel_ms_per_launch": ms,
-          "flop_model": model, "traffic": None,
-          "algorithmic_hbm_GBps": alg / (ms * 1e-3) / 1e9}
-  # instruction mix, issued fp64 flop and vector-issue utilisation of the kernel on this config:
-  # SQ counters from separate rocprofv3 --pmc runs of `bench.py --config N`
-  # (profiles/collect_r03.sh), replayed
-  allc = load_json(os.path.join(ROOT, "profiles", "r03", "counters.json"))
+KERNEL_MODELS = {
+    # per LAUNCH of the kernel: (flop, what one launch is)
+    "k_thermwind": lambda n, nz, ny, nb, M: n * flops_thermwind_update(nz, nb),
+    "k_column_steps": lambda n, nz, ny, nb, M: 2 * n * M * flops_column_step(nz),
+    "k_jn2018_steps": lambda n, nz, ny, nb, M: n * M * (2 * flops_column_step(nz) +
+                                                        flops_so_ml_step(ny)),
+}
+
+
+def kernel_breakdown(config, env, members, nsteps, warm_blocks, **kw):
+  """Run-average duration of every kernel of a coupled config: a fresh ensemble, `warm_blocks`
+  untimed MOC intervals, then the full run with HIP events around EVERY launch (LaunchTimer).  Returns
+  ({kernel: [launches, avg us]}, roofline of the kernel with the largest total)."""
+  from pymoc_amd.device import LaunchTimer
+  # (config 4: Psi_SO.solve and the thermal wind one after the other here -- side by side, as the
+  # driver runs them, each is stretched by the other and neither duration is the kernel's own)
+  if config == 4:
+    kw = dict(kw, overlap_updates=False)
+  cfg, ens = make_ensemble(config, env, members, **kw)
+  ens.run(warm_blocks * ens.M)
+  env["stream"].sync()
+  ens.timer = LaunchTimer()
+  ens.run(nsteps)
+  summ = ens.timer.summary()
+  ens.timer = None
+  kern = {k: [n, sig(1e3 * t / n, 4)] for k, (n, t) in summ.items()}
+  dom = max((k for k in summ if k != "k_column_steps_short"), key=lambda k: summ[k][1])
+  us = 1e3 * summ[dom][1] / summ[dom][0]
+  n, nz, M, nb, ny = ens.n, ens.nz, ens.M, ens.nb, getattr(ens, "ny", 0)
+  roof = {"bound": "fp64-valu", "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "kernel": dom,
+          "kernel_us": sig(us, 4), "traffic": None}
+  prof, prof_round = profile_counters()
   cnt = None
-  for kk, vv in allc.items():
+  for kk, vv in prof.items():
     if kk.startswith("c%d/" % config) and kk.split("/", 1)[1].startswith(
         "k_jn2018" if dom == "k_jn2018_steps" else dom):
       if cnt is None or vv.get("avg_us", 0) * vv.get("launches", 0) > cnt.get("avg_us", 0) * cnt.get("launches", 0):
-        cnt, roof["profiled_kernel"] = vv, kk
+        cnt = vv
+  issued = cnt["fp64_flop_issued_per_launch"] / (us * 1e-6) / 1e12 if cnt else None
+  if dom in KERNEL_MODELS:
+    tf = KERNEL_MODELS[dom](n, nz, ny, nb, M) / (us * 1e-6) / 1e12
+  else:
+    # the adaptive GM solve has no closed-form count: its figure is the fp64 flop the SQ counted
+    # as issued (replayed counters), over this run's average kernel time
+    tf = issued
+  roof["achieved"] = sig(tf)
+  roof["frac"] = sig(tf / FP64_PEAK_TFLOPS, 4) if tf is not None else None
   if cnt:
-    roof["valu_busy_frac"] = cnt["valu_busy"]
-    roof["valu_insts_per_wave"] = cnt["valu_per_wave"]
-    roof["salu_insts_per_wave"] = cnt["salu_per_wave"]
-    roof["profiled_kernel_avg_us"] = cnt["avg_us"]
-    roof["issued_fp64_flop_per_launch"] = cnt["fp64_flop_issued_per_launch"]
-    roof["issued_frac"] = cnt["fp64_flop_issued_per_launch"] / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
-    roof["counters_source"] = (
-        "replayed from profiles/r03/counters.json (separate rocprofv3 --pmc passes of `bench.py "
-        "--config %d`, not measured in this run): valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 / (kernel "
-        "cycles x 1024 SIMDs); issued fp64 flop = 64 x (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + TRANS_F64 + "
-        "2 FMA_F64) per launch, over THIS run's kernel time = issued_frac; kernel average under the "
-        "profiler: profiles/r03/c%d_kernel_stats.csv" % (config, config))
-    if dom == "k_psi_so":
-      # no closed-form flop count exists for the adaptive solve (mesh sizes and pass counts are
-      # data-dependent): the roofline figure of this kernel IS the counted one
-      roof["achieved"] = roof["issued_frac"] * FP64_PEAK_TFLOPS
-      roof["frac"] = roof["issued_frac"]
-      roof["flop_model"] = ("fp64 flop the kernel issued, counted by the SQ (see counters_source); "
-                            "the adaptive GM boundary-value solve has no closed-form count")
-  return shares, roof
+    roof["issued_frac"] = sig(issued / FP64_PEAK_TFLOPS, 4)
+    roof["traffic"] = cnt.get("hbm_bytes_per_launch")
+    roof["counters"] = prof_round
+  del ens
+  return kern, roof
 
 
-def bench_coupled(config, args, env, members, nsteps=None, warm_blocks=None, sharded=False,
-                  breakdown=True):
+def bench_coupled(config, args, env, members, nsteps=None, warm_blocks=None, sharded=False, **kw):
   """Time a coupled config.  nsteps=None: K MOC intervals (headline mode)."""
   pymoc_amd = env["pymoc_amd"]
   stream, comm, rank, world = env["stream"], env["comm"], env["rank"], env["world"]
   use_comm = comm if sharded else None
-  cfg, ens = make_ensemble(config, env, members, use_comm, world * members if sharded else None)
+  cfg, ens = make_ensemble(config, env, members, use_comm,
+                           world * members if sharded else None, **kw)
   M = ens.M
   steps = nsteps if nsteps is not None else args.steps * M
   warm = (warm_blocks if warm_blocks is not None else args.warmup) * M
@@ -536,6 +444,7 @@ def bench_coupled(config, args, env, members, nsteps=None, warm_blocks=None, sha
   comm.barrier(stream)
   pymoc_amd.synchronize()
   g0 = ens.diag.ngathers if ens.diag is not None else 0
+  c0 = getattr(ens.diag, "ncollectives", 0) if ens.diag is not None else 0
   t0 = time.perf_counter()
   ens.run(steps)
   if use_comm is not None:
@@ -545,46 +454,79 @@ def bench_coupled(config, args, env, members, nsteps=None, warm_blocks=None, sha
   pymoc_amd.synchronize()
   el = comm.max_host(time.perf_counter() - t0)
   bad = ens.nonfinite_members()
-  ncol = SIZES[config]["ncol"]
   tot = world * members if sharded else members
-  res = {"members_per_gpu": members, "nz": int(ens.nz), "model_steps": steps,
-         "MOC_up_iters": M, "seconds": el, "coupled_steps_per_s": tot * steps / el,
-         "column_timesteps_per_s": ncol * tot * steps / el,
-         "nonfinite_members": int(bad.size),
-         "nonfinite_member_ids": [int(cfg["members"][i]) for i in bad[:16]]}
+  res = {"members_per_gpu": members, "nz": int(ens.nz), "model_steps": steps, "M": M,
+         "seconds": sig(el), "steps_per_s": sig(tot * steps / el, 6),
+         "nonfinite": [int(cfg["members"][i]) for i in bad[:8]]}
   if use_comm is not None:
     res["gathers_in_timed_region"] = ens.diag.ngathers - g0
+    res["rccl_collectives_in_timed_region"] = getattr(ens.diag, "ncollectives", 0) - c0
     res["gather_bytes_per_rank"] = ens.diag.bytes_per_rank
-  if breakdown and rank == 0:
-    shares, roof = kernel_breakdown(config, cfg, ens, env)
-    res["kernels"] = shares
-    res["roofline"] = roof
   return res, ens
 
 
 def headline_coupled(config, args, env):
   members = args.members or SIZES[config]["members"]
   res, ens = bench_coupled(config, args, env, members, sharded=True)
+  M, nz = ens.M, int(ens.nz)
+  diag_iters = ens.diag_iters
+  del ens
+  roof = None
+  if env["rank"] == 0:  # (no collective inside: the other ranks go straight to the final barrier)
+    _, roof = kernel_breakdown(config, env, members, args.steps * M, args.warmup)
   if env["rank"] != 0:
     return None
-  world, K, W, M = env["world"], args.steps, args.warmup, ens.M
+  world, K, W = env["world"], args.steps, args.warmup
+  ncol = SIZES[config]["ncol"]
   out = {
-      "metric": "column-timesteps/sec (ensemble) at nz=%d" % ens.nz,
-      "value": res["column_timesteps_per_s"], "unit": "column-timesteps/s", "n_gpus": world,
-      "steps": K, "warmup": W, "ms_per_step": res["seconds"] * 1e3 / K,
+      "metric": "column-timesteps/sec (ensemble) at nz=%d" % nz,
+      "value": sig(ncol * res["steps_per_s"], 6), "unit": "column-timesteps/s", "n_gpus": world,
+      "steps": K, "warmup": W, "ms_per_step": sig(res["seconds"] * 1e3 / K),
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
       "data": "synthetic",
-      "config": {"workload": WORKLOAD[config] % (members, ens.nz),
-                 "members_per_gpu": members, "nz": int(ens.nz), "model_steps_per_step": M,
-                 "step": "one MOC interval = %d model steps of every column + one refresh of "
-                         "the overturning diagnostics" % M,
+      "config": {"workload": WORKLOAD_SHORT[config] % (members, nz), "members_per_gpu": members,
+                 "nz": nz, "model_steps_per_step": M,
                  "parallelism": "ensemble sharded over %d GPU(s); RCCL all-gather of "
                                 "{b_basin,b_north,Psi_AMOC,Psi_SO} every %s model steps and at "
-                                "the end" % (world, ens.diag_iters)},
-      "roofline": res.pop("roofline"),
+                                "the end" % (world, diag_iters)},
+      "roofline": roof,
   }
   out.update(res)
   return out
+
+
+def coupled_block(c, args, env, cpu):
+  """The compact block of a coupled config inside the default line: full-length run at the SURVEY
+  8d size; exact (default path), contracted columns, and the variants the config has."""
+  n, steps = SIZES[c]["members"], SIZES[c]["nsteps"]
+  res, ens = bench_coupled(c, args, env, n, nsteps=steps, warm_blocks=10)
+  st = ens.state()
+  blk = {"members": n, "steps": steps, "steps_per_s": res["steps_per_s"],
+         "nonfinite": res["nonfinite"], "checksum": float(np.nansum(st["b_basin"]))}
+  del ens, st
+  kern, roof = kernel_breakdown(c, env, n, steps, 10)
+  blk.update(dom=roof["kernel"], dom_us=roof["kernel_us"], frac=roof["frac"],
+             issued_frac=roof.get("issued_frac"), kernels=kern)
+  rc, e2 = bench_coupled(c, args, dict(env, arith="contracted"), n, nsteps=steps, warm_blocks=10)
+  blk["contracted"] = rc["steps_per_s"]
+  del e2
+  if c == 4:  # the fixed 8-fold GM mesh of round 1 (~1e-6 from the reference) for comparison
+    r8, e2 = bench_coupled(4, args, dict(env, bvp_refine=8), n, nsteps=steps, warm_blocks=10)
+    blk["fixed_mesh_R8"] = r8["steps_per_s"]
+    del e2
+  if c in (3, 5):  # the persistent per-member run kernel (one launch per Diag_iters stretch)
+    try:
+      rf, e2 = bench_coupled(c, args, env, n, nsteps=steps, warm_blocks=10, fused_run=True)
+      blk["fused_run"] = rf["steps_per_s"]
+      del e2
+    except ValueError:
+      blk["fused_run"] = None  # the phases' LDS does not fit at this shape
+  if c in cpu:
+    ncol = SIZES[c]["ncol"]
+    blk["cpu1"] = sig(cpu[c]["value"] / ncol)
+    blk["cpuN"] = sig(cpu[c]["all_cores"]["value"] / ncol)
+    blk["cores"] = cpu[c]["all_cores"]["cores"]
+  return blk
 
 
 # ------------------------------------------------------------------------------ main
@@ -648,38 +590,18 @@ def main():
 
   if args.config == 2:
     out = bench_config2(args, env)
+    blocks = {}
     if want_coupled and out is not None:
-      out["coupled"] = {}
       for c in (3, 4, 5):
-        res, ens = bench_coupled(c, args, env, SIZES[c]["members"],
-                                 nsteps=SIZES[c]["nsteps"], warm_blocks=10)
-        res["workload"] = WORKLOAD[c] % (SIZES[c]["members"], ens.nz)
-        if c == 4:
-          # the GM boundary-value solve follows scipy solve_bvp's adaptive mesh (1e-14 from the
-          # reference); the fixed 8-fold mesh of round 1 (~1e-6 from the reference) for comparison
-          res["gm_bvp"] = "adaptive mesh (scipy solve_bvp's own refinement), parity 1e-11"
-          del ens
-          r8, ens = bench_coupled(4, args, dict(env, bvp_refine=8), SIZES[4]["members"],
-                                  nsteps=SIZES[4]["nsteps"], warm_blocks=10, breakdown=False)
-          res["fixed_mesh_R8_coupled_steps_per_s"] = r8["coupled_steps_per_s"]
-        if c in (3, 4, 5):
-          # the columns in the opt-in tolerance mode (PM_OP_CONTRACTED / PM_JN_CONTRACTED; reference
-          # parity 1e-12 / 1e-11 / 1e-10-to-the-first-Psib-flip instead of bit-identity to the
-          # oracle: tests/test_thermwind_gpu.py, tests/test_so_ml_gpu.py)
-          del ens
-          rc, ens = bench_coupled(c, args, dict(env, arith="contracted"), SIZES[c]["members"],
-                                  nsteps=SIZES[c]["nsteps"], warm_blocks=10, breakdown=False)
-          res["contracted_columns_coupled_steps_per_s"] = rc["coupled_steps_per_s"]
-        if c in cpu:
-          res["cpu_baseline"] = cpu[c]
-        out["coupled"]["config%d" % c] = res
-        del ens
+        blocks["c%d" % c] = coupled_block(c, args, env, cpu)
   else:
     out = headline_coupled(args.config, args, env)
+    blocks = {}
   if out is not None:
     if args.config in cpu:
       out["cpu_baseline"] = cpu[args.config]
-    print(json.dumps(out), flush=True)
+    out.update(blocks)  # last: they land in the tail of the line
+    print(json.dumps(out, separators=(",", ":")), flush=True)
   comm.barrier(stream)
   comm.close()
 

@@ -409,6 +409,14 @@ typedef struct pm_jn2018_loop {
 } pm_jn2018_loop;
 int pm_jn2018_run(const pm_jn2018_loop *run, pm_stream_t stream);
 
+/* One MOC update of the Jansen & Nadeau driver (run_JansenNadeau_2018.py:206-217) in ONE launch:
+ * pm_psi_so_update(so, PM_SO_OP_SOLVE) followed by pm_thermwind_update(tw, tw_ops) for the same
+ * members (same device functions, bit-identical results; `tw` may read so->Psi as its Psi_SO).
+ * `so` without the boundary-value smoother (c = None), so->n == tw->n, so->nz == tw->nz <= 256.
+ * Other shapes: PM_EINVAL -- issue the two calls.                                              */
+int pm_so_tw_update(const pm_psi_so *so, const pm_thermwind *tw, int32_t tw_ops,
+                    pm_stream_t stream);
+
 /* LDS bytes per block (16 members) the phases of a run kernel need for this shape: kind 0 =
  * pm_twocol_run, 1 = pm_jn2018_run (ny: points of the mixed layer).  A launch is refused
  * (PM_EINVAL) above 160 KB; a driver asks first and keeps its launch sequence otherwise.

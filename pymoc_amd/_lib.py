@@ -200,6 +200,8 @@ SIGNATURES = {
     "pm_jn2018_steps": (C.c_int, [C.POINTER(pm_jn2018), C.c_double, C.c_int32, C.c_void_p]),
     "pm_twocol_run": (C.c_int, [C.POINTER(pm_twocol_loop), C.c_void_p]),
     "pm_jn2018_run": (C.c_int, [C.POINTER(pm_jn2018_loop), C.c_void_p]),
+    "pm_so_tw_update": (C.c_int, [C.POINTER(pm_psi_so), C.POINTER(pm_thermwind), C.c_int32,
+                                  C.c_void_p]),
     "pm_run_lds_bytes": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.POINTER(C.c_size_t)]),
     "pm_twobasin_forcing": (C.c_int, [C.c_int32, C.c_int32] + [c_dp] * 9 + [C.c_void_p]),

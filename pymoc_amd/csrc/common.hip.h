@@ -118,6 +118,14 @@ __device__ __forceinline__ bool in_fast_div_range(double x) {
   return (e >= 1023u - FAST_DIV_EXP && e <= 1023u + FAST_DIV_EXP) || x == 0.0;
 }
 
+// ... for kernels whose IEEE form is a follow-up launch (the fused JN2018 loop): a NON-FINITE operand
+// does not send the member there.  Such a member is lost -- the reference raises at its next
+// overturning update -- and is reported as non-finite; what its NaNs do until then is not defined.
+__device__ __forceinline__ bool in_fast_div_range_or_lost(double x) {
+  const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
+  return (e >= 1023u - FAST_DIV_EXP && e <= 1023u + FAST_DIV_EXP) || x == 0.0 || e == 0x7ffu;
+}
+
 // Phase clocks for profiling builds (make -B lib EXTRA=-DPM_PHASE_PROFILE; read and cleared
 // through pm_debug_prof).  PM_TICK(k) adds the cycles since the previous tick of this wave to
 // slot k of a per-wave accumulator; a kernel that uses it declares `PM_TICK_INIT` once and ends

@@ -35,10 +35,13 @@ __device__ __forceinline__ void run_phase_fence() {
 }
 
 // LDS doubles per wave of a run kernel: the phases reuse one region
+// (the thermal wind's cells in the 5-double layout at P = 4: nothing else fits; thermwind.hip.h)
+template <int P>
+constexpr int run_cell_w() { return P == 4 ? 5 : 6; }
 template <int P>
 inline int run_wave_stride(int nz, int nb, int ny, bool with_so) {
   int w = JfLds<P>::PER_WAVE;
-  const int t = tw_lds_doubles(nz, nb);
+  const int t = tw_lds_doubles(nz, nb, run_cell_w<P>());
   w = t > w ? t : w;
   if (with_so) {
     const int s = so_lds_doubles(nz, ny, false, false);
@@ -166,7 +169,7 @@ __device__ __forceinline__ void tc_member_run(const pm_columns &c, const double 
       }
     }
   };
-  if (range_ok)
+  if (__builtin_expect(range_ok, 1))
     run_leg(std::false_type{});
   else
     run_leg(std::true_type{});
@@ -212,7 +215,7 @@ void k_twocol_run(pm_twocol_loop r, int wstride) {
   // (one call site per phase: k = -1 is the block of n_first steps that precedes the first refresh)
   for (int k = r.sched.n_first > 0 ? -1 : 0; k < r.sched.n_updates; ++k) {
     if (k >= 0) {
-      tw_member<P, BIG>(r.tw, PM_TW_SOLVE | PM_TW_PSIB | PM_TW_PSIBZ, m_raw, wl, lane);
+      tw_member<P, BIG, run_cell_w<P>()>(r.tw, PM_TW_SOLVE | PM_TW_PSIB | PM_TW_PSIBZ, m_raw, wl, lane);
       run_phase_fence();
     }
     const int ns = k < 0 ? r.sched.n_first
@@ -226,33 +229,146 @@ void k_twocol_run(pm_twocol_loop r, int wstride) {
 
 // ------------------------------------------------------------------------ Jansen & Nadeau
 // (the pm_jn2018 must be the kernel's FIRST argument: jf_member_run re-reads it from there)
+// One member from block k0 of the schedule on (k = -1: the n_first steps before the first
+// refresh).  skip_diag: block k0's diagnostics are behind the member already (a resumed member).
+// s_first: steps of block k0 that are behind the member as well.  Returns the block in which the
+// member left this kernel's hands (operands outside the window of the exact-division shortcuts:
+// jf_member_run<IEEE = false> stops there and records the steps done), or INT_MAX.
+template <int P, bool CT, bool VEC, int BIG, bool IEEE>
+__device__ __forceinline__ int jn_run_member(const pm_jn2018 &a, const pm_thermwind &tw,
+                                             const pm_psi_so &so, double dt,
+                                             const pm_run_schedule &sched, int k0, bool skip_diag,
+                                             int s_first, int m_raw, double *lds, int wstride,
+                                             int wave, int lane) {
+  using L = JfLds<P>;
+  double *wl = lds + L::WAVE0 + wave * wstride;
+  int s0 = 0;
+  for (int k = k0; k < sched.n_updates; ++k) {
+    if (k >= 0 && !(skip_diag && k == k0)) {
+      so_member<P, false>(so, PM_SO_OP_SOLVE, m_raw, wl, lane);
+      run_phase_fence();
+      tw_member<P, BIG, run_cell_w<P>()>(tw, PM_TW_SOLVE | PM_TW_PSIB | PM_TW_PSIBZ, m_raw, wl, lane);
+      run_phase_fence();
+    }
+    int ns = k < 0 ? sched.n_first : ((k == sched.n_updates - 1) ? sched.n_last : sched.m_steps);
+    if (k == k0) ns -= s_first;
+    if (ns > 0) {
+      const int done = jf_member_run<P, CT, VEC, false, IEEE>(a, dt, ns, s0, m_raw, lds, wstride,
+                                                              wave, lane);
+      run_phase_fence();
+      if (!IEEE && done < ns) return k;
+      s0 += ns;
+    }
+  }
+  return 0x7fffffff;
+}
+
+// status word of a member that left the main launch: bit 5, the steps done in its last block in
+// bits 8..19 (jf_member_run), that block's index + 1 in bits 20..
+constexpr int RUN_RESUME_SHIFT = 20;
+
 template <int P, bool CT, bool VEC, int BIG>
 __global__ __launch_bounds__(64 * JF_WAVES) JF_OCC_ATTR
 void k_jn2018_run(pm_jn2018 a, pm_thermwind tw, pm_psi_so so, double dt, pm_run_schedule sched,
                   int wstride) {
-  using L = JfLds<P>;
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m_raw = blockIdx.x * JF_WAVES + wave;
   jf_block_tables<P>(a, dt, lds, wave, lane);
   __syncthreads();
-  double *wl = lds + L::WAVE0 + wave * wstride;
-  int s0 = 0;
-  for (int k = sched.n_first > 0 ? -1 : 0; k < sched.n_updates; ++k) {
-    if (k >= 0) {
-      so_member<P, false>(so, PM_SO_OP_SOLVE, m_raw, wl, lane);
-      run_phase_fence();
-      tw_member<P, BIG>(tw, PM_TW_SOLVE | PM_TW_PSIB | PM_TW_PSIBZ, m_raw, wl, lane);
-      run_phase_fence();
+  const int left_at = jn_run_member<P, CT, VEC, BIG, false>(
+      a, tw, so, dt, sched, sched.n_first > 0 ? -1 : 0, false, 0, m_raw, lds, wstride, wave, lane);
+  if (left_at != 0x7fffffff && lane == 0 && m_raw < a.n)  // (jf_member_run has set bit 5)
+    a.ml.status[m_raw] |= (left_at + 1) << RUN_RESUME_SHIFT;
+}
+
+// Follow-up launch of k_jn2018_run: the members that left it, resumed at the block they left at
+// and carried to the end of the schedule with the step loop in its IEEE form.  One-wave blocks.
+template <int P, bool VEC, int BIG>
+__global__ __launch_bounds__(64) void k_jn2018_run_ieee(pm_jn2018 a, pm_thermwind tw,
+                                                        pm_psi_so so, double dt,
+                                                        pm_run_schedule sched, int wstride) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63;
+  FlagScan scan;
+  scan.init();
+  bool tables = false;
+  for (;;) {
+    const int m = scan.take(a.ml.status, a.n, 32, lane);
+    if (m < 0) return;
+    if (!tables) {
+      jf_block_tables<P>(a, dt, lds, 0, lane);
+      __builtin_amdgcn_wave_barrier();
+      tables = true;
     }
-    const int ns = k < 0 ? sched.n_first : ((k == sched.n_updates - 1) ? sched.n_last : sched.m_steps);
-    if (ns > 0) {
-      jf_member_run<P, CT, VEC, false>(a, dt, ns, s0, m_raw, lds, wstride, wave, lane);
-      s0 += ns;
-      run_phase_fence();
+    const int word = a.ml.status[m];
+    const int k0 = (word >> RUN_RESUME_SHIFT) - 1, s_first = (word >> 8) & 0xfff;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) a.ml.status[m] = word & 0xff;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    jn_run_member<P, false, VEC, BIG, true>(a, tw, so, dt, sched, k0, true, s_first, m, lds, wstride,
+                                            0, lane);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------ one update
+// PsiSO.solve followed by AMOC.solve / Psibz of the same member by the same wave: the two
+// diagnostic launches of a Jansen & Nadeau MOC update (run_JansenNadeau_2018.py:206-217) as one
+// (one launch boundary and the small Psi_SO launch's drain less; the SO phase of one wave runs
+// under the class passes of the others).  `so` without the boundary-value smoother.
+template <int P, int BIG>
+__global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK)
+__attribute__((amdgpu_waves_per_eu(4))) void k_so_tw_update(pm_psi_so so, pm_thermwind tw,
+                                                             int tw_ops, int per_wave) {
+  extern __shared__ double lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m_raw = blockIdx.x * (blockDim.x >> 6) + wave;
+  double *wl = lds_all + (size_t)wave * per_wave;
+  so_member<P, false>(so, PM_SO_OP_SOLVE, m_raw, wl, lane);
+  run_phase_fence();
+  tw_member<P, BIG>(tw, tw_ops, m_raw, wl, lane);
+}
+
+template <int P, int BIG>
+static int launch_so_tw_impl(const pm_psi_so &so, const pm_thermwind &tw, int tw_ops, hipStream_t st) {
+  int per = tw_lds_doubles(tw.nz, tw.nb);
+  const int s = so_lds_doubles(so.nz, so.ny, false, false);
+  per = ((s > per ? s : per) + 1) & ~1;
+  const size_t per_wave = (size_t)per * sizeof(double);
+  int wpb = 1, best = 0;  // as launch_thermwind_impl: the block size that keeps most waves on a CU
+  for (int w = TW_WAVES_PER_BLOCK; w >= 1; w >>= 1) {
+    int resident = (int)((160 * 1024) / (per_wave * w)) * w;
+    resident = resident > 16 ? 16 : resident;
+    if (resident > best) {
+      best = resident;
+      wpb = w;
     }
   }
+  const size_t lds = per_wave * wpb;
+  if (lds > 160 * 1024) return fail(PM_EINVAL, "pm_so_tw_update needs %zu B of LDS per member", lds);
+  if (lds > 64 * 1024)
+    PM_HIP(hipFuncSetAttribute((const void *)k_so_tw_update<P, BIG>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const unsigned grid = (unsigned)((tw.n + wpb - 1) / wpb);
+  hipLaunchKernelGGL((k_so_tw_update<P, BIG>), dim3(grid), dim3(64 * wpb), lds, st, so, tw, tw_ops, per);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
+// (the lane shapes the stand-alone kernels use for this nz: results are bit-identical to them)
+int launch_so_tw_update(const pm_psi_so &so, const pm_thermwind &tw, int tw_ops, hipStream_t st) {
+  const int nz = tw.nz, P = (nz + 63) / 64;
+  switch (P) {
+    case 1: return launch_so_tw_impl<1, 0>(so, tw, tw_ops, st);
+    case 2: return launch_so_tw_impl<2, 0>(so, tw, tw_ops, st);
+    case 3: return nz - 1 <= 128 ? launch_so_tw_impl<3, 0>(so, tw, tw_ops, st)
+                                 : launch_so_tw_impl<3, 1>(so, tw, tw_ops, st);
+    case 4: return launch_so_tw_impl<4, 1>(so, tw, tw_ops, st);
+  }
+  return -1;  // not covered: the caller issues the two launches
 }
 
 // ------------------------------------------------------------------------ launchers
@@ -314,8 +430,19 @@ static int launch_jn2018_run_impl(const pm_jn2018_loop &r, hipStream_t st) {
   };
   if (ct && vec) return go(k_jn2018_run<P, true, true, BIG>);
   if (ct) return go(k_jn2018_run<P, true, false, BIG>);
-  if (vec) return go(k_jn2018_run<P, false, true, BIG>);
-  return go(k_jn2018_run<P, false, false, BIG>);
+  const int rc = vec ? go(k_jn2018_run<P, false, true, BIG>) : go(k_jn2018_run<P, false, false, BIG>);
+  if (rc != PM_OK) return rc;
+  // the IEEE leg of the members that left the launch (operands outside the division window)
+  const size_t lds1 = (size_t)(JfLds<P>::WAVE0 + wstride) * sizeof(double);
+  const unsigned g1 = (unsigned)((a.n + 63) / 64 < 64 ? (a.n + 63) / 64 : 64);
+  if (vec)
+    hipLaunchKernelGGL((k_jn2018_run_ieee<P, true, BIG>), dim3(g1), dim3(64), lds1, st, a, r.tw,
+                       r.so, r.dt, r.sched, wstride);
+  else
+    hipLaunchKernelGGL((k_jn2018_run_ieee<P, false, BIG>), dim3(g1), dim3(64), lds1, st, a, r.tw,
+                       r.so, r.dt, r.sched, wstride);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
 }
 
 int launch_jn2018_run(const pm_jn2018_loop &r, hipStream_t st) {

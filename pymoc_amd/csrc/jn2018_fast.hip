@@ -34,6 +34,7 @@
 #if !defined(PM_PHASE_PROFILE) || defined(PM_JF_IN_MAIN_TU)
 #ifndef PM_JF_IN_MAIN_TU
 #define PM_SO_ML_DEVICE_FUNCTIONS_ONLY
+#define PM_DIAG_DEVICE_FUNCTIONS_ONLY
 #endif
 #include <type_traits>
 #include "so_ml.hip.h"
@@ -473,10 +474,20 @@ __device__ __forceinline__ void jf_block_tables(const pm_jn2018 &a, double dt, d
 // behind it, for the lag-based issue priority).  The kernel's argument block must START with the
 // pm_jn2018 (jf_args re-reads it there).  SYNC: the block's tables are being built by this very
 // block (k_jn2018_fast): a __syncthreads() after the member's own loads publishes them.
+// IEEE = false: the exact-division shortcuts (div_by_recip2, the select-free upwind flux), for
+// members whose column operands all lie in the window of those shortcuts (in_fast_div_range; K1's
+// operand guard, checked where K1 checks it: at the launch's start -- state, forcing, the
+// coefficients, grid, dt -- and again when a BC switch brings in the other coefficient set).  A
+// member outside the window STOPS there: its state after the s steps done so far (0 at the
+// launch's start) goes back to HBM, status gets bit 5 and s in bits 8..19, and s is returned; the
+// caller's follow-up launch takes the remaining steps with IEEE = true (true divisions,
+// compare-select flux, boundary levels held by a select: col_vertadvdiff's DIV == 0 form) -- a
+// separate kernel, so that the hot kernel, which sits exactly at 128 registers, carries none of
+// that code (inlined as a second leg it cost 6.5 % of config 5).  Returns the steps done.
 // CT: the columns step in the contracted form (tolerance mode); otherwise every operation is
 // the reference's, in its order.
-template <int P, bool CT, bool VEC, bool SYNC>
-__device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int nsteps, int s0,
+template <int P, bool CT, bool VEC, bool SYNC, bool IEEE>
+__device__ __forceinline__ int jf_member_run(const pm_jn2018 &a, double dt, int nsteps, int s0,
                                               int m_raw, double *lds, int wstride, int wave,
                                               int lane) {
   using L = JfLds<P>;
@@ -492,7 +503,7 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
   JfCol<P> cb, cn;
   JfConv<P> vb, vn;
   int ksel_b, ksel_n;
-  bool hint_ok = true, range_ok = in_fast_div_range(dt);
+  bool hint_ok = true, range_ok = in_fast_div_range_or_lost(dt);
   const bool shared = (a.hints & PM_JN_SHARED_COEF) != 0;
   {
     const pm_columns &c = a.cols;
@@ -512,10 +523,10 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
       }
       hint_ok = hint_ok && __ballot(!same) == 0ull;
       {  // operands inside the exact-division window? (common.hip.h; flagged, not branched on)
-        bool ok = in_fast_div_range(a0) && a0 != 0.0 && in_fast_div_range(c.bs[col]) &&
-                  in_fast_div_range(c.N2min[col]) && in_fast_div_range(c.bbot[col]);
+        bool ok = in_fast_div_range_or_lost(a0) && a0 != 0.0 && in_fast_div_range_or_lost(c.bs[col]) &&
+                  in_fast_div_range_or_lost(c.N2min[col]) && in_fast_div_range_or_lost(c.bbot[col]);
 #pragma unroll
-        for (int p = 0; p < P; ++p) ok = ok && (lane * P + p >= nz || in_fast_div_range(r.b[p]));
+        for (int p = 0; p < P; ++p) ok = ok && (lane * P + p >= nz || in_fast_div_range_or_lost(r.b[p]));
         range_ok = range_ok && __ballot(!ok) == 0ull;
       }
       if (lane == 0) {
@@ -604,9 +615,9 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
     for (int p = 0; p < P; ++p) {
       const int i = lane * P + p, e = jf_entry<P>(lane, p);
       const double zv = lds[L::T_Z + e], dzv = lds[L::T_DZ + e], dzcv = lds[L::T_DZC + e];
-      ok = ok && (i >= nz || (in_fast_div_range(zv) &&
-                              (i >= nz - 1 || (in_fast_div_range(dzv) && dzv != 0.0)) &&
-                              in_fast_div_range(dzcv) && dzcv != 0.0));
+      ok = ok && (i >= nz || (in_fast_div_range_or_lost(zv) &&
+                              (i >= nz - 1 || (in_fast_div_range_or_lost(dzv) && dzv != 0.0)) &&
+                              in_fast_div_range_or_lost(dzcv) && dzcv != 0.0));
     }
     range_ok = range_ok && __ballot(!ok) == 0ull;
   }
@@ -619,6 +630,7 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
   // the same step: inside the loop the reload's merge with the resident coefficients cost the
   // register allocator more than the reload itself.
   int s = hint_ok ? 0 : nsteps;
+  bool skipped = false;
   while (s < nsteps) {
     {
       jf_kargs ka = jf_args();
@@ -641,7 +653,8 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
           const double we = interior ? w : 0.0;
           r.wn[p] = (we < 0.0) ? -we : 0.0;
           r.wp[p] = (we < 0.0) ? 0.0 : -we;
-          coef_ok = coef_ok && in_fast_div_range(we) && in_fast_div_range(r.kap[p]);
+          if constexpr (!IEEE && !CT)
+            coef_ok = coef_ok && in_fast_div_range_or_lost(we) && in_fast_div_range_or_lost(r.kap[p]);
           if constexpr (CT) {
             // cu = dt (kappa / (dzc dz) + wn / (A dz)), cl = dt (-kappa / (dzc dz') + wp / (A dz')),
             // dz' = the spacing below the level (col_make_contracted, column.hip.h)
@@ -659,11 +672,19 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
       };
       load_coef(cb, nullptr, m, ksel_b);
       load_coef(cn, wl + L::W_KN, n + m, ksel_n);
-      range_ok = range_ok && __ballot(!coef_ok) == 0ull;
+      if constexpr (!IEEE && !CT) {
+        range_ok = range_ok && __ballot(!coef_ok) == 0ull;
+        if (__builtin_expect(!range_ok, 0)) {
+          // not this kernel's member from step s on: the state of step s goes back to HBM, the
+          // IEEE follow-up launch takes the remaining steps (status bits 8.. carry s)
+          skipped = true;
+          break;
+        }
+      }
       __builtin_amdgcn_wave_barrier();
     }
     // BC switch + both columns of step s; false: a coefficient set changed (nothing done yet)
-    auto columns_step = [&](auto ieee_c, int lane_o, double *wl, double *ws) -> bool {
+    auto columns_step = [&](int lane_o, double *wl, double *ws) -> bool {
 #ifndef JF_NO_PRIO_ROTATE
       // The SIMD's arbiter favours its oldest wave: left alone its four waves (waves w, w+4,
       // w+8, w+12 of the block) finish ~20 us apart and the last runs alone; with priorities
@@ -718,7 +739,7 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
       if constexpr (CT) {
         jf_vertadvdiff_contracted<P>(cb);
         jf_vertadvdiff_contracted<P>(cn);
-      } else if constexpr (decltype(ieee_c)::value) {
+      } else if constexpr (IEEE) {
         jf_vertadvdiff_ieee<P, true>(cb, lds, ws + S_B, nullptr, lane_o, dt, nz);
         jf_vertadvdiff_ieee<P, false>(cn, lds, ws + S_NN, wl + L::W_KN, lane_o, dt, nz);
       } else {
@@ -730,12 +751,6 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
       }
       return true;
     };
-    // The step loop in one of two forms (wave-uniform choice per entry): the exact-division
-    // shortcuts while every operand of the column steps lies in their window, else the IEEE form
-    // (true divisions, compare-select flux, boundary levels held by a select) -- the operand guard
-    // of K1 (column.hip.h), checked where K1 checks it: at the launch's start and when a
-    // coefficient set is loaded.  The tolerance mode (CT) has no such shortcut to guard.
-    auto run_leg = [&](auto ieee_c) {
     if (ml_ok) {
     for (; s < nsteps; ++s) {
       PM_TICK(6)
@@ -746,7 +761,7 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
       asm volatile("" : "+v"(lane_o), "+s"(woff));
       const int a4 = lane_o << 2;
       double *wl = lds + L::WAVE0 + woff, *ws = wl + L::W_S;
-      if (__builtin_expect(!columns_step(ieee_c, lane_o, wl, ws), 0)) break;
+      if (__builtin_expect(!columns_step(lane_o, wl, ws), 0)) break;
       PM_TICK(0)
       JF_RARE(0)
       // ---- channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi) (:261), ml_step_reg's operations
@@ -880,14 +895,9 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
         int lane_o = lane, woff = wave * wstride;
         asm volatile("" : "+v"(lane_o), "+s"(woff));
         double *wl = lds + L::WAVE0 + woff, *ws = wl + L::W_S;
-        if (__builtin_expect(!columns_step(ieee_c, lane_o, wl, ws), 0)) break;
+        if (__builtin_expect(!columns_step(lane_o, wl, ws), 0)) break;
       }
     }
-    };
-    if (CT || range_ok)
-      run_leg(std::false_type{});
-    else
-      run_leg(std::true_type{});
   }
 
   PM_TICK_FLUSH
@@ -915,7 +925,7 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
   }
   const bool anybad = __ballot(bad) != 0ull;
   if (lane == 0 && m_ok) {
-    if (hint_ok && nsteps > 0) {
+    if (hint_ok && s > 0) {  // (s: the steps done)
       // Column.bbot after the last step = what that step imposed on level 0
       double *bbot = const_cast<double *>(ka->cols.bbot);
       int32_t *ksel = const_cast<int32_t *>(ka->cols.ksel);
@@ -933,9 +943,10 @@ __device__ __forceinline__ void jf_member_run(const pm_jn2018 &a, double dt, int
     // (a persistent run ORs the intervals' flags together: its caller zeroes the array first)
     if (st)
       st[m] = (SYNC ? 0 : st[m]) | status | (anybad ? 2 : 0) | (hint_ok ? 0 : 16) |
-              (range_ok ? 0 : 32);
+              ((IEEE || skipped) ? 32 : 0) | (skipped ? (s << 8) : 0);
   }
   PM_WAVE_END(m_raw)
+  return s;
 }
 
 template <int P, bool CT, bool VEC>
@@ -945,8 +956,61 @@ void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   jf_block_tables<P>(a, dt, lds, wave, lane);
-  jf_member_run<P, CT, VEC, true>(a, dt, nsteps, 0, blockIdx.x * JF_WAVES + wave, lds,
-                                  JfLds<P>::PER_WAVE, wave, lane);
+  jf_member_run<P, CT, VEC, true, false>(a, dt, nsteps, 0, blockIdx.x * JF_WAVES + wave, lds,
+                                         JfLds<P>::PER_WAVE, wave, lane);
+}
+
+// The next flagged member (status bit `bit`) of a one-wave block's share of the ensemble, -1 when
+// none is left: every lane looks at one member's status, a ballot collects 64 of them (the scan
+// of k_psi_so's follow-up launch).
+struct FlagScan {
+  int next, base;
+  unsigned long long pending;
+  __device__ __forceinline__ void init() {
+    next = blockIdx.x * 64;
+    base = 0;
+    pending = 0ull;
+  }
+  __device__ __forceinline__ int take(const int32_t *status, int n, int bit, int lane) {
+    while (pending == 0ull) {
+      if (next >= n) return -1;
+      base = next;
+      next += gridDim.x * 64;
+      const int mm = base + lane;
+      pending = __ballot(mm < n && (status[mm] & bit) != 0);
+    }
+    const int m = base + __builtin_ctzll(pending);
+    pending &= pending - 1ull;
+    return m;
+  }
+};
+
+// Follow-up launch of k_jn2018_fast: the members it flagged (operands outside the window of the
+// exact-division shortcuts) stepped in the IEEE form.  One-wave blocks; ~2 us when no member is
+// flagged (no table is built then).
+template <int P, bool VEC>
+__global__ __launch_bounds__(64) void k_jn2018_ieee(pm_jn2018 a, double dt, int nsteps) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63;
+  FlagScan scan;
+  scan.init();
+  bool tables = false;
+  for (;;) {
+    const int m = scan.take(a.ml.status, a.n, 32, lane);
+    if (m < 0) return;
+    if (!tables) {
+      jf_block_tables<P>(a, dt, lds, 0, lane);
+      __builtin_amdgcn_wave_barrier();
+      tables = true;
+    }
+    const int s0 = (a.ml.status[m] >> 8) & 0xfff;  // steps the main launch has done
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) a.ml.status[m] &= 0xff;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    jf_member_run<P, false, VEC, false, true>(a, dt, nsteps - s0, s0, m, lds, JfLds<P>::PER_WAVE, 0,
+                                              lane);
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 template <int P>
@@ -971,12 +1035,23 @@ static int launch_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st
     JF_LAUNCH(false, false);
 #undef JF_LAUNCH
   PM_HIP(hipGetLastError());
+  if (!ct && a.ml.status) {  // the IEEE leg of the members this launch flagged
+    const size_t lds1 = (size_t)(JfLds<P>::WAVE0 + JfLds<P>::PER_WAVE) * sizeof(double);
+    const unsigned g1 = (unsigned)((a.n + 63) / 64 < 64 ? (a.n + 63) / 64 : 64);
+    if (vec)
+      hipLaunchKernelGGL((k_jn2018_ieee<P, true>), dim3(g1), dim3(64), lds1, st, a, dt, nsteps);
+    else
+      hipLaunchKernelGGL((k_jn2018_ieee<P, false>), dim3(g1), dim3(64), lds1, st, a, dt, nsteps);
+    PM_HIP(hipGetLastError());
+  }
   return PM_OK;
 }
 
 bool jn2018_fast_applies(const pm_jn2018 &a) {
+  // (status: how the launch hands members outside the exact-division window to its IEEE
+  // follow-up launch)
   return (a.hints & PM_JN_UNIFORM_AREA) != 0 && a.ml.ny <= 64 && a.cols.nz <= 256 &&
-         a.cols.nz >= 4;
+         a.cols.nz >= 4 && a.ml.status != nullptr;
 }
 
 int launch_jn2018_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st) {

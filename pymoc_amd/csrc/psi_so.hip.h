@@ -1117,6 +1117,7 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
   PM_WAVE_END(m_raw)
 }
 
+#ifndef PM_DIAG_DEVICE_FUNCTIONS_ONLY  // (coupled_run.hip.h shares so_member only)
 template <int P, bool BVP, bool FIX = false>
 __global__ __launch_bounds__(64 * SO_WAVES_PER_BLOCK) void k_psi_so(pm_psi_so a, int ops) {
   extern __shared__ double lds_all[];
@@ -1202,5 +1203,7 @@ inline int dispatch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
   }
   return fail(PM_EINVAL, "nz=%d unsupported by psi_so (max 512)", a.nz);
 }
+
+#endif  // PM_DIAG_DEVICE_FUNCTIONS_ONLY
 
 }  // namespace pm

@@ -486,6 +486,27 @@ int pm_jn2018_steps(const pm_jn2018 *jn, double dt, int32_t nsteps, pm_stream_t 
   }
 }
 
+int pm_so_tw_update(const pm_psi_so *so, const pm_thermwind *tw, int32_t tw_ops,
+                    pm_stream_t stream) {
+  PM_REQUIRE(so && tw, "NULL argument");
+  const pm_psi_so &a = *so;
+  const pm_thermwind &t = *tw;
+  PM_REQUIRE(a.n == t.n && a.nz == t.nz && a.n >= 0, "inconsistent sizes");
+  PM_REQUIRE(t.nz >= 2 && t.nz <= 256 && a.ny >= 2 && a.ny <= 2048 && t.nb >= 1,
+             "pm_so_tw_update: nz <= 256 (nz=%d)", t.nz);
+  PM_REQUIRE(!(a.flags & PM_SO_HAS_C), "pm_so_tw_update: Psi_SO without the boundary-value smoother");
+  PM_REQUIRE((tw_ops & ~15) == 0 && tw_ops != 0 && (!(tw_ops & PM_TW_PSIBZ) || (tw_ops & PM_TW_PSIB)),
+             "bad thermal-wind ops 0x%x", tw_ops);
+  if (a.n == 0) return PM_OK;
+  PM_REQUIRE(a.z && a.y && a.b && a.bs && a.tau && a.KGM && a.Psi && a.Psi_Ek && a.Psi_GM,
+             "pm_psi_so has a NULL required pointer");
+  PM_REQUIRE(t.z && t.b1 && t.b2 && t.Psi && (!(tw_ops & PM_TW_SOLVE) || t.f),
+             "pm_thermwind has a NULL required pointer");
+  const int rc = launch_so_tw_update(a, t, tw_ops, resolve_stream(stream));
+  if (rc == -1) return fail(PM_EINVAL, "pm_so_tw_update: shape not covered (nz=%d)", t.nz);
+  return rc;
+}
+
 int pm_run_lds_bytes(int32_t kind, int32_t nz, int32_t nb, int32_t ny, size_t *bytes) {
   PM_REQUIRE(bytes && (kind == 0 || kind == 1), "bad arguments");
   *bytes = run_lds_bytes(kind, nz, nb, ny);
@@ -520,7 +541,7 @@ int pm_jn2018_run(const pm_jn2018_loop *run, pm_stream_t stream) {
   PM_REQUIRE(a.n >= 0 && c.ncols == 2 * a.n && a.ml.n == a.n && a.ml.nz == c.nz && r.tw.n == a.n &&
                  r.tw.nz == c.nz && r.so.n == a.n && r.so.nz == c.nz && r.so.ny == a.ml.ny,
              "inconsistent batch sizes n=%d", a.n);
-  PM_REQUIRE(jn2018_fast_applies(a), "pm_jn2018_run needs PM_JN_UNIFORM_AREA, ny <= 64, 4 <= nz <= 256");
+  PM_REQUIRE(jn2018_fast_applies(a), "pm_jn2018_run needs PM_JN_UNIFORM_AREA, ny <= 64, 4 <= nz <= 256, ml.status");
   PM_REQUIRE(c.nsel == 2 && c.ksel && c.z && c.b && c.kappa && c.area && c.dAkappa && c.bs &&
                  c.bbot && c.N2min,
              "pm_jn2018_loop.jn.cols has a NULL pointer or nsel != 2");

@@ -885,5 +885,6 @@ int launch_jn2018_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st
 int launch_twocol_run(const pm_twocol_loop &r, hipStream_t st);
 int launch_jn2018_run(const pm_jn2018_loop &r, hipStream_t st);
 size_t run_lds_bytes(int kind, int nz, int nb, int ny);
+int launch_so_tw_update(const pm_psi_so &so, const pm_thermwind &tw, int tw_ops, hipStream_t st);
 
 }  // namespace pm

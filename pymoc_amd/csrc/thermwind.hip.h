@@ -92,30 +92,54 @@ __device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
   return r;
 }
 
-// Cells of the Psib sum in LDS, 6 doubles each (three 16-byte broadcast loads):
-//   top, d = top - bot | yh = RN(1/d) or NaN, yl = recip_lo(d, yh) | u, (pad)
-constexpr int TW_CELL = 6;
+// Cells of the Psib sum in LDS.  Two layouts:
+//   W = 6: 6 doubles per cell, top, d = top - bot | yh = RN(1/d) or NaN, yl = recip_lo(d, yh) | u, bot
+//          (three 16-byte broadcast loads; the sixth slot feeds the group ranges of lane shapes
+//          whose groups do not coincide with lanes);
+//   W = 5 (P = 1, 2, 4, 8: the group ranges come from the lanes' registers): {top, d | yh, yl}[nz]
+//          followed by u[nz] -- two 16-byte loads and one 8-byte load per cell, the all-ones groups
+//          read u alone.  A sixth less LDS per wave (16 members of nz = 200 then fit a CU together
+//          with the fused step loop's tables: coupled_run.hip.h) and a sixth less LDS traffic in
+//          the class passes.
+// Measured (profiles/r04/run_ab_w5.sh): W = 5 makes k_thermwind<4,1> SLOWER, 77.5 against 69.6 us
+// per update of config 5 (the third, narrower load costs the tile loop more than the bytes it
+// saves), and changes nothing at P = 2.  The stand-alone kernel keeps W = 6; the persistent run
+// kernel uses W = 5 at P = 4, where nothing else fits the LDS.
+__host__ __device__ constexpr bool tw_w5_ok(int P) { return P == 1 || P == 2 || P == 4 || P == 8; }
 struct PsibCell {
   double top, d, yh, yl, u;
+};
+template <int W>
+struct CellView {
+  const double *base;
+  int nz;
+  __device__ __forceinline__ PsibCell load(int k) const {
+    if constexpr (W == 6) {
+      const double2 *c = reinterpret_cast<const double2 *>(base + (size_t)k * 6);
+      const double2 v0 = c[0], v1 = c[1], v2 = c[2];
+      return PsibCell{v0.x, v0.y, v1.x, v1.y, v2.x};
+    } else {
+      const double2 *c = reinterpret_cast<const double2 *>(base + (size_t)k * 4);
+      const double2 v0 = c[0], v1 = c[1];
+      return PsibCell{v0.x, v0.y, v1.x, v1.y, base[4 * nz + k]};
+    }
+  }
+  __device__ __forceinline__ double u(int k) const {
+    return W == 6 ? base[(size_t)k * 6 + 4] : base[4 * nz + k];
+  }
 };
 // The psib row (nb doubles, read by Psibz) overlays the cells when the class passes' results
 // fit in registers (<= TW_HELD passes): they are written once the last pass has read the cells.
 // Only where it buys residency: nz > 128 (smaller grids keep 16 waves on a CU anyway).
 constexpr int TW_HELD = 8 / TW_JT_N;  // (TW_JT_N = 1, 64-class passes: measured no faster)
-__host__ __device__ inline bool tw_overlay(int nz, int nb) {
-  return nz > 128 && nb <= 64 * TW_JT * TW_HELD && nb <= TW_CELL * nz;
+__host__ __device__ inline bool tw_overlay(int nz, int nb, int W = 6) {
+  return nz > 128 && nb <= 64 * TW_JT * TW_HELD && nb <= W * nz;
 }
 // LDS doubles per wave: cells, the psib row unless overlaid, two group-range rows; even, so
 // that every wave's cells stay 16-byte aligned
-__host__ __device__ inline int tw_lds_doubles(int nz, int nb) {
-  return (TW_CELL * nz + (tw_overlay(nz, nb) ? 0 : nb) + 2 * ((nz + 7) / 8) + 1) & ~1;
+__host__ __device__ inline int tw_lds_doubles(int nz, int nb, int W = 6) {
+  return (W * nz + (tw_overlay(nz, nb, W) ? 0 : nb) + 2 * ((nz + 7) / 8) + 1) & ~1;
 }
-__device__ __forceinline__ PsibCell psib_load_cell(const double *cells, int k) {
-  const double2 *c = reinterpret_cast<const double2 *>(cells + (size_t)k * TW_CELL);
-  const double2 v0 = c[0], v1 = c[1], v2 = c[2];
-  return PsibCell{v0.x, v0.y, v1.x, v1.y, v2.x};
-}
-
 // RN(fma(r, yh, q)) clamped to [0, 1] by the VOP3 clamp modifier (the last Markstein step and
 // np.clip in one instruction; finite operands only)
 __device__ __forceinline__ double fma_clamp01(double r, double yh, double q) {
@@ -179,8 +203,8 @@ __device__ __forceinline__ double tw_uniform(double x) {
 
 // terms of the 8 cells of group k8/8 into r (ADD: accumulate, else initialise).
 // kind: 0 general and regular, 1 general and irregular, 2 all masks one, 3 all masks zero
-template <bool ADD>
-__device__ __forceinline__ void psib_group(const double *cells, int k8, int kind,
+template <bool ADD, class CV>
+__device__ __forceinline__ void psib_group(const CV &cells, int k8, int kind,
                                            const double (&bg)[TW_JT],
                                            double (&r)[8][TW_JT] PM_TICK_PARAM) {
   double term[TW_JT];
@@ -188,7 +212,7 @@ __device__ __forceinline__ void psib_group(const double *cells, int k8, int kind
     PM_COUNT(12)
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-      const double uk = cells[(size_t)(k8 + a) * TW_CELL + 4];
+      const double uk = cells.u(k8 + a);
 #pragma unroll
       for (int j = 0; j < TW_JT; ++j) r[a][j] = ADD ? r[a][j] + uk : uk;
     }
@@ -204,7 +228,7 @@ __device__ __forceinline__ void psib_group(const double *cells, int k8, int kind
     PM_COUNT(11)
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-      psib_regular_terms(psib_load_cell(cells, k8 + a), bg, term);
+      psib_regular_terms(cells.load(k8 + a), bg, term);
 #pragma unroll
       for (int j = 0; j < TW_JT; ++j) r[a][j] = ADD ? r[a][j] + term[j] : term[j];
     }
@@ -212,7 +236,7 @@ __device__ __forceinline__ void psib_group(const double *cells, int k8, int kind
     PM_COUNT(14)
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-      psib_cell_terms(psib_load_cell(cells, k8 + a), bg, term);
+      psib_cell_terms(cells.load(k8 + a), bg, term);
 #pragma unroll
       for (int j = 0; j < TW_JT; ++j) r[a][j] = ADD ? r[a][j] + term[j] : term[j];
     }
@@ -223,7 +247,8 @@ __device__ __forceinline__ void psib_group(const double *cells, int k8, int kind
 // block are classified at once -- lane l compares the range of group k0/8 + l with the pass's
 // class range, three ballots give the masks -- so the loop below visits only the groups that
 // add something, with scalar bit tests instead of an LDS round trip and two compares per group.
-__device__ __forceinline__ void psib_block_sum(const double *cells, int k0, int n,
+template <class CV>
+__device__ __forceinline__ void psib_block_sum(const CV &cells, int k0, int n,
                                                const double (&bg)[TW_JT],
                                                double (&res)[TW_JT],
                                                const PsibRange &rg PM_TICK_PARAM) {
@@ -232,7 +257,7 @@ __device__ __forceinline__ void psib_block_sum(const double *cells, int k0, int 
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) res[j] = 0.;
     for (int k = k0; k < k0 + n; ++k) {
-      psib_cell_terms(psib_load_cell(cells, k), bg, term);
+      psib_cell_terms(cells.load(k), bg, term);
 #pragma unroll
       for (int j = 0; j < TW_JT; ++j) res[j] += term[j];
     }
@@ -251,12 +276,12 @@ __device__ __forceinline__ void psib_block_sum(const double *cells, int k0, int 
     return ((ones >> g) & 1ull) ? 2 : (((zero >> g) & 1ull) ? 3 : (((irr >> g) & 1ull) ? 1 : 0));
   };
   double r[8][TW_JT];
-  psib_group<false>(cells, k0, kind_of(0), bg, r PM_TICK_ARG);  // initialises the accumulators
+  psib_group<false, CV>(cells, k0, kind_of(0), bg, r PM_TICK_ARG);  // initialises the accumulators
   unsigned long long todo = ~zero & ((1ull << ng) - 1ull) & ~1ull;
   while (todo != 0ull) {
     const int g = __builtin_ctzll(todo);
     todo &= todo - 1ull;
-    psib_group<true>(cells, k0 + 8 * g, kind_of(g), bg, r PM_TICK_ARG);
+    psib_group<true, CV>(cells, k0 + 8 * g, kind_of(g), bg, r PM_TICK_ARG);
   }
 #pragma unroll
   for (int j = 0; j < TW_JT; ++j)
@@ -266,13 +291,13 @@ __device__ __forceinline__ void psib_block_sum(const double *cells, int k0, int 
     const int kt = kind_of(ng);
     if (kt == 2) {
       for (int k = (ng << 3); k < n; ++k) {
-        const double uk = cells[(size_t)(k0 + k) * TW_CELL + 4];
+        const double uk = cells.u(k0 + k);
 #pragma unroll
         for (int j = 0; j < TW_JT; ++j) res[j] += uk;
       }
     } else if (kt != 3) {  // (all masks zero: the tail adds zeros)
       for (int k = (ng << 3); k < n; ++k) {
-        psib_cell_terms(psib_load_cell(cells, k0 + k), bg, term);
+        psib_cell_terms(cells.load(k0 + k), bg, term);
 #pragma unroll
         for (int j = 0; j < TW_JT; ++j) res[j] += term[j];
       }
@@ -282,7 +307,8 @@ __device__ __forceinline__ void psib_block_sum(const double *cells, int k0, int 
 
 // out-of-line copy for the recursive (nz > 129) path: 16 inlined copies per kernel cost
 // minutes of compile time and every register
-__device__ __noinline__ void psib_block_sum_call(const double *cells, int k0, int n,
+template <class CV>
+__device__ __noinline__ void psib_block_sum_call(const CV &cells, int k0, int n,
                                                  const double (&bg)[TW_JT],
                                                  double (&res)[TW_JT],
                                                  const PsibRange &rg PM_TICK_PARAM) {
@@ -291,8 +317,8 @@ __device__ __noinline__ void psib_block_sum_call(const double *cells, int k0, in
 
 // np.add.reduce pairwise recursion (blocks of <= 128, left half rounded down to a
 // multiple of 8).  D bounds the recursion depth: D=4 covers n <= 128*16.
-template <int D>
-__device__ __forceinline__ void psib_pairwise(const double *cells, int k0, int n,
+template <int D, class CV>
+__device__ __forceinline__ void psib_pairwise(const CV &cells, int k0, int n,
                                               const double (&bg)[TW_JT], double (&res)[TW_JT],
                                               const PsibRange &rg PM_TICK_PARAM) {
   if constexpr (D == 0) {
@@ -305,8 +331,8 @@ __device__ __forceinline__ void psib_pairwise(const double *cells, int k0, int n
     int n2 = n / 2;
     n2 -= n2 % 8;
     double l[TW_JT], r[TW_JT];
-    psib_pairwise<D - 1>(cells, k0, n2, bg, l, rg PM_TICK_ARG);
-    psib_pairwise<D - 1>(cells, k0 + n2, n - n2, bg, r, rg PM_TICK_ARG);
+    psib_pairwise<D - 1, CV>(cells, k0, n2, bg, l, rg PM_TICK_ARG);
+    psib_pairwise<D - 1, CV>(cells, k0 + n2, n - n2, bg, r, rg PM_TICK_ARG);
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) res[j] = l[j] + r[j];
   }
@@ -386,19 +412,20 @@ __device__ __forceinline__ void tw_pass_priority(int pass) {
 // One member's update: `s_cell` = the wave's tw_lds_doubles(nz, nb) doubles of LDS.  The body of
 // k_thermwind, and the diagnostic phase of the persistent run kernels (coupled_run.hip), which
 // call it between two blocks of time steps of the same wave.
-template <int P, int BIG>
+template <int P, int BIG, int W = 6>
 __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_raw,
                                           double *s_cell, int lane) {
+  static_assert(W == 6 || (W == 5 && tw_w5_ok(P)), "cell layout");
   const bool m_ok = m_raw < a.n;
   const int m = m_ok ? m_raw : a.n - 1;
   const int nz = a.nz, nb = a.nb;
   const int ngrp = (nz + 7) >> 3;
-  // s_cell: [nz][TW_CELL] cells of the Psib sum
+  // s_cell: the cells of the Psib sum, layout W (CellView)
   double *s_a = s_cell;                                // [nz]  G of the solve (before Psib)
   double *s_b = s_a + nz;                              // [nz]  I of the solve
-  const bool overlay = P >= 3 && tw_overlay(nz, nb);
-  double *s_psib = overlay ? s_cell : s_cell + TW_CELL * nz;  // [nb]
-  double *s_gbot = s_cell + TW_CELL * nz + (overlay ? 0 : nb);  // [ngrp] min(bot) of each 8-cell group
+  const bool overlay = P >= 3 && tw_overlay(nz, nb, W);
+  double *s_psib = overlay ? s_cell : s_cell + W * nz;  // [nb]
+  double *s_gbot = s_cell + W * nz + (overlay ? 0 : nb);  // [ngrp] min(bot) of each 8-cell group
   double *s_gtop = s_gbot + ngrp;                   // [ngrp] max(top)
   const size_t base = (size_t)m * nz;
 
@@ -528,7 +555,7 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
       // regular: every product of the reciprocal division stays far from over- and underflow
       const bool regular = range_ok && ad >= 1e-100 && ad <= 1e100 && __builtin_fabs(top) < 1e100;
       const double yh = regular ? 1.0 / d : __builtin_nan("");
-      double2 *cell = reinterpret_cast<double2 *>(s_cell + (size_t)k * TW_CELL);
+      double2 *cell = reinterpret_cast<double2 *>(s_cell + (size_t)k * (W == 6 ? 6 : 4));
       cell[0] = double2{top, d};
       cell[1] = double2{yh, recip_lo(d, yh)};
       // sixth slot: bot for the group ranges, -inf for a cell that bars its group from the
@@ -537,7 +564,10 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
       // its group from both shortcuts like a degenerate cell does
       const bool ufin = __builtin_fabs(u) <= 1.7976931348623157e308;
       const bool plain = regular && d > 0. && ufin;
-      cell[2] = double2{u, plain ? bot : -__builtin_inf()};
+      if constexpr (W == 6)
+        cell[2] = double2{u, plain ? bot : -__builtin_inf()};
+      else
+        s_cell[4 * nz + k] = u;
       lane_gb = plain ? __builtin_fmin(lane_gb, bot) : -__builtin_inf();
       lane_gt = (plain && lane_gt != __builtin_inf()) ? __builtin_fmax(lane_gt, top) : __builtin_inf();
     }
@@ -575,10 +605,10 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
     for (int a = 0; a < 8; ++a) {
       const int k = g * 8 + a;
       if (k < nc && ok) {
-        const double bk = s_cell[(size_t)k * TW_CELL + 5];
+        const double bk = s_cell[(size_t)k * 6 + 5];  // (W == 6 on this path)
         ok = bk != -__builtin_inf();
         gb = bk < gb ? bk : gb;
-        const double tk = s_cell[(size_t)k * TW_CELL];
+        const double tk = s_cell[(size_t)k * 6];
         gt = tk > gt ? tk : gt;
       }
     }
@@ -587,6 +617,7 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   }
   __builtin_amdgcn_wave_barrier();
   PM_TICK(8)
+  const CellView<W> cv{s_cell, nz};
   PsibRange rg;
   rg.gbot = s_gbot;
   rg.gtop = s_gtop;
@@ -625,18 +656,18 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
       rg.gmax = lin.at(ilast < nb ? ilast : nb - 1);
     }
     if constexpr (BIG == 2) {
-      psib_pairwise<4>(s_cell, 0, nc, bg, res, rg PM_TICK_ARG);
+      psib_pairwise<4, CellView<W>>(cv, 0, nc, bg, res, rg PM_TICK_ARG);
     } else if constexpr (BIG == 1) {
       // 128 < nc <= 256: NumPy's recursion is exactly two blocks, both inlined
       int n2 = nc / 2;
       n2 -= n2 % 8;
       double r2[TW_JT];
-      psib_block_sum(s_cell, 0, n2, bg, res, rg PM_TICK_ARG);
-      psib_block_sum(s_cell, n2, nc - n2, bg, r2, rg PM_TICK_ARG);
+      psib_block_sum(cv, 0, n2, bg, res, rg PM_TICK_ARG);
+      psib_block_sum(cv, n2, nc - n2, bg, r2, rg PM_TICK_ARG);
 #pragma unroll
       for (int j = 0; j < TW_JT; ++j) res[j] = res[j] + r2[j];
     } else {
-      psib_block_sum(s_cell, 0, nc, bg, res, rg PM_TICK_ARG);  // nc <= 128: one pairwise block
+      psib_block_sum(cv, 0, nc, bg, res, rg PM_TICK_ARG);  // nc <= 128: one pairwise block
     }
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) {
@@ -695,6 +726,7 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   PM_WAVE_END(m_raw)
 }
 
+#ifndef PM_DIAG_DEVICE_FUNCTIONS_ONLY  // (coupled_run.hip.h shares tw_member only)
 template <int P, int BIG>
 __global__ __launch_bounds__(64 * TW_WAVES_PER_BLOCK)
 __attribute__((amdgpu_waves_per_eu((P <= 4 && BIG != 2) ? 4 : 1))) void k_thermwind(pm_thermwind a,
@@ -793,5 +825,7 @@ inline int dispatch_thermwind(const pm_thermwind &a, int ops, hipStream_t st) {
   }
   return fail(PM_EINVAL, "nz=%d unsupported by thermwind (max 1024)", a.nz);
 }
+
+#endif  // PM_DIAG_DEVICE_FUNCTIONS_ONLY
 
 }  // namespace pm

@@ -61,6 +61,59 @@ class Event(object):
       pass
 
 
+class LaunchTimer(object):
+  """HIP events around every launch of a driver run (`ens.timer = LaunchTimer()`): the run-average
+  duration of each kernel IN SITU -- every launch on the state and forcing the run gives it --
+  which is what a roofline figure of a coupled config has to be computed from (replaying a
+  kernel on the run's final state is up to 25 % off).  Events are recorded on the stream the
+  kernel is launched on; `summary()` synchronises."""
+
+  class _Span(object):
+    def __init__(self, timer, name, stream):
+      self.timer, self.name, self.stream = timer, name, stream
+
+    def __enter__(self):
+      self.e0, self.e1 = Event(), Event()
+      self.e0.record(self.stream)
+      return self
+
+    def __exit__(self, et, ev, tb):
+      self.e1.record(self.stream)
+      self.timer.spans.append((self.name, self.e0, self.e1))
+      return False
+
+  def __init__(self):
+    self.spans = []
+
+  def span(self, name, stream=None):
+    return LaunchTimer._Span(self, name, stream)
+
+  def summary(self):
+    """{name: (launches, total ms)}"""
+    synchronize()
+    out = {}
+    for name, e0, e1 in self.spans:
+      n, t = out.get(name, (0, 0.0))
+      out[name] = (n + 1, t + e0.elapsed_ms(e1))
+    return out
+
+
+class _NoSpan(object):
+  def __enter__(self):
+    return self
+
+  def __exit__(self, et, ev, tb):
+    return False
+
+
+_NO_SPAN = _NoSpan()
+
+
+def launch_span(timer, name, stream=None):
+  """`with launch_span(self.timer, "k_thermwind", stream): launch` -- a no-op without a timer."""
+  return _NO_SPAN if timer is None else timer.span(name, stream)
+
+
 class Graph(object):
   """A captured launch sequence (hipGraph): `with Graph.capture(stream) as g: ...`."""
 

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _lib
 from .columns import ColumnBatch
-from .device import DeviceArray, _sh
+from .device import DeviceArray, _sh, launch_span
 from .equilibrium import ColumnEquiBatch
 from .psi_so import PsiSOBatch
 from .sharding import DiagnosticGather
@@ -171,6 +171,7 @@ class TwoColEnsemble(object):
     self.stream = stream
     self.diag_iters = cfg.get('Diag_iters') if diag_iters is None else diag_iters
     self.diag = None
+    self.timer = None  # optional device.LaunchTimer: events around every launch of run()
     if comm is not None or keep_history:
       self.diag = DiagnosticGather(comm, n, n if n_total is None else n_total,
                                    [(k, nz) for k in ('b_basin', 'b_north', 'Psi', 'Psi_SO')],
@@ -236,10 +237,12 @@ class TwoColEnsemble(object):
       self._ev_fork.record(self.stream)     # the columns' steps before this update
       self._side.wait(self._ev_fork)
       self.so.stream = self._side
-      self.so.update(self._b_basin, self.bs_SO)
+      with launch_span(self.timer, "k_psi_so", self._side):
+        self.so.update(self._b_basin, self.bs_SO)
       self.so.stream = self.stream
       self._ev_join.record(self._side)
-      self.tw.update(self._b_basin, self._b_north, ops=_TW_ALL, store_psib=False)
+      with launch_span(self.timer, "k_thermwind", self.stream):
+        self.tw.update(self._b_basin, self._b_north, ops=_TW_ALL, store_psib=False)
       if self.stream is not None:
         self.stream.wait(self._ev_join)
       else:
@@ -247,12 +250,19 @@ class TwoColEnsemble(object):
         check(lib.pm_stream_wait_event(None, self._ev_join.handle))
       return
     if self.so is not None:
-      self.so.update(self._b_basin, self.bs_SO)
-    self.tw.update(self._b_basin, self._b_north, ops=_TW_ALL, store_psib=False,
-                   Psi_SO=self._psi_so(),
-                   wA1=self.wA.ptr, wA2=self.wA.ptr + self._off)
+      with launch_span(self.timer, "k_psi_so", self.stream):
+        self.so.update(self._b_basin, self.bs_SO)
+    with launch_span(self.timer, "k_thermwind", self.stream):
+      self.tw.update(self._b_basin, self._b_north, ops=_TW_ALL, store_psib=False,
+                     Psi_SO=self._psi_so(),
+                     wA1=self.wA.ptr, wA2=self.wA.ptr + self._off)
 
   def _steps(self, n):
+    with launch_span(self.timer, "k_column_steps" if n >= 3 else "k_column_steps_short",
+                     self.stream):
+      self._steps_launch(n)
+
+  def _steps_launch(self, n):
     if self.so is not None and self._overlap and n >= 3:
       self.cols.steps(None, self.dt, n, lanes_per_col=self.lanes, arith=self.arith,
                       psi_forcing=(self.tw.psibz, self.so.Psi))
@@ -298,7 +308,8 @@ class TwoColEnsemble(object):
       d.tw = self.tw.descriptor(self._b_basin, self._b_north, wA1=self.wA.ptr,
                                 wA2=self.wA.ptr + self._off, store_psib=False)
       d.wA, d.dt, d.sched, d.status = self.wA.ptr, self.dt, sch, self.run_status.ptr
-      _lib.check(_lib.lib.pm_twocol_run(C.byref(d), _sh(self.stream)))
+      with launch_span(self.timer, "k_twocol_run", self.stream):
+        _lib.check(_lib.lib.pm_twocol_run(C.byref(d), _sh(self.stream)))
       remaining -= end - ii
       self.ii = end
       if gather_at is not None:
@@ -357,8 +368,8 @@ class JN2018Ensemble(object):
     """`fused_run`: whole stretches of the loop -- many [PsiSO.solve, AMOC.solve / Psibz,
     MOC_up_iters steps] intervals -- in ONE launch of the persistent per-member kernel
     (pm_jn2018_run), ending a launch only where diagnostics are sampled or gathered;
-    bit-identical to the launch sequence.  None = where it applies (the fused step loop's
-    conditions and the phases' LDS within 160 KB).
+    bit-identical to the launch sequence; needs the fused step loop's conditions and the phases'
+    LDS within 160 KB.  None = off (measured slower than the launch sequence: DESIGN.md section 6).
     `comm`, `n_total`, `diag_iters`: as for TwoColEnsemble; the gather happens where the
     script samples its diagnostics (`if ii % Diag_iters == 0`, right after the MOC update,
     run_JansenNadeau_2018.py:218-226; default Diag_iters = 10 MOC_up_iters, :99).
@@ -414,13 +425,17 @@ class JN2018Ensemble(object):
     # fused: one launch per MOC block for the whole [BC switch, 2 columns, mixed layer] loop
     self._fused = (nz <= 256) if fused is None else bool(fused)
     self.recorder = None  # optional diagnostics.JN2018Diagnostics
+    self.timer = None     # optional device.LaunchTimer
     can_fuse = (self._fused and self.cols.uniform_area and ny <= 64 and
                 _run_fits(1, nz, self.nb, ny))
     if fused_run and not can_fuse:
       raise ValueError("fused_run needs the fused step loop (Area constant in z, ny <= 64, "
                        "4 <= nz <= 256) and the phases' LDS within 160 KB")
-    self._fused_run = can_fuse if fused_run is None else bool(fused_run)
+    self._fused_run = False if fused_run is None else bool(fused_run)
     self._updated_at = -1  # iteration whose MOC update has been done already (fused_run)
+    # the two diagnostic launches of an update as one (pm_so_tw_update): scalar tau only? no --
+    # any Psi_SO without the boundary-value smoother on nz <= 256
+    self._one_update_launch = bool(cfg.get('one_update_launch', True)) and nz <= 256
     self.diag_iters = (cfg.get('Diag_iters', 10 * self.M) if diag_iters is None
                        else diag_iters)
     self.diag = None
@@ -442,11 +457,22 @@ class JN2018Ensemble(object):
 
   def _update(self):
     b_basin, b_north = self.cols.b.ptr, self.cols.b.ptr + self._off
-    self.so.update(b_basin, self.ml.bs)
+    if self._one_update_launch:
+      # PsiSO.solve + AMOC.solve / Psibz of a member by one wave, ONE launch (pm_so_tw_update)
+      ds = self.so.descriptor(b_basin, self.ml.bs)
+      dw = self.tw.descriptor(b_basin, b_north, Psi_SO=self.so.Psi, wA1=self.wA.ptr,
+                              wA2=self.wA.ptr + self._off, store_psib=self.recorder is not None)
+      with launch_span(self.timer, "k_so_tw_update", self.stream):
+        _lib.check(_lib.lib.pm_so_tw_update(self._C.byref(ds), self._C.byref(dw), _TW_ALL,
+                                            _sh(self.stream)))
+      return
+    with launch_span(self.timer, "k_psi_so", self.stream):
+      self.so.update(b_basin, self.ml.bs)
     # psib / bgrid go to HBM only when a diagnostics recorder will read them
-    self.tw.update(b_basin, b_north, ops=_TW_ALL, store_psib=self.recorder is not None,
-                   Psi_SO=self.so.Psi, wA1=self.wA.ptr,
-                   wA2=self.wA.ptr + self._off)
+    with launch_span(self.timer, "k_thermwind", self.stream):
+      self.tw.update(b_basin, b_north, ops=_TW_ALL, store_psib=self.recorder is not None,
+                     Psi_SO=self.so.Psi, wA1=self.wA.ptr,
+                     wA2=self.wA.ptr + self._off)
 
   def _step(self):
     from ._lib import check, lib
@@ -464,7 +490,8 @@ class JN2018Ensemble(object):
     from ._lib import check, lib
     from .device import _sh
     d = self._jn_descriptor()
-    check(lib.pm_jn2018_steps(self._C.byref(d), self.dt, int(nsteps), _sh(self.stream)))
+    with launch_span(self.timer, "k_jn2018_steps", self.stream):
+      check(lib.pm_jn2018_steps(self._C.byref(d), self.dt, int(nsteps), _sh(self.stream)))
 
   def _jn_descriptor(self):
     from ._lib import pm_jn2018, pm_so_ml
@@ -525,7 +552,8 @@ class JN2018Ensemble(object):
                                 store_psib=self.recorder is not None)
       d.dt, d.sched = self.dt, sch
       check(lib.pm_memset(self.ml.status.ptr, 0, self.ml.status.nbytes, _sh(self.stream)))
-      check(lib.pm_jn2018_run(self._C.byref(d), _sh(self.stream)))
+      with launch_span(self.timer, "k_jn2018_run", self.stream):
+        check(lib.pm_jn2018_run(self._C.byref(d), _sh(self.stream)))
       remaining -= pos - ii
       self.ii = pos
       if stopped:

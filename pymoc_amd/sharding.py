@@ -153,6 +153,9 @@ class RcclCommunicator(object):
     h = C.c_void_p()
     _lib.check(_lib.lib.pm_comm_init(C.byref(h), self.world, self.rank, buf))
     self.handle = h
+    # a communicator someone asked for explicitly runs its collectives even with ONE rank
+    # (bench.py --force-rccl, the single-GPU rehearsal of the N > 1 path): DiagnosticGather
+    self.always_collective = True
     self._scalar = DeviceArray((2,))
     self.barrier()
     if self.rank == 0:
@@ -244,8 +247,12 @@ class DiagnosticGather(object):
     self.keep_history = keep_history
     self.history = []  # [(step, {field: [n_total, nlev]})] when keep_history
     self.ngathers = 0
+    self.ncollectives = 0  # device collectives issued (RCCL all-gathers)
     self._send = self._recv = None
     self._host = None  # last gathered [world][count] in host mode
+
+  def _collective_always(self):
+    return bool(getattr(self.comm, "always_collective", False))
 
   def due(self, step, diag_iters):
     return diag_iters is not None and diag_iters > 0 and step % int(diag_iters) == 0
@@ -255,7 +262,7 @@ class DiagnosticGather(object):
     from .device import DeviceArray
     if self._send is None:
       self._send = DeviceArray.zeros((self.count,), stream=self.stream)
-      self._recv = (self._send if self.comm.world == 1 else
+      self._recv = (self._send if (self.comm.world == 1 and not self._collective_always()) else
                     DeviceArray((self.comm.world, self.count)))
     return self._send, self._recv
 
@@ -268,8 +275,9 @@ class DiagnosticGather(object):
       ptr = src if isinstance(src, int) else src.ptr
       check(lib.pm_memcpy_d2d(send.ptr + 8 * self.offsets[name], ptr,
                               8 * self.n_local * nlev, _sh(self.stream)))
-    if self.comm.world > 1:
+    if self.comm.world > 1 or self._collective_always():
       self.comm.allgather_device(send, recv, self.stream)
+      self.ncollectives += 1
 
   # ------------------------------------------------------------------ host path
   def _to_host(self, src, nlev):

@@ -83,7 +83,7 @@ fake = types.SimpleNamespace(ColumnBatch=ColumnBatch, TwoColEnsemble=Ensemble, J
 comm = Comm()
 env = dict(pymoc_amd=fake, configs=configs, DeviceArray=DeviceArray, Event=Event, stream=Stream(),
            comm=comm, rank=comm.rank, world=comm.world)
-bench.kernel_breakdown = lambda config, cfg, ens, env, reps=20: ({}, {"bound": "stub"})
+bench.kernel_breakdown = lambda config, env, members, nsteps, warm_blocks: ({}, {"bound": "stub"})
 args = types.SimpleNamespace(members=8, nz=100, steps_per_launch=10, steps=3, warmup=1, lanes=0,
                              force_rccl=False, no_single_step=True)
 outs = {}

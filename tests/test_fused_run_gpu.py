@@ -93,7 +93,7 @@ def test_twocol_fused_run_ieee_leg(gpu):
   assert np.all(st[[i for i in range(32) if i not in (5, 9)]] & 32 == 0)
 
 
-@pytest.mark.parametrize("nz,ny,dt_days", [(81, 51, 30.), (100, 40, 30.)])
+@pytest.mark.parametrize("nz,ny,dt_days", [(81, 51, 30.), (100, 40, 30.), (200, 51, 10.)])
 def test_jn2018_fused_run_equals_launch_sequence_bitwise(gpu, nz, ny, dt_days):
   """run_JansenNadeau_2018.py's loop: pm_jn2018_run against [pm_psi_so_update, pm_thermwind_update,
   pm_jn2018_steps] per interval, every split of the run; with the diagnostics recorder attached
@@ -108,7 +108,7 @@ def test_jn2018_fused_run_equals_launch_sequence_bitwise(gpu, nz, ny, dt_days):
   M = a.M
   a.recorder = JN2018Diagnostics(a, 2 * M, 20 * M)
   b.recorder = JN2018Diagnostics(b, 2 * M, 20 * M)
-  for n in (1, M - 1, M, 5, 3 * M + 7, 2 * M - 12, 4 * M):
+  for n in (1, M - 1, M, 5, 3 * M + 7, 2 * M - 10, 4 * M):
     a.run(n)
     b.run(n)
     assert a.ii == b.ii
@@ -181,3 +181,24 @@ def test_jn2018_fused_steps_ieee_leg_bitwise_vs_oracle(gpu):
       assert np.array_equal(s["b_north"][m], bn, equal_nan=True), (fused_run, m)
       assert np.array_equal(s["bs_SO"][m], bsSO, equal_nan=True), (fused_run, m)
     assert st[3] & 32 == 0
+
+
+@pytest.mark.parametrize("nz,ny,dt_days", [(200, 51, 10.), (81, 51, 30.), (150, 40, 10.), (46, 51, 30.)])
+def test_one_update_launch_equals_two_launches_bitwise(gpu, nz, ny, dt_days):
+  """pm_so_tw_update (PsiSO.solve + AMOC.solve / Psibz of a member by one wave, one launch) against
+  pm_psi_so_update followed by pm_thermwind_update: every lane shape (P = 1 ... 4)."""
+  N = 70
+  c = configs.config5(N=N, nz=nz, ny=ny, dt_days=dt_days)
+  c["rest_mask"] = np.repeat(c["rest_mask"][None], N, axis=0)
+  a = gpu.JN2018Ensemble(dict(c, one_update_launch=True), fused_run=False)
+  b = gpu.JN2018Ensemble(dict(c, one_update_launch=False), fused_run=False)
+  assert a._one_update_launch and not b._one_update_launch
+  for n in (1, 2 * a.M, a.M + 3):
+    a.run(n)
+    b.run(n)
+    sb = b.state()
+    ok = np.isfinite(sb["b_basin"]).all(axis=1) & np.isfinite(sb["bs_SO"]).all(axis=1)
+    _same(a.state(), sb, rows=ok, what="nz=%d ii=%d" % (nz, a.ii))
+    for k in ("Psi_Ek", "Psi_GM"):
+      assert np.array_equal(getattr(a.so, k).download()[ok], getattr(b.so, k).download()[ok])
+    assert np.array_equal(a.so.status.download()[ok], b.so.status.download()[ok])

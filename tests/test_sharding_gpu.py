@@ -140,3 +140,43 @@ def test_explicit_stream_equals_default_stream(gpu):
     sa, sb = a.state(), b.state()
     for k in sa:
       assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("args,nfields", [
+    (["--config", "4", "--members", "512", "--steps", "20", "--warmup", "2"], 4),
+    (["--config", "5", "--members", "256", "--steps", "20", "--warmup", "2"], 4),
+    (["--config", "2", "--steps", "3", "--warmup", "1", "--no-single-step"], 0),
+])
+def test_bench_under_torch_distributed_run_with_rccl_one_rank(gpu, args, nfields):
+  """Rehearsal of the driver's N > 1 launch on the one GPU a test box has:
+  `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --force-rccl ...` as a
+  FRESH child process (the launcher starts the rank before anything in it touches the GPU).
+  RCCL is initialised through the launcher's environment, its barrier / all-reduce bracket the
+  timed region, and the Diag_iters all-gathers of {b_basin, b_north, Psi_AMOC, Psi_SO} run INSIDE
+  the timed region as real RCCL collectives on device buffers, next to the two-stream update of
+  config 4.  What this cannot show is more than one rank: no 1 -> 8 curve has been measured."""
+  import importlib.util
+  import json
+  # (torch must NOT be imported into this process: its bundled ROCm runtime next to the system's
+  # makes a later in-process RCCL initialisation fail with "no ROCm-capable device")
+  if importlib.util.find_spec("torch") is None:
+    pytest.skip("torch.distributed.run not available")
+  port = _free_port()
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+         "--master-addr", "127.0.0.1", "--master-port", str(port),
+         os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-rccl", "--no-cpu-baseline"] + args
+  env = dict(os.environ, OMP_NUM_THREADS="1")
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+  assert p.returncode == 0, p.stderr[-2000:]
+  line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+  out = json.loads(line)
+  assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
+  if nfields:
+    members, nz = out["members_per_gpu"], out["nz"]
+    assert out["gathers_in_timed_region"] >= 2   # the cadence gathers + the final one
+    assert out["rccl_collectives_in_timed_region"] == out["gathers_in_timed_region"]
+    # SURVEY 8(e): members_per_gpu x n_fields x nz x 8 B per rank and gather
+    assert out["gather_bytes_per_rank"] == members * nfields * nz * 8
+    assert set(out["nonfinite"]) <= {2, 1268}  # (config 5: the two members the REFERENCE loses)
