@@ -1204,6 +1204,7 @@ inline int dispatch_psi_so(const pm_psi_so &a, int ops, hipStream_t st) {
   return fail(PM_EINVAL, "nz=%d unsupported by psi_so (max 512)", a.nz);
 }
 
+
 #endif  // PM_DIAG_DEVICE_FUNCTIONS_ONLY
 
 }  // namespace pm
