@@ -125,11 +125,16 @@ int pm_graph_destroy(pm_graph_t graph);
                                 to rounding (<= 1e-12 relative over BASELINE's runs), not bit for
                                 bit; without the flag every result is bit-identical to NumPy.    */
 
+#define PM_COLS_ALL_UNIFORM_AREA 1 /* pm_columns.reserved, batch-wide HINT: EVERY column carries
+                              PM_COL_UNIFORM_AREA.  With it, PM_OP_WEFF and kappa_base /
+                              kappa_profile a one-step launch on a large batch keeps only b and
+                              weff of a column in flight (24 nz B per column-step)               */
+
 typedef struct pm_columns {
   int32_t ncols;         /* independent columns in the batch                      */
   int32_t nz;            /* levels per column (2 <= nz <= 1024)                   */
   int32_t nsel;          /* coefficient sets per column (1, or 2 for JN2018)      */
-  int32_t reserved;
+  int32_t reserved;      /* batch-wide hint bits (PM_COLS_*), else 0              */
   const double *z;       /* [nz]              shared grid, ascending              */
   double *b;             /* [ncols][nz]       buoyancy, updated in place          */
   const double *kappa;   /* [nsel][ncols][nz] kappa(z)                            */
@@ -143,6 +148,16 @@ typedef struct pm_columns {
   const int32_t *ksel;   /* [ncols] coefficient set in use (NULL -> set 0)        */
   int32_t *nonfinite;    /* [ncols] out: 1 if b holds a non-finite value at the
                             end of the call (NULL -> not reported)                */
+  const double *kappa_base;    /* [ncols] or NULL */
+  const double *kappa_profile; /* [nz] or NULL.  Both given (nsel = 1): a HINT that
+                            kappa[col][i] == kappa_base[col] + kappa_profile[i] BIT FOR BIT (one
+                            fp64 addition) -- a parameter sweep over a background diffusivity, the
+                            kappa sweep of BASELINE's ensembles.  Launches that stream the
+                            coefficient arrays (one or two steps per launch on a large batch) then
+                            FORM kappa instead of reading it: with PM_OP_WEFF 24 nz B per
+                            column-step (b and weff in, b out: SURVEY 8d's algorithmic bytes) instead
+                            of 32 nz.  The caller vouches for the identity (the Python ColumnBatch
+                            verifies it on the host arrays); other launches read kappa as ever.  */
 } pm_columns;
 
 /* nsteps repetitions of the selected ops with wA (and vdx_in/b_in) held fixed, the

@@ -22,6 +22,7 @@ PM_EQ_HFREE, PM_EQ_HAS_BBOT, PM_EQ_KAPPA_ARRAY, PM_EQ_PSI_ARRAY = 1, 2, 4, 8
 PM_OP_CONVECT, PM_OP_VERTADVDIFF, PM_OP_HORADV, PM_OP_TIMESTEP, PM_OP_WEFF = 1, 2, 4, 7, 8
 PM_OP_CONTRACTED = 16
 PM_OP_WA_PSI = 32
+PM_COLS_ALL_UNIFORM_AREA = 1
 
 c_dp = C.c_void_p  # device pointers travel as plain addresses
 
@@ -38,7 +39,8 @@ class pm_columns(C.Structure):
       ("ncols", C.c_int32), ("nz", C.c_int32), ("nsel", C.c_int32),
       ("reserved", C.c_int32), ("z", c_dp), ("b", c_dp), ("kappa", c_dp),
       ("area", c_dp), ("dAkappa", c_dp), ("bs", c_dp), ("bbot", c_dp), ("bzbot", c_dp),
-      ("N2min", c_dp), ("flags", c_dp), ("ksel", c_dp), ("nonfinite", c_dp)
+      ("N2min", c_dp), ("flags", c_dp), ("ksel", c_dp), ("nonfinite", c_dp),
+      ("kappa_base", c_dp), ("kappa_profile", c_dp)
   ]
 
 

@@ -53,7 +53,12 @@ def _in_fast_range(x):
 
 class ColumnBatch(object):
   def __init__(self, z, kappa, area, b, bs=0.025, bbot=0.0, bzbot=None, N2min=1e-7,
-               do_conv=False, kappa_alt=None, stream=None, report_nonfinite=True):
+               do_conv=False, kappa_alt=None, stream=None, report_nonfinite=True,
+               kappa_affine=None):
+    """`kappa_affine=(kappa_base [ncols], kappa_profile [nz])`: the sweep's structure, when
+    `kappa == kappa_base[:, None] + kappa_profile[None, :]` holds BIT FOR BIT (checked here; a
+    ValueError otherwise).  One-step launches on a large batch then form kappa on the device
+    instead of streaming it (pm_columns.kappa_base / kappa_profile)."""
     _lib.require_device()
     z = np.ascontiguousarray(z, dtype=np.float64)
     if z.ndim != 1 or z.size < 2:
@@ -70,6 +75,8 @@ class ColumnBatch(object):
     self.z = DeviceArray.from_host(z, stream=stream)
     self.b = DeviceArray.from_host(b, stream=stream)
     self.nsel = 2 if kappa_alt is not None else 1
+    self.kappa_base = self.kappa_profile = None
+    self._kappa_affine = kappa_affine
     self.kappa = DeviceArray((self.nsel, ncols, nz))
     self.dAk = DeviceArray((self.nsel, ncols, nz))
     self.area = DeviceArray((ncols, nz))
@@ -107,6 +114,16 @@ class ColumnBatch(object):
         np.array_equal(a[:h], np.broadcast_to(a[0], (h, nz))) and
         np.array_equal(a[h:], np.broadcast_to(a[h], (h, nz))) for a in [area] + ks))
     self.kappa.upload(np.stack(ks), self.stream)
+    aff = getattr(self, "_kappa_affine", None)
+    self.kappa_base = self.kappa_profile = None
+    if aff is not None and self.nsel == 1:
+      kb = np.ascontiguousarray(aff[0], dtype=np.float64).reshape(ncols)
+      kp = np.ascontiguousarray(aff[1], dtype=np.float64).reshape(nz)
+      if not np.array_equal(kb[:, None] + kp[None, :], ks[0]):
+        raise ValueError("kappa_affine: kappa != kappa_base[:, None] + kappa_profile[None, :] bit for bit")
+      self.kappa_base = DeviceArray.from_host(kb, stream=self.stream)
+      self.kappa_profile = DeviceArray.from_host(kp, stream=self.stream)
+    self._kappa_affine = None  # (a later set_static without the pair drops the hint)
     dAks = [dAkappa_dz(area, k, self.z_host) for k in ks]
     self.dAk.upload(np.stack(dAks), self.stream)
     # PM_COL_STATIC_IN_RANGE (include/pymoc_hip.h): the static operands of a column lie inside
@@ -190,12 +207,15 @@ class ColumnBatch(object):
   # ------------------------------------------------------------------ compute
   def descriptor(self):
     d = pm_columns()
-    d.ncols, d.nz, d.nsel, d.reserved = self.ncols, self.nz, self.nsel, 0
+    d.ncols, d.nz, d.nsel = self.ncols, self.nz, self.nsel
+    d.reserved = _lib.PM_COLS_ALL_UNIFORM_AREA if self.uniform_area else 0
     d.z, d.b = self.z.ptr, self.b.ptr
     d.kappa, d.area, d.dAkappa = self.kappa.ptr, self.area.ptr, self.dAk.ptr
     d.bs, d.bbot, d.bzbot, d.N2min = self.bs.ptr, self.bbot.ptr, self.bzbot.ptr, self.N2min.ptr
     d.flags, d.ksel = self.flags.ptr, self.ksel.ptr
     d.nonfinite = self.nonfinite.ptr if self.nonfinite else None
+    if self.kappa_base is not None:
+      d.kappa_base, d.kappa_profile = self.kappa_base.ptr, self.kappa_profile.ptr
     return d
 
   def kernel_shape(self, lanes_per_col=0):

@@ -27,7 +27,7 @@ def _slice(members, N):
 
 # keys of each ensemble config that carry one entry per member (first axis = member)
 PER_MEMBER = {
-    2: ("kappa", "Area", "wA", "b0", "bs", "bbot", "N2min", "do_conv"),
+    2: ("kappa", "kappa_back", "Area", "wA", "b0", "bs", "bbot", "N2min", "do_conv"),
     3: ("kappa", "A_basin", "A_north", "bs", "bs_north", "bbot", "b_basin0", "b_north0"),
     4: ("kappa", "tau", "KGM", "A_basin", "A_north", "bs", "bs_north", "bbot", "bs_SO",
         "b_basin0", "b_north0"),
@@ -69,12 +69,13 @@ def config2(N=1024, nz=100, seed=20240, members=None):
   n = idx.size
   z = np.linspace(-4000., 0., nz)
   bbot = -0.003
-  kappa = kappa_back[:, None] + 2e-4 * np.exp(-z / 1000 - 4)[None, :]
+  kappa_profile = 2e-4 * np.exp(-z / 1000 - 4)
+  kappa = kappa_back[:, None] + kappa_profile[None, :]
   Area = np.repeat(area[:, None], nz, axis=1)
   wA = area[:, None] * w0[:, None] * np.sin(np.pi * z / 4000.)[None, :]
   b0 = (bs[:, None] - bbot) * np.exp(z / 300.)[None, :] + bbot
-  return dict(z=z, kappa=kappa, Area=Area, wA=wA, b0=b0, bs=bs,
-              bbot=np.full(n, bbot), N2min=np.full(n, 1e-7),
+  return dict(z=z, kappa=kappa, kappa_back=kappa_back, kappa_profile=kappa_profile, Area=Area,
+              wA=wA, b0=b0, bs=bs, bbot=np.full(n, bbot), N2min=np.full(n, 1e-7),
               do_conv=(idx % 2 == 1), dt=30 * DAY, nsteps=1000, members=idx)
 
 

@@ -929,13 +929,19 @@ template <int P>
 struct ColStage {
   double b[P], wA[P], kap[P], area[P], dAk[P];
 };
+// LEAN (forcing precombined, Area one number per column, kappa formed from its two factors): a
+// column in flight is b and weff -- 4 P registers per ring stage instead of 10 P
+template <int P>
+struct ColStageLean {
+  double b[P], wA[P];
+};
 
 constexpr int STREAM_MAX_CPW = 64;  // columns per wave <= lanes (the scalars' vector load)
 
 // the wave's per-column scalars, lane i = column col0 + i
 struct StreamScalars {
   int flags, sel;
-  double bs, bbot, bzbot, N2min, area0;
+  double bs, bbot, bzbot, N2min, area0, kbase;
   __device__ __forceinline__ void load(const pm_columns &c, int col0, int cend, int lane) {
     const int col = col0 + lane < cend ? col0 + lane : cend - 1;
     flags = c.flags ? c.flags[col] : 0;
@@ -945,10 +951,12 @@ struct StreamScalars {
     N2min = c.N2min[col];
     bzbot = ((flags & PM_COL_BZBOT) != 0 && c.bzbot != nullptr) ? c.bzbot[col] : 0.0;
     area0 = (flags & PM_COL_UNIFORM_AREA) ? c.area[(size_t)col * c.nz] : 0.0;
+    kbase = c.kappa_base ? c.kappa_base[col] : 0.0;
   }
 };
 
-template <int P>
+// AFF: kappa is formed from kappa_base + kappa_profile (pm_columns), not read
+template <int P, bool AFF = false>
 __device__ __forceinline__ void col_stage_load(ColStage<P> &s, const pm_columns &c,
                                                const double *__restrict__ wA_g, int col,
                                                int lane, bool weff_in, int flags, int sel,
@@ -958,7 +966,7 @@ __device__ __forceinline__ void col_stage_load(ColStage<P> &s, const pm_columns 
   const size_t sbase = ((size_t)sel * c.ncols + col) * nz;
   load_levels<P>(s.b, c.b + base, lane, nz);
   load_levels<P>(s.wA, wA_g + base, lane, nz);
-  load_levels<P>(s.kap, c.kappa + sbase, lane, nz);
+  if constexpr (!AFF) load_levels<P>(s.kap, c.kappa + sbase, lane, nz);
   if ((flags & PM_COL_UNIFORM_AREA) == 0) {
     load_levels<P>(s.area, c.area + base, lane, nz);
   } else {
@@ -973,7 +981,7 @@ __device__ __forceinline__ void col_stage_load(ColStage<P> &s, const pm_columns 
   }
 }
 
-template <int P, int D>
+template <int P, int D, bool AFF = false, bool LEAN = false>
 __global__ __launch_bounds__(256) void k_column_stream(pm_columns c,
                                                        const double *__restrict__ wA_g,
                                                        double dt, int nsteps, int cpw, bool dt_ok,
@@ -987,15 +995,27 @@ __global__ __launch_bounds__(256) void k_column_stream(pm_columns c,
 
   StreamScalars sc;
   sc.load(c, col0, cend, lane);
+  static_assert(!LEAN || AFF, "the lean ring needs the affine kappa");
+  using Stage = typename std::conditional<LEAN, ColStageLean<P>, ColStage<P>>::type;
   auto flags_of = [&](int k) { return __builtin_amdgcn_readlane(sc.flags, k); };
-  auto issue = [&](ColStage<P> &st, int col) {
+  auto issue = [&](Stage &st, int col) {
     const int k = col - col0;
-    col_stage_load<P>(st, c, wA_g, col, lane, weff_in, flags_of(k),
-                      __builtin_amdgcn_readlane(sc.sel, k), lane_value(sc.area0, k));
+    if constexpr (LEAN) {
+      const size_t base = (size_t)col * nz;
+      load_levels<P>(st.b, c.b + base, lane, nz);
+      load_levels<P>(st.wA, wA_g + base, lane, nz);
+    } else {
+      col_stage_load<P, AFF>(st, c, wA_g, col, lane, weff_in, flags_of(k),
+                             __builtin_amdgcn_readlane(sc.sel, k), lane_value(sc.area0, k));
+    }
   };
   ColGrid<P> g;
   col_load_grid<P, 1>(g, c, lane);
-  ColStage<P> ring[D];
+  double kprof[P];  // AFF: the shared part of kappa, once per wave
+#pragma unroll
+  for (int p = 0; p < P; ++p) kprof[p] = 0.0;
+  if constexpr (AFF) load_levels<P>(kprof, c.kappa_profile, lane, nz);
+  Stage ring[D];
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (col0 + d < cend) issue(ring[d], col0 + d);
@@ -1010,9 +1030,17 @@ __global__ __launch_bounds__(256) void k_column_stream(pm_columns c,
       for (int p = 0; p < P; ++p) {
         r.b[p] = ring[d].b[p];
         wA[p] = ring[d].wA[p];
-        r.kap[p] = ring[d].kap[p];
-        r.area[p] = ring[d].area[p];
-        r.dAk[p] = ring[d].dAk[p];
+        if constexpr (AFF)  // kappa[col][i] = kappa_base[col] + kappa_profile[i]: the caller's identity
+          r.kap[p] = lane_value(sc.kbase, col - col0) + kprof[p];
+        else
+          r.kap[p] = ring[d].kap[p];
+        if constexpr (LEAN) {
+          r.area[p] = lane_value(sc.area0, col - col0);
+          r.dAk[p] = 0.0;  // weff - 0 = weff, exactly
+        } else {
+          r.area[p] = ring[d].area[p];
+          r.dAk[p] = ring[d].dAk[p];
+        }
         r.rarea[p] = r.rarea_l[p] = 0.;
       }
       if (col + D < cend) issue(ring[d], col + D);  // keep D columns' loads in flight
@@ -1118,9 +1146,48 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
       const bool dt_ok = dt == 0.0 || (adt >= 0x1p-200 && adt <= 0x1p200);
       // stages of the load ring: three arrays per column with the forcing precombined, five
       // without (the ring's registers bound the occupancy)
-      if (weff_in)
+      const bool aff = c.kappa_base && c.kappa_profile && c.nsel == 1;
+      // PM_COL_BATCH_UNIFORM_AREA in reserved: the caller vouches that EVERY column carries
+      // PM_COL_UNIFORM_AREA (the kernel cannot branch per column on what its ring holds)
+      const bool lean = weff_in && aff && (c.reserved & PM_COLS_ALL_UNIFORM_AREA) != 0;
+      static const int lean_d = []() {
+        const char *e = getenv("PYMOC_STREAM_LEAN_D");  // experiments: ring depth of the lean form
+        return e ? atoi(e) : 0;
+      }();
+      if (lean && lean_d == 4)
+        hipLaunchKernelGGL((k_column_stream<P, 4, true, true>), dim3((waves + 3) / 4), dim3(256), 0,
+                           st, c, wA, dt, nsteps, cpw, dt_ok, weff_in);
+      else if (lean && lean_d == 5)
+        hipLaunchKernelGGL((k_column_stream<P, 5, true, true>), dim3((waves + 3) / 4), dim3(256), 0,
+                           st, c, wA, dt, nsteps, cpw, dt_ok, weff_in);
+      else if (lean && lean_d == 8)
+        hipLaunchKernelGGL((k_column_stream<P, 8, true, true>), dim3((waves + 3) / 4), dim3(256), 0,
+                           st, c, wA, dt, nsteps, cpw, dt_ok, weff_in);
+      else if (lean && lean_d == 6)
+        hipLaunchKernelGGL((k_column_stream<P, 6, true, true>), dim3((waves + 3) / 4), dim3(256), 0,
+                           st, c, wA, dt, nsteps, cpw, dt_ok, weff_in);
+      else if (lean) {
+        // measured at 262144 columns x nz = 100 (profiles/r04/probe_stream_lean.py): ring depth
+        // 4 / 5 / 6 / 8 -> 150.5 / 148.8 / 158.6 / 154.8 us at their best columns-per-wave; 16
+        // columns per wave beat 32 (the non-lean forms' choice) and 8
+        int cl = cpw;
+        if (!getenv("PYMOC_STREAM_CPW")) {
+          cl = c.ncols / 16384;
+          cl = cl < 2 ? 2 : (cl > 16 ? 16 : cl);
+        }
+        const unsigned wl = (unsigned)((c.ncols + cl - 1) / cl);
+        hipLaunchKernelGGL((k_column_stream<P, 5, true, true>), dim3((wl + 3) / 4), dim3(256), 0, st,
+                           c, wA, dt, nsteps, cl, dt_ok, weff_in);
+      }
+      else if (weff_in && aff)
+        hipLaunchKernelGGL((k_column_stream<P, 4, true>), dim3((waves + 3) / 4), dim3(256), 0, st, c,
+                           wA, dt, nsteps, cpw, dt_ok, weff_in);
+      else if (weff_in)
         hipLaunchKernelGGL((k_column_stream<P, 3>), dim3((waves + 3) / 4), dim3(256), 0, st, c, wA,
                            dt, nsteps, cpw, dt_ok, weff_in);
+      else if (aff)
+        hipLaunchKernelGGL((k_column_stream<P, 3, true>), dim3((waves + 3) / 4), dim3(256), 0, st, c,
+                           wA, dt, nsteps, cpw, dt_ok, weff_in);
       else
         hipLaunchKernelGGL((k_column_stream<P, 2>), dim3((waves + 3) / 4), dim3(256), 0, st, c, wA,
                            dt, nsteps, cpw, dt_ok, weff_in);

@@ -322,7 +322,7 @@ int pm_column_kernel_name(int32_t ncols, int32_t nz, int32_t lanes_per_col, int3
   const bool plain =
       (ops & ~(PM_OP_WEFF | PM_OP_CONTRACTED | PM_OP_WA_PSI)) == PM_OP_TIMESTEP && !has_horadv;
   if (G == 64 && P <= 4 && nsteps < 3 && plain && stream_cols_per_wave(ncols) >= 2)
-    snprintf(name, name_len, "k_column_stream<%d>", P);
+    snprintf(name, name_len, "k_column_stream<%d>", P);  // (+ ring depth / affine-kappa variants)
   else if (G == 64 && P <= 4 && nsteps >= 3 && plain && (ops & PM_OP_CONTRACTED))
     snprintf(name, name_len, "k_column_steps<64,%d,4,true>", P);
   else  // mirrors launch_column_steps (column.hip.h)

@@ -453,3 +453,34 @@ def test_contracted_mode_ragged_sizes_and_splits(gpu, nz):
     sp.steps(wA, dt, n, arith="contracted")
   assert _rel(ct.get_b(), ex.get_b()) <= CONTRACTED_RTOL
   assert _rel(sp.get_b(), ex.get_b()) <= CONTRACTED_RTOL
+
+
+@pytest.mark.parametrize("nsteps,precombined", [(1, True), (2, True), (1, False), (25, True)])
+def test_affine_kappa_hint_bitwise(gpu, nsteps, precombined):
+  """pm_columns.kappa_base / kappa_profile: a kappa sweep kappa[m][i] = kappa_back[m] + profile[i]
+  (how BASELINE config 2 is built) handed over as its two factors -- the streaming kernel forms
+  kappa with one addition instead of reading it (24 nz instead of 32 nz B per column-step with the
+  forcing precombined).  Same bits as streaming the array, on a ragged large batch with mixed
+  flags; a pair that does not reproduce the array is refused."""
+  N = 70001
+  c = configs.config2(N=N)
+  kw = dict(bs=c["bs"], bbot=c["bbot"], N2min=c["N2min"], do_conv=c["do_conv"])
+  plain = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"], **kw)
+  aff = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"],
+                        kappa_affine=(c["kappa_back"], c["kappa_profile"]), **kw)
+  assert aff.kappa_base is not None and plain.kappa_base is None
+  wA = gpu.DeviceArray.from_host(c["wA"])
+  fa, fp = (aff.combine_forcing(wA), plain.combine_forcing(wA)) if precombined else (wA, wA)
+  for _ in range(3):
+    plain.steps(fp, c["dt"], nsteps, precombined=precombined)
+    aff.steps(fa, c["dt"], nsteps, precombined=precombined)
+  assert np.array_equal(plain.get_b(), aff.get_b())
+  m = 12345
+  ref = c["b0"][m].copy()
+  for _ in range(3 * nsteps):
+    ref = O.column_timestep(c["z"], c["kappa"][m], c["Area"][m], ref, c["wA"][m], c["dt"],
+                            do_conv=bool(c["do_conv"][m]), bs=c["bs"][m], bbot=c["bbot"][m])
+  assert np.array_equal(aff.get_b()[m], ref)
+  with pytest.raises(ValueError):
+    gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"],
+                    kappa_affine=(c["kappa_back"] * (1 + 2.0**-52), c["kappa_profile"]), **kw)

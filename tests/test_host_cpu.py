@@ -28,10 +28,24 @@ def test_library_exports_every_declared_symbol():
   assert b"gfx950" in _lib.lib.pm_version()
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+  """sizeof of every struct of include/pymoc_hip.h as gcc sees it against its ctypes mirror."""
+  import subprocess
+  from conftest import ROOT
   from pymoc_amd import _lib
-  # 4 int32 + 12 pointers
-  assert ctypes.sizeof(_lib.pm_columns) == 16 + 12 * 8
+  names = ["pm_columns", "pm_thermwind", "pm_psi_so", "pm_so_ml", "pm_jn2018_bc", "pm_jn2018",
+           "pm_run_schedule", "pm_twocol_loop", "pm_jn2018_loop", "pm_column_equi",
+           "pm_equi_column"]
+  src = tmp_path / "sizes.c"
+  src.write_text('#include <stdio.h>\n#include "pymoc_hip.h"\nint main(void) {\n' +
+                 "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in names) +
+                 "  return 0;\n}\n")
+  exe = tmp_path / "sizes"
+  subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+  out = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+  for n in names:
+    assert ctypes.sizeof(getattr(_lib, n)) == int(out[n]), n
+  assert ctypes.sizeof(_lib.pm_columns) == 16 + 14 * 8  # 4 int32 + 14 pointers
 
 
 def test_no_device_fails_loudly():
