@@ -289,7 +289,7 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
       for (int p = 0; p < P; ++p) rr[p] = __builtin_fma(-g.dz[p], q[p], num[p]);
 #pragma unroll
       for (int p = 0; p < P; ++p) q[p] = __builtin_fma(rr[p], g.rdz[p], q[p]);
-    } else if constexpr (DIV == 1 || DIV == 3) {
+    } else if constexpr (DIV == 1 || DIV == 3 || DIV == 5) {
 #pragma unroll
       for (int p = 0; p < P; ++p) q[p] = num[p] * g.rdz[p];
 #pragma unroll
@@ -355,6 +355,20 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
     for (int p = 0; p < P; ++p) {
       bzz[p] = __builtin_fma(r1[p], g.rdzc[p], bzz[p]);
       adv[p] = __builtin_fma(r2[p], (UA ? r.rarea_u : r.rarea[p]), adv[p]);
+    }
+  } else if constexpr (DIV == 5) {  // grid as DIV == 3; Area (UA: one number) by its double-double reciprocal
+    double r1[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      bzz[p] = dbz[p] * g.rdzc[p];
+      adv[p] = div_by_recip2(flx[p], r.area_u, r.rarea_u, r.rarea_lu);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) r1[p] = __builtin_fma(-g.dzc[p], bzz[p], dbz[p]);
+#pragma unroll
+      for (int p = 0; p < P; ++p) bzz[p] = __builtin_fma(r1[p], g.rdzc[p], bzz[p]);
     }
   } else if constexpr (DIV == 3) {  // grid division by reciprocal, area by IEEE division
     double r1[P];
@@ -953,6 +967,7 @@ constexpr int STREAM_MAX_CPW = 64;  // columns per wave <= lanes (the scalars' v
 struct StreamScalars {
   int flags, sel;
   double bs, bbot, bzbot, N2min, area0, kbase;
+  double ra, ral;  // RN(1 / area0) and its low part, for ALL the wave's columns by one vector division
   __device__ __forceinline__ void load(const pm_columns &c, int col0, int cend, int lane) {
     const int col = col0 + lane < cend ? col0 + lane : cend - 1;
     flags = c.flags ? c.flags[col] : 0;
@@ -963,6 +978,8 @@ struct StreamScalars {
     bzbot = ((flags & PM_COL_BZBOT) != 0 && c.bzbot != nullptr) ? c.bzbot[col] : 0.0;
     area0 = (flags & PM_COL_UNIFORM_AREA) ? c.area[(size_t)col * c.nz] : 0.0;
     kbase = c.kappa_base ? c.kappa_base[col] : 0.0;
+    ra = 1.0 / area0;
+    ral = recip_lo(area0, ra);
   }
 };
 
@@ -1047,6 +1064,9 @@ __global__ __launch_bounds__(256) void k_column_stream(pm_columns c,
           r.kap[p] = ring[d].kap[p];
         if constexpr (LEAN) {
           r.area[p] = lane_value(sc.area0, col - col0);
+          r.area_u = r.area[p];
+          r.rarea_u = lane_value(sc.ra, col - col0);
+          r.rarea_lu = lane_value(sc.ral, col - col0);
           r.dAk[p] = 0.0;  // weff - 0 = weff, exactly
         } else {
           r.area[p] = ring[d].area[p];
@@ -1073,6 +1093,9 @@ __global__ __launch_bounds__(256) void k_column_stream(pm_columns c,
         col_pin<P>(r.b);
         if (__builtin_expect(slow, 0))
           col_vertadvdiff<64, P, 0>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lane, nz);
+        else if constexpr (LEAN)  // (Area one number: its reciprocal came with the wave's scalars)
+          col_vertadvdiff<64, P, 5, true, false, true>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot,
+                                                       bzbot, lane, nz);
         else
           col_vertadvdiff<64, P, 3>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lane, nz);
       }
