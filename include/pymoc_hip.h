@@ -315,9 +315,11 @@ typedef struct pm_so_ml {
                               kernel only) an operand of the column steps -- state, forcing,
                               coefficients, grid, dt -- outside the window [2^-200, 2^200] in
                               which the kernel's 4-instruction division is IEEE-identical: the
-                              member was stepped, but is not guaranteed bit-identical to the
-                              reference's arithmetic; pm_column_steps tests the same and falls
-                              back to IEEE division instead (may be NULL)               */
+                              member's steps from there on were taken by the call's follow-up
+                              launch with true divisions (the reference's arithmetic for any
+                              operand, like pm_column_steps' own fallback); informational.
+                              Bits 8.. are scratch of that hand-over and are cleared by it
+                              (may be NULL: pm_jn2018_steps then uses its general kernel)   */
 } pm_so_ml;
 
 int pm_so_ml_step(const pm_so_ml *ml, double dt, pm_stream_t stream);

@@ -255,6 +255,37 @@ def test_config3_full_length_sweep_vs_reference(gpu):
     assert np.array_equal(sp[k], st[k][1024:1536]), k
 
 
+def test_config3_at_the_example_scripts_own_length_bitwise_vs_oracle(gpu):
+  """example_twocol.py runs 48 000 steps (:44-45, 4000 years at dt = 30 d); BASELINE asks for
+  2400.  The whole 4096-member ensemble over the script's own length: the members that stay
+  finite in the oracle are reproduced BIT FOR BIT at the end (every kernel of this driver is
+  bit-identical to the oracle, so 2000 overturning updates and 96 000 column steps per member add
+  no drift at all), and the members the explicit scheme loses on the way (a fifth of this sweep
+  within 48 000 steps, none within BASELINE's 2400; small A_basin) are lost by the oracle too."""
+  c = configs.config3(N=4096)
+  n = 48000
+  ens = gpu.TwoColEnsemble(c)
+  ens.run(2400)
+  assert ens.nonfinite_members().size == 0
+  ens.run(n - 2400)
+  st = ens.state()
+  lost = set(int(i) for i in ens.nonfinite_members())
+  assert 0 < len(lost) < 4096 // 4
+  keys = ("A_basin", "A_north", "bs", "bs_north", "bbot", "kappa", "b_basin0", "b_north0")
+  for i in (5, 1234, 3000, 100, 4095):
+    m = dict(c)
+    for k in keys:
+      m[k] = c[k][i]
+    s = drivers.run_twocol(m, n, {n})[n]
+    if np.isfinite(s["b_basin"]).all() and np.isfinite(s["b_north"]).all():
+      assert i not in lost
+      for k in ("b_basin", "b_north", "Psi", "Psi_iso_b", "Psi_iso_n"):
+        assert np.array_equal(st[k][i], s[k]), (i, k)
+    else:
+      assert i in lost, i
+  assert {100, 4095} <= lost and not ({5, 1234, 3000} & lost)
+
+
 def test_coupled_configs_with_contracted_columns_vs_reference(gpu):
   """The columns in the opt-in tolerance mode inside the coupled drivers (VERDICT r2 item 2:
   does Psib's discontinuity let the coupled tolerances survive?): BASELINE configs 3 and 4 at
