@@ -233,7 +233,11 @@ class ColumnBatch(object):
     buf = C.create_string_buffer(96)
     check(lib.pm_column_kernel_name(self.ncols, self.nz, int(lanes_per_col), int(nsteps),
                                     int(ops), int(bool(horadv)), buf, 96))
-    return buf.value.decode()
+    name = buf.value.decode()
+    # the batch-wide PM_COLS_ALL_UNIFORM_AREA hint selects the scalar-Area instantiation
+    if self.uniform_area and name.startswith("k_column_steps<64,") and name.endswith(",2,true>"):
+      name = name[:-1] + ",true>"
+    return name
 
   def combine_forcing(self, wA, out=None):
     """weff = wA - d(A kappa)/dz of each column's coefficient set in use, on the device

@@ -599,7 +599,7 @@ __device__ __forceinline__ unsigned conv_variant(const ConvCache<P> &cc) {
 // conditional branch several; the 3-instruction loop control and the check's compare + branch
 // are paid once per UNR steps.  Returns the number of steps done when the new pattern belongs
 // to another SEL class (the caller re-dispatches) or at nsteps.
-template <int P, int DIV, unsigned SEL>
+template <int P, int DIV, unsigned SEL, bool UA = false>
 __device__ __forceinline__ int conv_spec_run(const ColGrid<P> &g, ColRegs<P> &r,
                                              const double (&wA)[P], double dt, double bs,
                                              double bbot, double N2min, int lane, int nz,
@@ -641,7 +641,7 @@ __device__ __forceinline__ int conv_spec_run(const ColGrid<P> &g, ColRegs<P> &r,
       // established the cached pattern imposed it, and neither vertadvdiff (the surface level
       // advances with dt = 0) nor an unchanged pattern alters that level
     }
-    col_vertadvdiff<64, P, DIV, false>(g, r, wA, dt, true, bs, bbot, false, 0., lane, nz);
+    col_vertadvdiff<64, P, DIV, false, false, UA>(g, r, wA, dt, true, bs, bbot, false, 0., lane, nz);
     // (mask ^ cached) AFTER the step's arithmetic has been issued (no wait for the compare
     // results).  The xor is asm because the optimiser rewrites the C form of the whole test
     // into compare + select chains (more scalar instructions).
@@ -683,7 +683,7 @@ __device__ __forceinline__ int conv_spec_run(const ColGrid<P> &g, ColRegs<P> &r,
     for (int k = 0; k < nb; ++k) {
       col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);
       if (lane == 0) r.b[0] = bbot;
-      col_vertadvdiff<64, P, DIV, false>(g, r, wA, dt, true, bs, bbot, false, 0., lane, nz);
+      col_vertadvdiff<64, P, DIV, false, false, UA>(g, r, wA, dt, true, bs, bbot, false, 0., lane, nz);
     }
   };
   // Blocks of UNR steps, then of 4, then of 1.  The only loop-carried scalar of a tier is the count of blocks left;
@@ -766,7 +766,10 @@ __device__ __forceinline__ void col_pin(double (&b)[P]) {
 
 // PLAIN: ops == PM_OP_TIMESTEP without horadv inputs -- the time loop then carries no
 // loop-invariant branches (they cost a lone wave ~15% of a step).
-template <int G, int P, int FAST, bool PLAIN>
+// UA (launch-level: pm_columns.reserved & PM_COLS_ALL_UNIFORM_AREA): Area and its reciprocal pair
+// are three scalars instead of three P-element arrays -- 12 registers at P = 2, which is what
+// separates 4 from 5 waves per SIMD (108 -> 96).
+template <int G, int P, int FAST, bool PLAIN, bool UA = false>
 __global__ __launch_bounds__(256) void k_column_steps(
     pm_columns c, const double *__restrict__ wA_g, const double *__restrict__ vdx_g,
     const double *__restrict__ bin_g, double dt, int nsteps, int ops) {
@@ -786,6 +789,11 @@ __global__ __launch_bounds__(256) void k_column_steps(
   // (a wave holds one column when G == 64: the hint is then wave-uniform)
   const bool ua = G == 64 && __builtin_amdgcn_readfirstlane(flags & PM_COL_UNIFORM_AREA) != 0;
   col_load_static<P, FAST>(r, c, col, sel, lg, 0, ua, (ops & PM_OP_WEFF) != 0);
+  if constexpr (UA) {  // (the arrays col_load_static filled with the same number die here)
+    r.area_u = lane_value(r.area[0], 0);
+    r.rarea_u = lane_value(r.rarea[0], 0);
+    r.rarea_lu = lane_value(r.rarea_l[0], 0);
+  }
 
   double wA[P], vdx[P], bin[P];
   load_levels<P>(r.b, c.b + base, lg, nz);
@@ -858,7 +866,7 @@ __global__ __launch_bounds__(256) void k_column_steps(
     if (do_conv && use_bzbot) {
       for (int s = 0; s < nsteps; ++s) {
         col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
-        col_vertadvdiff<G, P, FAST>(g, r, wA, dt, true, bs, bbot, true, bzbot, lg, nz);
+        col_vertadvdiff<G, P, FAST, true, false, UA>(g, r, wA, dt, true, bs, bbot, true, bzbot, lg, nz);
       }
     } else if (do_conv) {
       // b[0] = bbot is constant unless a convection event rewrites level 0: impose it once
@@ -870,34 +878,34 @@ __global__ __launch_bounds__(256) void k_column_steps(
       if constexpr (G == 64) {
         col_convect_cached<P>(r.b, g.z, bs, N2min, lane, nz, cc);  // step 0: establishes cc
         if (lg == 0) r.b[0] = bbot;
-        col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
+        col_vertadvdiff<G, P, FAST, false, false, UA>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
         int s = 1;
         while (s < nsteps) {  // one pass per established pattern class (rarely more than one)
           const unsigned v = conv_variant<P>(cc);
           if constexpr (P <= 2) {
             switch (v) {
-              case 0: s = conv_spec_run<P, FAST, 0u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
-              case 1: s = conv_spec_run<P, FAST, 1u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
-              case 2: s = conv_spec_run<P, FAST, 2u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
-              default: s = conv_spec_run<P, FAST, 3u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
+              case 0: s = conv_spec_run<P, FAST, 0u, UA>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
+              case 1: s = conv_spec_run<P, FAST, 1u, UA>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
+              case 2: s = conv_spec_run<P, FAST, 2u, UA>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
+              default: s = conv_spec_run<P, FAST, 3u, UA>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps); break;
             }
           } else {
             if (v == 0u)
-              s = conv_spec_run<P, FAST, 0u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps);
+              s = conv_spec_run<P, FAST, 0u, UA>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps);
             else
-              s = conv_spec_run<P, FAST, (1u << P) - 1u>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps);
+              s = conv_spec_run<P, FAST, (1u << P) - 1u, UA>(g, r, wA, dt, bs, bbot, N2min, lane, nz, cc, s, nsteps);
           }
         }
       } else {
         for (int s = 0; s < nsteps; ++s) {
           col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
           if (lg == 0) r.b[0] = bbot;  // column.py:232 (a convection event may rewrite level 0)
-          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
+          col_vertadvdiff<G, P, FAST, false, false, UA>(g, r, wA, dt, true, bs, bbot, false, 0., lg, nz);
         }
       }
     } else if (use_bzbot) {
       for (int s = 0; s < nsteps; ++s)
-        col_vertadvdiff<G, P, FAST>(g, r, wA, dt, false, bs, bbot, true, bzbot, lg, nz);
+        col_vertadvdiff<G, P, FAST, true, false, UA>(g, r, wA, dt, false, bs, bbot, true, bzbot, lg, nz);
     } else {
       // constant boundary values: impose them once, then run the BC-free step
 #pragma unroll
@@ -910,14 +918,14 @@ __global__ __launch_bounds__(256) void k_column_steps(
       int s = 0;
       if constexpr (P <= 2) {
         for (; s + 4 <= nsteps; s += 4) {
-          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
-          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
-          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
-          col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
+          col_vertadvdiff<G, P, FAST, false, false, UA>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
+          col_vertadvdiff<G, P, FAST, false, false, UA>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
+          col_vertadvdiff<G, P, FAST, false, false, UA>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
+          col_vertadvdiff<G, P, FAST, false, false, UA>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
         }
       }
       for (; s < nsteps; ++s)
-        col_vertadvdiff<G, P, FAST, false>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
+        col_vertadvdiff<G, P, FAST, false, false, UA>(g, r, wA, dt, false, bs, bbot, false, 0., lg, nz);
     }
   } else {
     for (int s = 0; s < nsteps; ++s) {
@@ -925,7 +933,7 @@ __global__ __launch_bounds__(256) void k_column_steps(
         col_convect<G, P>(r.b, g.z, bs, N2min, lg, lane, nz, c.z);
       col_pin<P>(r.b);
       if (ops & PM_OP_VERTADVDIFF)
-        col_vertadvdiff<G, P, FAST>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lg, nz);
+        col_vertadvdiff<G, P, FAST, true, false, UA>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lg, nz);
       if ((ops & PM_OP_HORADV) && vdx_g) col_horadv<P>(r, vdx, bin, dt, lg, nz);
     }
   }
@@ -1238,7 +1246,16 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
     }
   }
   // the reciprocal path pays 3 true divisions per level up front: worth it from 3 steps on
-  if (nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx)
+  bool launched = false;
+  if constexpr (G == 64 && P <= 4) {
+    if (nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx && (c.reserved & PM_COLS_ALL_UNIFORM_AREA)) {
+      hipLaunchKernelGGL((k_column_steps<G, P, 2, true, true>), dim3(grid), dim3(256), 0, st, c, wA,
+                         vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
+      launched = true;
+    }
+  }
+  if (launched) {
+  } else if (nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx)
     hipLaunchKernelGGL((k_column_steps<G, P, 2, true>), dim3(grid), dim3(256), 0, st, c, wA,
                        vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
   else if (nsteps >= 3)
