@@ -130,7 +130,9 @@ class ColumnBatch(object):
     # the window of the kernels' exact-division shortcut, so the one-step streaming kernel only
     # has to test the state and the forcing
     dz = np.diff(self.z_host)
-    ok = _in_fast_range(self.z_host).all() and _in_fast_range(dz).all() and (dz != 0).all()
+    dzc = 0.5 * (dz[1:] + dz[:-1])  # column.py:238's spacing, as the kernels form it
+    ok = (_in_fast_range(self.z_host).all() and _in_fast_range(dz).all() and (dz != 0).all() and
+          _in_fast_range(dzc).all() and (dzc != 0).all())
     self._static_ok = np.full(ncols, bool(ok))
     for a in [area] + ks + dAks:
       self._static_ok &= _in_fast_range(a).all(axis=1)
