@@ -181,6 +181,100 @@ __device__ __forceinline__ SoElem so_shfl_down(const SoElem &e, int d) {
   return o;
 }
 
+// Lane movement of the scans by DPP (vector-ALU moves) instead of ds_bpermute (LDS pipe, and
+// an LDS round trip of latency per scan step).  GFX9 DPP controls: row_shr:d = 0x110 + d
+// (lane i <- lane i-d inside its row of 16), row_shl:d = 0x100 + d, row_bcast:15 = 0x142 (lane
+// 15 of every row to all of the next row), row_bcast:31 = 0x143 (lane 31 to the upper half);
+// lanes without a source, and rows masked out, receive 0.
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ double so_dpp(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWS, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWS, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ SoElem so_dpp(const SoElem &e) {
+  SoElem o;
+  o.a11 = so_dpp<CTRL, ROWS>(e.a11);
+  o.a12 = so_dpp<CTRL, ROWS>(e.a12);
+  o.c1 = so_dpp<CTRL, ROWS>(e.c1);
+  o.a21 = so_dpp<CTRL, ROWS>(e.a21);
+  o.a22 = so_dpp<CTRL, ROWS>(e.a22);
+  o.c2 = so_dpp<CTRL, ROWS>(e.c2);
+  return o;
+}
+__device__ __forceinline__ double so_lane_value(double x, int src_lane) {  // src_lane: constant
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Inclusive prefix scan of chunk elements over the wave: on return lane i holds the element of
+// [first node of lane 0, last node of lane i].  Lanes with `has` are a prefix of the wave.
+// Rows of 16 by doubling, then the row totals: 6 merges per lane like the plain doubling scan,
+// associated differently (this solve is compared at 1e-11, never bitwise).
+__device__ __forceinline__ SoElem so_prefix_scan(SoElem PL, bool has, int lane) {
+  const int li = lane & 15;
+  SoElem o = so_dpp<0x111>(PL);
+  if (li >= 1 && has) PL = so_merge(o, PL);
+  o = so_dpp<0x112>(PL);
+  if (li >= 2 && has) PL = so_merge(o, PL);
+  o = so_dpp<0x114>(PL);
+  if (li >= 4 && has) PL = so_merge(o, PL);
+  o = so_dpp<0x118>(PL);
+  if (li >= 8 && has) PL = so_merge(o, PL);
+  o = so_dpp<0x142, 0xa>(PL);
+  if ((lane & 16) && has) PL = so_merge(o, PL);
+  o = so_dpp<0x143, 0xc>(PL);
+  if (lane >= 32 && has) PL = so_merge(o, PL);
+  return PL;
+}
+
+// Suffix scan of affine maps u_i = A_i + B_i u_(i+1): on return A is u_i given that the map of
+// the last lane is a constant (B = 0 there).
+__device__ __forceinline__ double so_affine_suffix_scan(double A, double B, int lane) {
+#pragma clang fp contract(fast)
+  const int li = lane & 15;
+#define SO_AFFINE_STEP(D)                                                  \
+  {                                                                        \
+    const double A2 = so_dpp<0x100 + D>(A), B2 = so_dpp<0x100 + D>(B);     \
+    if (li + D < 16) {                                                     \
+      A = __builtin_fma(B, A2, A);                                         \
+      B = B * B2;                                                          \
+    }                                                                      \
+  }
+  SO_AFFINE_STEP(1)
+  SO_AFFINE_STEP(2)
+  SO_AFFINE_STEP(4)
+  SO_AFFINE_STEP(8)
+#undef SO_AFFINE_STEP
+  {  // rows 0 and 2 continue into rows 1 and 3
+    const double A16 = so_lane_value(A, 16), B16 = so_lane_value(B, 16);
+    const double A48 = so_lane_value(A, 48), B48 = so_lane_value(B, 48);
+    const double A2 = lane < 32 ? A16 : A48, B2 = lane < 32 ? B16 : B48;
+    if (!(lane & 16)) {
+      A = __builtin_fma(B, A2, A);
+      B = B * B2;
+    }
+  }
+  {  // the lower half continues into the upper half
+    const double A2 = so_lane_value(A, 32);
+    if (lane < 32) A = __builtin_fma(B, A2, A);
+  }
+  return A;
+}
+
+// inclusive prefix sum over the wave
+__device__ __forceinline__ int so_prefix_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------
 // The GM boundary-value problem on the mesh scipy.integrate.solve_bvp itself ends on
 // (a.bvp_refine <= 0, the default; a.bvp_refine = R > 0 selects the fixed R-fold mesh, 2-3x
@@ -489,33 +583,20 @@ __device__ __forceinline__ void so_reg_solve(const SoRegMesh &w, int m, double u
     if (c < nl) TL = so_merge(TL, e[c]);
   PM_TICK(1)
   // ---- prefix scan: PL = element of [node 0, this chunk's last node]
-  SoElem PL = TL;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const SoElem o = so_shfl_up(PL, d);
-    if (lane >= d && has) PL = so_merge(o, PL);
-  }
+  const SoElem PL = so_prefix_scan(TL, has, lane);
   PM_TICK(2)
   // ---- chunk-end values: (PL.a22 + TLn.a11) u_l + TLn.a12 u_l(next) = PL.c2 + TLn.c1 - PL.a21 ua
-  const double n11 = __shfl_down(TL.a11, 1, 64), n12 = __shfl_down(TL.a12, 1, 64),
-               nc1 = __shfl_down(TL.c1, 1, 64);
-  const bool next_has = __shfl_down(has ? 1 : 0, 1, 64) != 0 && lane < 63;
+  const double n11 = from_next_lane_z(TL.a11), n12 = from_next_lane_z(TL.a12),
+               nc1 = from_next_lane_z(TL.c1);
+  const bool next_has = lane < 63 && f + RC < ne;  // the chunks with intervals are a prefix
   double A = ub, B = 0.;
   if (has && next_has) {
     const double rden = so_rcp(PL.a22 + n11);
     A = (PL.c2 + nc1 - PL.a21 * ua) * rden;
     B = -n12 * rden;
   }
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const double A2 = __shfl_down(A, d, 64), B2 = __shfl_down(B, d, 64);
-    if (lane + d < 64) {
-      A = __builtin_fma(B, A2, A);
-      B = B * B2;
-    }
-  }
-  const double ul = A;
-  double uf = __shfl_up(ul, 1, 64);
+  const double ul = so_affine_suffix_scan(A, B, lane);
+  double uf = from_prev_lane_z(ul);
   if (lane == 0) uf = ua;
   PM_TICK(3)
   // ---- Thomas inside the chunk between uf (node f) and ul (node f + nl)
@@ -582,7 +663,7 @@ __device__ __forceinline__ int so_gm_adaptive_reg(const SoRegMesh &w, int nz, do
       case 3: so_reg_solve<3>(w, m, ua, ub, lane PM_TICK_ARG); break;
       default: so_reg_solve<4>(w, m, ua, ub, lane PM_TICK_ARG); break;
     }
-    const bool next_has = __shfl_down(has ? 1 : 0, 1, 64) != 0 && lane < 63;
+    const bool next_has = lane < 63 && f + C < ne;
     __builtin_amdgcn_wave_barrier();
     // ---- rms residual and insertion count of every interval (estimate_rms_residuals); a real
     // loop (register pressure); the counts of the lane's intervals are packed 2 bits each
@@ -633,12 +714,7 @@ __device__ __forceinline__ int so_gm_adaptive_reg(const SoRegMesh &w, int nz, do
     // ---- new mesh (modify_mesh): positions by a prefix sum of the nodes each lane writes; its
     // last entry is the new node count
     const int mine = nl + added;
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += o;
-    }
+    const int incl = so_prefix_sum(mine);
     added = __builtin_amdgcn_readlane(incl, 63) - ne;
     const bool grow = added != 0 && m + added <= max_nodes && m + added <= SO_REG_CAP;
     if (!grow) {
