@@ -160,27 +160,6 @@ __device__ __forceinline__ SoElem so_merge(const SoElem &E, const SoElem &e) {
   return o;
 }
 
-__device__ __forceinline__ SoElem so_shfl_up(const SoElem &e, int d) {
-  SoElem o;
-  o.a11 = __shfl_up(e.a11, d, 64);
-  o.a12 = __shfl_up(e.a12, d, 64);
-  o.c1 = __shfl_up(e.c1, d, 64);
-  o.a21 = __shfl_up(e.a21, d, 64);
-  o.a22 = __shfl_up(e.a22, d, 64);
-  o.c2 = __shfl_up(e.c2, d, 64);
-  return o;
-}
-__device__ __forceinline__ SoElem so_shfl_down(const SoElem &e, int d) {
-  SoElem o;
-  o.a11 = __shfl_down(e.a11, d, 64);
-  o.a12 = __shfl_down(e.a12, d, 64);
-  o.c1 = __shfl_down(e.c1, d, 64);
-  o.a21 = __shfl_down(e.a21, d, 64);
-  o.a22 = __shfl_down(e.a22, d, 64);
-  o.c2 = __shfl_down(e.c2, d, 64);
-  return o;
-}
-
 // Lane movement of the scans by DPP (vector-ALU moves) instead of ds_bpermute (LDS pipe, and
 // an LDS round trip of latency per scan step).  GFX9 DPP controls: row_shr:d = 0x110 + d
 // (lane i <- lane i-d inside its row of 16), row_shl:d = 0x100 + d, row_bcast:15 = 0x142 (lane
@@ -228,6 +207,48 @@ __device__ __forceinline__ SoElem so_prefix_scan(SoElem PL, bool has, int lane) 
   o = so_dpp<0x143, 0xc>(PL);
   if (lane >= 32 && has) PL = so_merge(o, PL);
   return PL;
+}
+
+// Suffix scan: on return lane i holds the element of [first node of lane i, last node of the
+// last lane with `has`]; nhas = number of lanes with `has` (they are a prefix of the wave).
+__device__ __forceinline__ SoElem so_lane_value(const SoElem &e, int src_lane) {
+  SoElem o;
+  o.a11 = so_lane_value(e.a11, src_lane);
+  o.a12 = so_lane_value(e.a12, src_lane);
+  o.c1 = so_lane_value(e.c1, src_lane);
+  o.a21 = so_lane_value(e.a21, src_lane);
+  o.a22 = so_lane_value(e.a22, src_lane);
+  o.c2 = so_lane_value(e.c2, src_lane);
+  return o;
+}
+__device__ __forceinline__ SoElem so_select(bool first, const SoElem &a, const SoElem &b) {
+  SoElem o;
+  o.a11 = first ? a.a11 : b.a11;
+  o.a12 = first ? a.a12 : b.a12;
+  o.c1 = first ? a.c1 : b.c1;
+  o.a21 = first ? a.a21 : b.a21;
+  o.a22 = first ? a.a22 : b.a22;
+  o.c2 = first ? a.c2 : b.c2;
+  return o;
+}
+__device__ __forceinline__ SoElem so_suffix_scan(SoElem PR, int nhas, int lane) {
+  const int li = lane & 15;
+  SoElem o = so_dpp<0x101>(PR);
+  if (li + 1 < 16 && lane + 1 < nhas) PR = so_merge(PR, o);
+  o = so_dpp<0x102>(PR);
+  if (li + 2 < 16 && lane + 2 < nhas) PR = so_merge(PR, o);
+  o = so_dpp<0x104>(PR);
+  if (li + 4 < 16 && lane + 4 < nhas) PR = so_merge(PR, o);
+  o = so_dpp<0x108>(PR);
+  if (li + 8 < 16 && lane + 8 < nhas) PR = so_merge(PR, o);
+  {  // rows 0 and 2 continue into rows 1 and 3
+    const SoElem o16 = so_lane_value(PR, 16), o48 = so_lane_value(PR, 48);
+    o = so_select(lane < 32, o16, o48);
+    if (!(lane & 16) && (lane | 15) + 1 < nhas) PR = so_merge(PR, o);
+  }
+  o = so_lane_value(PR, 32);
+  if (lane < 32 && 32 < nhas) PR = so_merge(PR, o);
+  return PR;
 }
 
 // Suffix scan of affine maps u_i = A_i + B_i u_(i+1): on return A is u_i given that the map of
@@ -378,25 +399,16 @@ __device__ __forceinline__ int so_gm_adaptive(SoMesh w, double ua, double ub, in
       TL = (i == f) ? e : so_merge(TL, e);
     }
     // ---- B: scans (lanes with an empty chunk carry nothing; non-empty lanes are a prefix)
-    SoElem PL = TL, PR = TL;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const SoElem o = so_shfl_up(PL, d);
-      if (lane >= d && has) PL = so_merge(o, PL);
-    }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const SoElem o = so_shfl_down(PR, d);
-      const bool ohas = __shfl_down(has ? 1 : 0, d, 64) != 0 && lane + d < 64;
-      if (has && ohas) PR = so_merge(PR, o);
-    }
-    const SoElem XL = so_shfl_up(PL, 1);  // everything left of this chunk (lane > 0)
+    const int nhas = __builtin_popcountll(__ballot(has));
+    const SoElem PL = so_prefix_scan(TL, has, lane);
+    const SoElem PR = so_suffix_scan(TL, nhas, lane);
+    const SoElem XL = so_dpp<0x138>(PL);  // everything left of this chunk (lane > 0)
     // PR: everything from this chunk's first node to the end of the mesh
     // ---- C: first node of the chunk
     double uf = ua;
     if (has && lane > 0) uf = (XL.c2 + PR.c1 - XL.a21 * ua - PR.a12 * ub) / (XL.a22 + PR.a11);
-    double ul = __shfl_down(uf, 1, 64);
-    const bool next_has = __shfl_down(has ? 1 : 0, 1, 64) != 0 && lane < 63;
+    double ul = from_next_lane_z(uf);
+    const bool next_has = lane + 1 < nhas;
     if (!next_has) ul = ub;
     // ---- D: Thomas inside the chunk, Dirichlet ends uf (node f) and ul (node l)
     if (has) {
@@ -473,8 +485,7 @@ __device__ __forceinline__ int so_gm_adaptive(SoMesh w, double ua, double ub, in
       w.cnt[i] = (short)c;
       added += c;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) added += __shfl_xor(added, o, 64);
+    added = __builtin_amdgcn_readlane(so_prefix_sum(added), 63);
     if (added == 0) break;                       // status 0
     static_assert(SO_BIG_CAP >= 1000, "the general solver follows meshes up to max_nodes");
     if (m + added > max_nodes) {
@@ -487,12 +498,7 @@ __device__ __forceinline__ int so_gm_adaptive(SoMesh w, double ua, double ub, in
     // ---- G: new mesh (modify_mesh); chunk-wise prefix sum of 1 + cnt
     int mine = 0;
     for (int i = f; i < l; ++i) mine += 1 + w.cnt[i];
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += o;
-    }
+    const int incl = so_prefix_sum(mine);
     int pos = incl - mine;
     for (int i = f; i < l; ++i) {
       const double xa = w.x[i], xb = w.x[i + 1];
@@ -1131,20 +1137,12 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
     SoElem TL = Lp[P - 1];  // element of all valid intervals of this lane (Lp saturates at cnt-1)
     SoElem TR = Rp[0];
     const bool has = cnt > 0;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const SoElem o = so_shfl_up(TL, d);
-      if (lane >= d && has) TL = so_merge(o, TL);  // lanes to the left of a valid lane are full
-    }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const SoElem o = so_shfl_down(TR, d);
-      const bool ohas = __shfl_down(has ? 1 : 0, d, 64) != 0 && lane + d < 64;
-      if (has && ohas) TR = so_merge(TR, o);
-    }
-    const SoElem XL = so_shfl_up(TL, 1);    // everything left of this lane
-    const SoElem XR = so_shfl_down(TR, 1);  // everything right of this lane
-    const bool xr_has = __shfl_down(has ? 1 : 0, 1, 64) != 0 && lane < 63;
+    const int nhas = __builtin_popcountll(__ballot(has));  // lanes to the left of a valid lane are full
+    TL = so_prefix_scan(TL, has, lane);
+    TR = so_suffix_scan(TR, nhas, lane);
+    const SoElem XL = so_dpp<0x138>(TL);  // everything left of this lane
+    const SoElem XR = so_dpp<0x130>(TR);  // everything right of this lane
+    const bool xr_has = lane + 1 < nhas;
     // L_{i-1} of this lane's first node lives in the previous lane
     SoElem Lfull[P], Rfull[P];
 #pragma unroll
@@ -1152,7 +1150,7 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
       Lfull[p] = (lane > 0) ? so_merge(XL, Lp[p]) : Lp[p];
       Rfull[p] = xr_has ? so_merge(Rp[p], XR) : Rp[p];
     }
-    const SoElem Lprev = so_shfl_up(Lfull[P - 1], 1);
+    const SoElem Lprev = so_dpp<0x138>(Lfull[P - 1]);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = lane * P + p;
