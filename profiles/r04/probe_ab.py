@@ -27,6 +27,7 @@ for c in sys.argv[3:]:
     print("%s config %d: %.4g coupled steps/s, %.1f us per interval" % (sys.argv[2], c, n * steps / t, t / (steps / e.M) * 1e6), flush=True)
     del e
 '''
-for tag, path in (("r03 ", os.path.join(ROOT, "profiles", "r04", "ab_r03")), ("tree", ROOT),
-                  ("r03 ", os.path.join(ROOT, "profiles", "r04", "ab_r03")), ("tree", ROOT)):
+OTHER = os.path.join(ROOT, "profiles", "r04", os.environ.get("PYMOC_AB_OTHER", "ab_r03"))
+OTAG = os.environ.get("PYMOC_AB_OTHER", "r03 ")[-4:]
+for tag, path in ((OTAG, OTHER), ("tree", ROOT), (OTAG, OTHER), ("tree", ROOT)):
   subprocess.run([sys.executable, "-c", CHILD, path, tag] + (sys.argv[1:] or ["5"]), check=True)

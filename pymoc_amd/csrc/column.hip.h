@@ -469,10 +469,12 @@ __device__ __forceinline__ bool col_inputs_in_fast_range(const ColGrid<P> &g, co
 // kappa)/dz (wA and d(A kappa)/dz enter the step only through their difference).
 template <int P>
 __device__ __forceinline__ bool col_state_in_fast_range(const ColRegs<P> &r, const double (&wA)[P]) {
-  bool ok = true;
+  // (bit operations, not &&: the short-circuit form compiled to a branch per operand)
+  int ok = 1;
 #pragma unroll
-  for (int p = 0; p < P; ++p) ok = ok && in_fast_div_range(r.b[p]) && in_fast_div_range(wA[p] - r.dAk[p]);
-  return ok;
+  for (int p = 0; p < P; ++p)
+    ok &= (int)in_fast_div_range(r.b[p]) & (int)in_fast_div_range(wA[p] - r.dAk[p]);
+  return ok != 0;
 }
 
 // grid metrics of the batch into registers
@@ -1017,8 +1019,13 @@ __device__ __forceinline__ void col_stage_load(ColStage<P> &s, const pm_columns 
   }
 }
 
-template <int P, int D, bool AFF = false, bool LEAN = false>
-__global__ __launch_bounds__(256) void k_column_stream(pm_columns c,
+// VEC (lean form, P == 2; the launcher checks: nz even, b and weff 16-byte aligned): a column's
+// two levels per lane move as ONE 16-byte access at a loop-invariant lane offset from a scalar
+// base.  (load_levels takes that decision per call; inside the ring the compiler turned it
+// into both address forms, selects, and two 8-byte loads.)
+template <int P, int D, bool AFF = false, bool LEAN = false, bool VEC = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VEC ? 4 : 1)))
+void k_column_stream(pm_columns c,
                                                        const double *__restrict__ wA_g,
                                                        double dt, int nsteps, int cpw, bool dt_ok,
                                                        bool weff_in) {
@@ -1032,11 +1039,21 @@ __global__ __launch_bounds__(256) void k_column_stream(pm_columns c,
   StreamScalars sc;
   sc.load(c, col0, cend, lane);
   static_assert(!LEAN || AFF, "the lean ring needs the affine kappa");
+  static_assert(!VEC || (LEAN && P == 2), "16-byte accesses: the lean form with two levels per lane");
+  const int off2 = lane * 2 < nz - 2 ? lane * 2 : nz - 2;  // padding lanes re-read the last pair
   using Stage = typename std::conditional<LEAN, ColStageLean<P>, ColStage<P>>::type;
   auto flags_of = [&](int k) { return __builtin_amdgcn_readlane(sc.flags, k); };
   auto issue = [&](Stage &st, int col) {
     const int k = col - col0;
-    if constexpr (LEAN) {
+    if constexpr (VEC) {
+      const size_t base = (size_t)col * nz;
+      const double2 vb = *reinterpret_cast<const double2 *>(c.b + base + off2);
+      const double2 vw = *reinterpret_cast<const double2 *>(wA_g + base + off2);
+      st.b[0] = vb.x;
+      st.b[P - 1] = vb.y;
+      st.wA[0] = vw.x;
+      st.wA[P - 1] = vw.y;
+    } else if constexpr (LEAN) {
       const size_t base = (size_t)col * nz;
       load_levels<P>(st.b, c.b + base, lane, nz);
       load_levels<P>(st.wA, wA_g + base, lane, nz);
@@ -1110,7 +1127,13 @@ __global__ __launch_bounds__(256) void k_column_stream(pm_columns c,
       const size_t base = (size_t)col * nz;
       bool bad = false;
       bool stored = false;
-      if constexpr (P == 2) {
+      if constexpr (VEC) {
+        if (lane * 2 < nz) {
+          *reinterpret_cast<double2 *>(c.b + base + lane * 2) = make_double2(r.b[0], r.b[P - 1]);
+          bad = !isfinite(r.b[0]) || !isfinite(r.b[P - 1]);
+        }
+        stored = true;
+      } else if constexpr (P == 2) {
         if ((nz & 1) == 0 && (((unsigned long long)(c.b + base)) & 15ull) == 0ull) {
           if (lane * 2 < nz) {
             *reinterpret_cast<double2 *>(c.b + base + lane * 2) = make_double2(r.b[0], r.b[1]);
@@ -1218,8 +1241,18 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
           cl = cl < 2 ? 2 : (cl > 16 ? 16 : cl);
         }
         const unsigned wl = (unsigned)((c.ncols + cl - 1) / cl);
-        hipLaunchKernelGGL((k_column_stream<P, 5, true, true>), dim3((wl + 3) / 4), dim3(256), 0, st,
-                           c, wA, dt, nsteps, cl, dt_ok, weff_in);
+        bool vec = false;
+        if constexpr (P == 2)
+          vec = (c.nz & 1) == 0 && ((((unsigned long long)c.b) | ((unsigned long long)wA)) & 15ull) == 0ull &&
+                !getenv("PYMOC_STREAM_NO_VEC");
+        if constexpr (P == 2) {
+          if (vec)
+            hipLaunchKernelGGL((k_column_stream<P, 5, true, true, true>), dim3((wl + 3) / 4), dim3(256),
+                               0, st, c, wA, dt, nsteps, cl, dt_ok, weff_in);
+        }
+        if (!vec)
+          hipLaunchKernelGGL((k_column_stream<P, 5, true, true>), dim3((wl + 3) / 4), dim3(256), 0,
+                             st, c, wA, dt, nsteps, cl, dt_ok, weff_in);
       }
       else if (weff_in && aff)
         hipLaunchKernelGGL((k_column_stream<P, 4, true>), dim3((waves + 3) / 4), dim3(256), 0, st, c,

@@ -115,7 +115,7 @@ __device__ __forceinline__ double div_by_recip2(double a, double d, double yh, d
 constexpr int FAST_DIV_EXP = 200;
 __device__ __forceinline__ bool in_fast_div_range(double x) {
   const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;  // biased exponent
-  return (e >= 1023u - FAST_DIV_EXP && e <= 1023u + FAST_DIV_EXP) || x == 0.0;
+  return (int)(e - (1023u - FAST_DIV_EXP) <= 2u * FAST_DIV_EXP) | (int)(x == 0.0);
 }
 
 // ... for kernels whose IEEE form is a follow-up launch (the fused JN2018 loop): a NON-FINITE operand
