@@ -1282,7 +1282,11 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
   bool launched = false;
   if constexpr (G == 64 && P <= 4) {
     if (nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx && (c.reserved & PM_COLS_ALL_UNIFORM_AREA)) {
-      hipLaunchKernelGGL((k_column_steps<G, P, 2, true, true>), dim3(grid), dim3(256), 0, st, c, wA,
+      static const int lds_pad = []() {
+        const char *e = getenv("PYMOC_K1_LDS");  // experiments: unused LDS per block caps the occupancy
+        return e ? atoi(e) : 0;
+      }();
+      hipLaunchKernelGGL((k_column_steps<G, P, 2, true, true>), dim3(grid), dim3(256), lds_pad, st, c, wA,
                          vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
       launched = true;
     }
