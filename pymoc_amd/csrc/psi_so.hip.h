@@ -816,15 +816,34 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
   double *s_w = s_tau + ny;  // BVP workspace: T and N2 on the column grid
   const size_t base = (size_t)m * nz;
 
+  // ---- every global operand of the member is requested here, before the first use of any:
+  // taken where they are used, the loads form five dependent round trips to memory (surface
+  // profiles -> levels -> scalars -> the neighbours for N2 -> the grid for the mesh), a
+  // quarter of the member's time under load
+  double z[P], b[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    const int ic = i < nz ? i : nz - 1;
+    z[p] = a.z[ic];
+    b[p] = a.b[base + ic];
+  }
+  const int jf = lane < ny ? lane : ny - 1;
+  const double bs_f = a.bs[(size_t)m * ny + jf], y_f = a.y[jf];
+  const double tau_f = tau_arr ? a.tau[(size_t)m * ny + jf] : 0.;
+  const double tau_s = tau_arr ? 0. : a.tau[m];
+  const double KGM = a.KGM[m];
+
   // ---- stage the member's surface profiles; min / argmin of bs (np.min, np.argmin)
   double mn = __builtin_inf();
   int mi = 0x7fffffff;
   bool nanv = false;
   for (int j = lane; j < ny; j += 64) {
-    const double v = a.bs[(size_t)m * ny + j];
-    s_y[j] = a.y[j];
+    const bool first = j == lane;
+    const double v = first ? bs_f : a.bs[(size_t)m * ny + j];
+    s_y[j] = first ? y_f : a.y[j];
     s_bs[j] = v;
-    s_tau[j] = tau_arr ? a.tau[(size_t)m * ny + j] : 0.;
+    s_tau[j] = first ? tau_f : (tau_arr ? a.tau[(size_t)m * ny + j] : 0.);
     nanv |= (v != v);
     if (v < mn) {
       mn = v;
@@ -850,13 +869,11 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
   const bool ambiguous = __ballot(nonmono) != 0ull;
 
   // ---- per level: outcrop latitude ys (psi_SO.py:106-140)
-  double z[P], b[P], ys[P];
+  double ys[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int i = lane * P + p;
     const int ic = i < nz ? i : nz - 1;
-    z[p] = a.z[ic];
-    b[p] = a.b[base + ic];
     double yv;
     if (a.ys_in != nullptr) {  // the caller's own inversion of a callable bs(y)
       yv = a.ys_in[base + ic];
@@ -892,7 +909,6 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
   }
 
   // ---- calc_Ekman (psi_SO.py:218-243)
-  const double tau_s = tau_arr ? 0. : a.tau[m];
   double tmean_scalar = 0.;
   if (!tau_arr) {
     // np.mean of 100 copies of tau (pairwise: 8 accumulators x 12 rounds, tree, 4 tail)
@@ -956,7 +972,6 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
   }
 
   // ---- calc_GM (psi_SO.py:277-331)
-  const double KGM = a.KGM[m];
   double dy[P], temp[P], bott[P], topt[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -984,19 +999,26 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
     // --- F2010 boundary-value smoother (psi_SO.py:308-323)
     double *s_T = s_w, *s_N2 = s_w + nz;
     const double c2 = a.c * a.c;
+    // the levels above and below come from the neighbouring slots / lanes (the same values the
+    // arrays hold; level nz-1 never looks up, level 0 never down)
+    const double b_nl = from_next_lane_z(b[0]), z_nl = from_next_lane_z(z[0]);
+    const double b_pl = from_prev_lane_z(b[P - 1]), z_pl = from_prev_lane_z(z[P - 1]);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = lane * P + p;
+      const double b_up = p + 1 < P ? b[p + 1 < P ? p + 1 : p] : b_nl;
+      const double z_up = p + 1 < P ? z[p + 1 < P ? p + 1 : p] : z_nl;
+      const double b_dn = p > 0 ? b[p > 0 ? p - 1 : 0] : b_pl;
+      const double z_dn = p > 0 ? z[p > 0 ? p - 1 : 0] : z_pl;
       if (i < nz) {
         s_T[i] = KGM * z[p] / dy[p] * a.L * topt[p] * bott[p];  // :310
         double n2;  // calc_N2, :154-160
         if (i == 0)
-          n2 = (a.b[base + 1] - b[p]) / (a.z[1] - z[p]);
+          n2 = (b_up - b[p]) / (z_up - z[p]);
         else if (i == nz - 1)
-          n2 = (b[p] - a.b[base + nz - 2]) / (z[p] - a.z[nz - 2]);
+          n2 = (b[p] - b_dn) / (z[p] - z_dn);
         else
-          n2 = (a.b[base + i + 1] - a.b[base + i - 1]) /
-               ((a.z[i + 1] - z[p]) + (z[p] - a.z[i - 1]));
+          n2 = (b_up - b_dn) / ((z_up - z[p]) + (z[p] - z_dn));
         s_N2[i] = n2;
       }
     }
@@ -1024,11 +1046,15 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
       ms.up = s_y;          // over the staging area: written only after the tables are filled
       double *outl = s_y;   // ... and read for the last time before `out` is written
       const double rc2 = 1. / c2;
-      for (int i = lane; i < nz; i += 64) {
-        ms.x[i] = a.z[i];
-        ms.q[i] = s_N2[i] * rc2;
-        ms.t[i] = s_T[i];
-        ms.mark[i] = (short)i;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {  // (the lane's own entries of s_N2 / s_T)
+        const int i = lane * P + p;
+        if (i < nz) {
+          ms.x[i] = z[p];
+          ms.q[i] = s_N2[i] * rc2;
+          ms.t[i] = s_T[i];
+          ms.mark[i] = (short)i;
+        }
       }
       __builtin_amdgcn_wave_barrier();
       so_gm_adaptive_reg(ms, nz, ua0, ub0, lane, outl, &gm_status PM_TICK_ARG);

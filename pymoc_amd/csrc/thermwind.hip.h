@@ -445,10 +445,15 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
     b2u[p] = a.b2[base + iu];
     Psi[p] = 0.;
   }
+  // (the scalars of the solve are requested with the profiles, not one memory round trip each
+  // where they are used)
+  const bool solving = (ops & PM_TW_SOLVE) != 0;
+  const double f_m = solving ? a.f[m] : 1.;
+  const double z_first = solving ? a.z[0] : 0., z_last = solving ? a.z[nz - 1] : 1.;
 
   PM_TICK(0)
-  if (ops & PM_TW_SOLVE) {
-    const double rf = 1. / a.f[m];  // psi_thermwind.py:123
+  if (solving) {
+    const double rf = 1. / f_m;  // psi_thermwind.py:123
     double g[P], gu[P], h[P], dG[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -490,7 +495,7 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
 #pragma unroll
     for (int p = 0; p < P; ++p)
       if ((nz - 1) % P == p) Iend = lane_value(Il[p], (nz - 1) / P);
-    const double z0 = a.z[0], span = a.z[nz - 1] - z0;
+    const double z0 = z_first, span = z_last - z0;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int i = lane * P + p;
