@@ -56,6 +56,9 @@ int pm_memcpy_d2h(void *dst, const void *src, size_t bytes, pm_stream_t stream);
 int pm_memcpy_d2d(void *dst, const void *src, size_t bytes, pm_stream_t stream);
 
 int pm_stream_create(pm_stream_t *stream);
+/* priority > 0: the device's highest stream priority (its workgroups are dispatched before those
+   of normal streams when both have work pending), 0: as pm_stream_create */
+int pm_stream_create_priority(pm_stream_t *stream, int priority);
 int pm_stream_destroy(pm_stream_t stream);
 int pm_stream_sync(pm_stream_t stream);
 int pm_device_sync(void);

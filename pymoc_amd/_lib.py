@@ -172,6 +172,7 @@ SIGNATURES = {
     "pm_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pm_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pm_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "pm_stream_create_priority": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "pm_stream_destroy": (C.c_int, [C.c_void_p]),
     "pm_stream_sync": (C.c_int, [C.c_void_p]),
     "pm_device_sync": (C.c_int, []),

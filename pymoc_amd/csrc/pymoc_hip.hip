@@ -197,6 +197,15 @@ int pm_stream_create(pm_stream_t *stream) {
   *stream = (pm_stream_t)s;
   return PM_OK;
 }
+int pm_stream_create_priority(pm_stream_t *stream, int priority) {
+  PM_REQUIRE(stream, "stream is NULL");
+  int least = 0, greatest = 0;
+  PM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));  // numerically lower = higher
+  hipStream_t s;
+  PM_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority > 0 ? greatest : 0));
+  *stream = (pm_stream_t)s;
+  return PM_OK;
+}
 int pm_stream_destroy(pm_stream_t stream) {
   if (stream) PM_HIP(hipStreamDestroy((hipStream_t)stream));
   return PM_OK;

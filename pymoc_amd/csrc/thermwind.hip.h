@@ -711,12 +711,22 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   }
   // ---- Psibz (psi_thermwind.py:203-208) and the drivers' wA coupling
   const double rstep = 1.0 / lin.step;  // (only a starting guess is taken from it)
+  // P >= 3: the two profiles are read again here instead of living in 4 P registers through
+  // the class passes (where the kernel sits at its register cap and spills per pass)
+  double b1e[P], b2e[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int i = lane * P + p;
+    const int ic = i < nz ? i : nz - 1;
+    b1e[p] = P >= 3 ? a.b1[base + ic] : b1[p];
+    b2e[p] = P >= 3 ? a.b2[base + ic] : b2[p];
+  }
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int i = lane * P + p;
     if (i < nz && m_ok) {
-      const double p1 = interp_uniform(b1[p], lin, s_psib, nb, rstep);
-      const double p2 = interp_uniform(b2[p], lin, s_psib, nb, rstep);
+      const double p1 = interp_uniform(b1e[p], lin, s_psib, nb, rstep);
+      const double p2 = interp_uniform(b2e[p], lin, s_psib, nb, rstep);
       if (a.psibz1) a.psibz1[base + i] = p1;
       if (a.psibz2) a.psibz2[base + i] = p2;
       if (a.wA1) {  // (Psi_iso_b - SO.Psi) * 1e6   (example_twocol_plusSO.py:105)

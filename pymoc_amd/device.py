@@ -8,10 +8,15 @@ from ._lib import check, lib
 
 
 class Stream(object):
-  def __init__(self):
+  def __init__(self, high_priority=False):
+    """`high_priority`: the device dispatches this stream's workgroups before those of normal
+    streams when both have work pending (hipStreamCreateWithPriority)."""
     _lib.require_device()
     h = C.c_void_p()
-    check(lib.pm_stream_create(C.byref(h)))
+    if high_priority:
+      check(lib.pm_stream_create_priority(C.byref(h), 1))
+    else:
+      check(lib.pm_stream_create(C.byref(h)))
     self.handle = h
 
   def sync(self):

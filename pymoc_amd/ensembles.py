@@ -203,7 +203,9 @@ class TwoColEnsemble(object):
     self._overlap = self.so is not None and bool(overlap_updates)
     if self._overlap:
       from .device import Stream, Event
-      self._side, self._ev_fork, self._ev_join = Stream(), Event(), Event()
+      import os
+      self._side = Stream(high_priority=os.environ.get("PYMOC_SIDE_PRIORITY", "0") == "1")
+      self._ev_fork, self._ev_join = Event(), Event()
     can_fuse = (self.so is None and arith == "exact" and self.cols.uniform_area and
                 not np.any(self.cols._flags_host & _lib.PM_COL_BZBOT) and
                 _run_fits(0, nz, self.nb, 0))
