@@ -19,7 +19,9 @@ gpu.synchronize()
 _lib.lib.pm_debug_prof(out)
 v = np.array(list(out), dtype=np.float64)
 names = ["pass head", "elements+chunk", "prefix scan", "affine scan", "thomas+store", "residual",
-         "mesh", None, "before the BVP", "BVP tail", "epilogue"]
+         "mesh", None, "before the BVP", "BVP tail", "epilogue",
+         # (only in builds that place PM_TICK(11..13) in so_member: staging, ys, Ekman; slot 8 is then calc_GM's head)
+         "staging+argmin", "outcrop latitude", "Ekman"]
 tot = sum(c for n, c in zip(names, v) if n)
 print("passes per member-update: %.2f" % (v[7] / v[15] + 1))
 for n, c in zip(names, v):

@@ -869,6 +869,28 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
   const bool ambiguous = __ballot(nonmono) != 0ull;
 
   // ---- per level: outcrop latitude ys (psi_SO.py:106-140)
+  // The interval search of the unambiguous case, for all of the lane's levels at once: the
+  // same probes as a per-level `while (j < hi)` loop, but the levels' LDS round trips overlap
+  // (a uniform trip count; a level that has converged repeats nothing).  Lanes on the other
+  // branches search as well and ignore the result (indices stay inside [minind, ny-2]).
+  int sj[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) sj[p] = minind;
+  if (a.ys_in == nullptr && !ambiguous && !bs_nan) {  // wave-uniform
+    int sh[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) sh[p] = ny - 2;
+    for (int span = ny - 2 - minind; span > 0; span >>= 1) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int mid = (sj[p] + sh[p]) >> 1;
+        const bool open = sj[p] < sh[p];
+        const bool ge = s_bs[mid + 1] >= b[p];
+        sh[p] = (open && ge) ? mid : sh[p];
+        sj[p] = (open && !ge) ? mid + 1 : sj[p];
+      }
+    }
+  }
   double ys[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -888,14 +910,7 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
     } else {
       // first crossing north of argmin: bs is non-decreasing there (not `ambiguous`), so the
       // first j with bs[j+1] >= b is a lower bound -- 6 probes instead of a walk over y
-      int j = minind, hi = ny - 2;
-      while (j < hi) {
-        const int mid = (j + hi) >> 1;
-        if (s_bs[mid + 1] >= b[p])
-          hi = mid;
-        else
-          j = mid + 1;
-      }
+      const int j = sj[p];
       const double f0 = s_bs[j], f1 = s_bs[j + 1];
       if (f0 == b[p])
         yv = s_y[j];
