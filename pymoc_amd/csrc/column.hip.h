@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void col_stage_load(ColStage<P> &s, const pm_columns 
 // base.  (load_levels takes that decision per call; inside the ring the compiler turned it
 // into both address forms, selects, and two 8-byte loads.)
 template <int P, int D, bool AFF = false, bool LEAN = false, bool VEC = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VEC ? 4 : 1)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LEAN && P <= 2 && D <= 5) ? 4 : 1)))
 void k_column_stream(pm_columns c,
                                                        const double *__restrict__ wA_g,
                                                        double dt, int nsteps, int cpw, bool dt_ok,

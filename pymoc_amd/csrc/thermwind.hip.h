@@ -711,15 +711,16 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   }
   // ---- Psibz (psi_thermwind.py:203-208) and the drivers' wA coupling
   const double rstep = 1.0 / lin.step;  // (only a starting guess is taken from it)
-  // P >= 3: the two profiles are read again here instead of living in 4 P registers through
-  // the class passes (where the kernel sits at its register cap and spills per pass)
+  // 3-4 levels per lane (129 <= nz <= 256): the two profiles are read again here instead of
+  // living in 4 P registers through the class passes (where the kernel sits at its register cap
+  // and spills per pass); taller grids run at 1-2 waves per SIMD anyway and gain nothing
   double b1e[P], b2e[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int i = lane * P + p;
     const int ic = i < nz ? i : nz - 1;
-    b1e[p] = P >= 3 ? a.b1[base + ic] : b1[p];
-    b2e[p] = P >= 3 ? a.b2[base + ic] : b2[p];
+    b1e[p] = (P >= 3 && BIG <= 1) ? a.b1[base + ic] : b1[p];
+    b2e[p] = (P >= 3 && BIG <= 1) ? a.b2[base + ic] : b2[p];
   }
 #pragma unroll
   for (int p = 0; p < P; ++p) {
