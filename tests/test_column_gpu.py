@@ -318,6 +318,44 @@ def test_operands_outside_the_fast_division_window_streaming_kernel(gpu):
       assert np.array_equal(got[m], ref, equal_nan=True), m
 
 
+@pytest.mark.parametrize("nz", [100, 81, 40, 128, 150])
+def test_lean_streaming_forms_bitwise_with_operands_outside_the_window(gpu, nz):
+  """The lean streaming form (forcing precombined, kappa formed from its two factors, Area one
+  number per column: 24 nz B per column-step) in every shape the launcher picks -- 16-byte
+  accesses (nz even, two levels per lane), per-level accesses (nz odd), one and three levels per
+  lane -- on a ragged batch in which some columns carry operands outside the exact-division
+  window (scaled by 2^-1000 / 2^+900, inf / NaN levels, subnormal forcing): those step in the IEEE
+  form.  Bit-identical to the oracle, and the non-finite flags are the results'."""
+  N = 33003
+  c = configs.config2(N=N, nz=nz)
+  sel = np.arange(5, N, 499)
+  sub = {k: (v[sel] if isinstance(v, np.ndarray) and v.shape[:1] == (N,) else v) for k, v in c.items()}
+  b0s, wAs, bss, bbots, kinds = _extreme_cases(sub, sel.size)
+  b0, wA, bs = c["b0"].copy(), c["wA"].copy(), c["bs"].copy()
+  bbot = np.array(c["bbot"], dtype=float) + np.zeros(N)
+  b0[sel], wA[sel], bs[sel], bbot[sel] = b0s, wAs, bss, bbots
+  aff = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], b0, bs=bs, bbot=bbot, N2min=c["N2min"],
+                        do_conv=c["do_conv"], kappa_affine=(c["kappa_back"], c["kappa_profile"]))
+  assert aff.kappa_base is not None
+  assert aff.kernel_name(1).startswith("k_column_stream")
+  with np.errstate(all="ignore"):
+    w = aff.combine_forcing(gpu.DeviceArray.from_host(wA))
+    weff_host = w.download()
+    for _ in range(3):
+      aff.steps(w, c["dt"], 1, precombined=True)
+    got = aff.get_b()
+    for m in list(sel[:24]) + [0, 1, 2, N - 1]:
+      ref = b0[m].copy()
+      for _ in range(3):
+        ref = O.column_timestep(c["z"], c["kappa"][m], c["Area"][m], ref, wA[m], c["dt"],
+                                do_conv=bool(c["do_conv"][m]), bs=bs[m], bbot=bbot[m],
+                                N2min=c["N2min"][m])
+      assert np.array_equal(got[m], ref, equal_nan=True), (nz, int(m))
+  assert np.isfinite(weff_host[0]).all()
+  nf = aff.get_nonfinite()
+  assert np.array_equal(nf != 0, ~np.isfinite(got).all(axis=1))
+
+
 @pytest.mark.parametrize("nsteps", [1, 2, 25])
 def test_precombined_forcing_and_uniform_area_bitwise(gpu, nsteps):
   """PM_OP_WEFF (the caller hands weff = wA - d(A kappa)/dz, computed once per overturning
