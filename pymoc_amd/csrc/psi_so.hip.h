@@ -22,7 +22,7 @@
 //    interval, each lane condenses its R sub-intervals to one 2x2 element (static
 //    condensation), and the remaining nz-point system is solved without a serial sweep: the
 //    node elimination `so_merge` is associative, so a prefix and a suffix scan of the
-//    elements (in-lane merges + 6 shuffle steps each) give every node its closing row.
+//    elements (in-lane merges + 6 DPP scan steps each) give every node its closing row.
 #pragma once
 #include "common.hip.h"
 
@@ -1157,7 +1157,7 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
     // a prefix scan gives L_k (the element of [z_0, z_k+1]) and a suffix scan R_k (the element
     // of [z_k, z_nz-1]); interior node i then closes with its own row
     //   L_{i-1}.a21 ua + (L_{i-1}.a22 + R_i.a11) u_i + R_i.a12 ub = L_{i-1}.c2 + R_i.c1.
-    // Each scan is P-1 merges inside a lane, 6 shuffle steps across the wave and P merges to
+    // Each scan is P-1 merges inside a lane, 6 DPP scan steps across the wave and P merges to
     // fold the carried element in -- no serial sweep over the rows.
     const int ne = nz - 1;                       // number of elements
     const int nv = ne - lane * P;                // valid elements of this lane (may be <= 0)
