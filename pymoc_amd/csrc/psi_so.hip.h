@@ -832,7 +832,7 @@ __device__ __forceinline__ void so_member(const pm_psi_so &a, int ops, int m_raw
   const double bs_f = a.bs[(size_t)m * ny + jf], y_f = a.y[jf];
   const double tau_f = tau_arr ? a.tau[(size_t)m * ny + jf] : 0.;
   const double tau_s = tau_arr ? 0. : a.tau[m];
-  const double KGM = a.KGM[m];
+  const double KGM = a.KGM[m];  // (non-NULL for every op: checked at the C-ABI)
 
   // ---- stage the member's surface profiles; min / argmin of bs (np.min, np.argmin)
   double mn = __builtin_inf();
