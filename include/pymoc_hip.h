@@ -571,6 +571,13 @@ int pm_comm_barrier(pm_comm_t comm, pm_stream_t stream);
 int pm_selftest_fastdiv(uint64_t seed, int32_t blocks, int32_t per_thread, int32_t emax,
                         uint64_t *tested, uint64_t *mismatches);
 
+/* debug/test: the wave scans of the GM boundary-value solve (DPP row steps + row joins: element
+ * prefix / suffix scans, the affine suffix scan, the node-count prefix sum) against the same
+ * compositions done serially, for `nhas` (1..64) occupied lanes: max_rel3 = largest relative
+ * deviations {prefix, suffix, affine} (association differs: ~1e-14), sum_mismatches = lanes whose
+ * integer prefix sum differs (must be 0). */
+int pm_selftest_so_scans(int32_t nhas, uint64_t seed, double *max_rel3, int32_t *sum_mismatches);
+
 /* debug/test: lane-shift primitive self check (DPP wave shifts vs ds_bpermute) */
 int pm_selftest_lane_shift(int32_t *mismatches);
 

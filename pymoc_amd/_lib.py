@@ -221,6 +221,8 @@ SIGNATURES = {
     "pm_selftest_fastdiv": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "pm_selftest_lane_shift": (C.c_int, [C.POINTER(C.c_int32)]),
+    "pm_selftest_so_scans": (C.c_int, [C.c_int32, C.c_uint64, C.POINTER(C.c_double),
+                                       C.POINTER(C.c_int32)]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

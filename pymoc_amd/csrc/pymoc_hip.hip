@@ -58,6 +58,71 @@ __global__ void k_selftest_lane_shift(int *mismatch) {
   if (bad) atomicAdd(mismatch, 1);
 }
 
+// ---- wave scans of the GM boundary-value solve (psi_so.hip.h) against serial composition ----
+// One wave per case: `nhas` lanes carry a random diagonally dominant element (the others are
+// empty, as past the end of a mesh).  out[0..2] = largest relative deviation of the DPP prefix
+// scan, suffix scan and affine suffix scan from the same composition done serially, lane by
+// lane, through LDS (the association differs: 1e-13, not bits); out_int += mismatches of the
+// integer prefix sum (exact).
+__global__ void k_selftest_so_scans(int nhas, unsigned long long seed, double *out, int *out_int) {
+  __shared__ SoElem el[64];
+  __shared__ double aff[128];
+  const int lane = threadIdx.x & 63;
+  unsigned long long x = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull * (unsigned long long)(lane + 1);
+  auto rnd = [&]() {  // uniform in [0, 1)
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    return (double)((x * 0x2545F4914F6CDD1Dull) >> 11) * 0x1p-53;
+  };
+  const bool has = lane < nhas;
+  SoElem e;  // shaped like so_sub_element's: a11, a22 ~ -2/h, a12, a21 ~ +2/h, dominant diagonal
+  const double h = 0.01 + rnd(), q = rnd();
+  e.a11 = -(2. / h + q * h / 3.);
+  e.a12 = 2. / h - q * h / 6.;
+  e.a21 = 2. / h - q * h / 6.;
+  e.a22 = -(2. / h + q * h / 3.);
+  e.c1 = rnd() - 0.5;
+  e.c2 = rnd() - 0.5;
+  el[lane] = e;
+  const double A = rnd() - 0.5, B = (lane == nhas - 1 || !has) ? 0. : 0.9 * (rnd() - 0.5);
+  aff[2 * lane] = has ? A : 7.;
+  aff[2 * lane + 1] = has ? B : 0.;
+  __syncthreads();
+  const SoElem PL = so_prefix_scan(e, has, lane);
+  const SoElem PR = so_suffix_scan(e, nhas, lane);
+  const double U = so_affine_suffix_scan(has ? A : 7., has ? B : 0., lane);
+  const int cnt = 1 + (int)(rnd() * 3.);
+  const int incl = so_prefix_sum(cnt);
+  double dev[3] = {0., 0., 0.};
+  int ibad = 0;
+  if (has) {
+    SoElem L = el[0];
+    for (int i = 1; i <= lane; ++i) L = so_merge(L, el[i]);
+    SoElem R = el[nhas - 1];
+    for (int i = nhas - 2; i >= lane; --i) R = so_merge(el[i], R);
+    double u = aff[2 * (nhas - 1)];
+    for (int i = nhas - 2; i >= lane; --i) u = aff[2 * i] + aff[2 * i + 1] * u;
+    auto rel = [](double a, double b) { return __builtin_fabs(a - b) / (1e-300 + __builtin_fabs(b)); };
+    dev[0] = fmax(fmax(fmax(rel(PL.a11, L.a11), rel(PL.a12, L.a12)), fmax(rel(PL.a21, L.a21), rel(PL.a22, L.a22))),
+                  fmax(rel(PL.c1, L.c1), rel(PL.c2, L.c2)));
+    dev[1] = fmax(fmax(fmax(rel(PR.a11, R.a11), rel(PR.a12, R.a12)), fmax(rel(PR.a21, R.a21), rel(PR.a22, R.a22))),
+                  fmax(rel(PR.c1, R.c1), rel(PR.c2, R.c2)));
+    dev[2] = rel(U, u);
+  }
+  {
+    __shared__ int cs[64];
+    cs[lane] = cnt;
+    __syncthreads();
+    int ref = 0;
+    for (int i = 0; i <= lane; ++i) ref += cs[i];
+    ibad = ref != incl;
+  }
+  for (int k = 0; k < 3; ++k) {
+    const double m = group_max<64>(dev[k]);
+    if (lane == 0) out[k] = m;
+  }
+  if (ibad) atomicAdd(out_int, 1);
+}
+
 // ---- fast exact division self test -----------------------------------------------
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long &x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -676,6 +741,27 @@ int pm_selftest_fastdiv(uint64_t seed, int32_t blocks, int32_t per_thread, int32
   PM_HIP(hipFree(d));
   *mismatches = h;
   *tested = 4ull * (unsigned long long)per_thread * 256ull * (unsigned long long)blocks;
+  return PM_OK;
+}
+
+int pm_selftest_so_scans(int32_t nhas, uint64_t seed, double *max_rel3, int32_t *sum_mismatches) {
+  PM_REQUIRE(max_rel3 && sum_mismatches, "NULL output");
+  PM_REQUIRE(nhas >= 1 && nhas <= 64, "nhas must be in [1,64]");
+  double *d = nullptr;
+  PM_HIP(hipMalloc((void **)&d, 4 * sizeof(double)));
+  hipStream_t st = resolve_stream(nullptr);
+  PM_HIP(hipMemsetAsync(d, 0, 4 * sizeof(double), st));
+  hipLaunchKernelGGL(k_selftest_so_scans, dim3(1), dim3(64), 0, st, (int)nhas,
+                     (unsigned long long)seed, d, reinterpret_cast<int *>(d + 3));
+  PM_HIP(hipGetLastError());
+  double h[4];
+  PM_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st));
+  PM_HIP(hipStreamSynchronize(st));
+  PM_HIP(hipFree(d));
+  for (int k = 0; k < 3; ++k) max_rel3[k] = h[k];
+  int32_t bad;
+  memcpy(&bad, &h[3], sizeof(bad));
+  *sum_mismatches = bad;
   return PM_OK;
 }
 

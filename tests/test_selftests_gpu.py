@@ -15,3 +15,18 @@ def test_division_by_precomputed_reciprocal_is_correctly_rounded(gpu, emax):
   check(lib.pm_selftest_fastdiv(20240 + emax, 2048, 2000, emax, C.byref(tested), C.byref(bad)))
   assert tested.value == 4 * 2000 * 256 * 2048
   assert bad.value == 0, "%d of %d quotients differ" % (bad.value, tested.value)
+
+
+@pytest.mark.parametrize("nhas", [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64])
+def test_dpp_wave_scans_match_serial_composition(gpu, nhas):
+  """The GM boundary-value solve's wave scans (psi_so.hip.h: rows of 16 by DPP row shifts, the
+  rows joined by row_bcast / v_readlane) for every way the occupied lanes can end inside or at
+  the edge of a row: the element prefix and suffix scans and the affine suffix scan against the
+  same compositions done serially (the association differs, so 1e-12 rather than bits), the
+  integer prefix sum exactly."""
+  from pymoc_amd._lib import lib, check
+  for seed in range(5):
+    dev, bad = (C.c_double * 3)(), C.c_int32(0)
+    check(lib.pm_selftest_so_scans(nhas, 1000 + seed, dev, C.byref(bad)))
+    assert bad.value == 0
+    assert max(dev) < 1e-12, (nhas, seed, list(dev))
