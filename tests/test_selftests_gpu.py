@@ -30,3 +30,20 @@ def test_dpp_wave_scans_match_serial_composition(gpu, nhas):
     check(lib.pm_selftest_so_scans(nhas, 1000 + seed, dev, C.byref(bad)))
     assert bad.value == 0
     assert max(dev) < 1e-12, (nhas, seed, list(dev))
+
+
+def test_high_priority_stream_runs_the_same_work(gpu):
+  """pm_stream_create_priority: a batch stepped on a stream of the device's highest priority gives
+  the bits it gives on an ordinary stream (the entry point only changes dispatch order)."""
+  import numpy as np
+  from pymoc_amd import configs
+  from pymoc_amd.device import Stream
+  c = configs.config2(N=96)
+  out = []
+  for st in (Stream(), Stream(high_priority=True)):
+    b = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"], bs=c["bs"], bbot=c["bbot"],
+                        N2min=c["N2min"], do_conv=c["do_conv"], stream=st)
+    b.steps(gpu.DeviceArray.from_host(c["wA"], stream=st), c["dt"], 50)
+    st.sync()
+    out.append(b.get_b())
+  assert np.array_equal(out[0], out[1])
