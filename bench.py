@@ -233,14 +233,21 @@ def bench_config2(args, env):
                                 bs=cfg["bs"], bbot=cfg["bbot"], N2min=cfg["N2min"],
                                 do_conv=cfg["do_conv"], stream=stream)
   wA = DeviceArray.from_host(cfg["wA"], stream=stream)
+  # diagnostic output of the job: the final buoyancy of every member gathered into one buffer.
+  # EVERY N pays it inside the timed region the same way -- pack on the compute stream, the
+  # exchange on the communication stream (N = 1 without a communicator: the pack alone) -- and
+  # every rank's clock stops when ITS device has finished (all launches done, gather landed);
+  # the closing barrier comes after, so that its own latency is not read as scaling loss.
   use_gather = world > 1 or args.force_rccl
-  gathered = DeviceArray((world, C, nz)) if use_gather else None
+  diag = env["make_gather"](comm if use_gather else None, C, world * C, [("b", nz)], stream,
+                            getattr(args, "gather", "all"),
+                            not getattr(args, "gather_inline", False))
   dt = cfg["dt"]
 
   run_steps(batch, wA, dt, W * F, F, args.lanes)
-  if use_gather:  # RCCL sets its channels up at the first call of each collective: not timed
-    comm.allgather_device(batch.b, gathered, stream)
-    comm.max_host(0.0)
+  diag.gather(dict(b=batch.b))  # RCCL sets its channels up at the first call: not timed
+  diag.wait()
+  comm.max_host(0.0)
   stream.sync()
 
   ev0, ev1 = Event(), Event()
@@ -250,12 +257,15 @@ def bench_config2(args, env):
   ev0.record(stream)
   launches = run_steps(batch, wA, dt, K * F, F, args.lanes)
   ev1.record(stream)
-  if use_gather:  # diagnostic output: RCCL all-gather of the final buoyancy
-    comm.allgather_device(batch.b, gathered, stream)
+  diag.gather(dict(b=batch.b))
   stream.sync()
+  diag.wait()
+  t_local = time.perf_counter() - t0
   comm.barrier(stream)
   pymoc_amd.synchronize()
-  elapsed = comm.max_host(time.perf_counter() - t0)
+  t_closed = time.perf_counter() - t0
+  elapsed = comm.max_host(t_local)
+  elapsed_closed = comm.max_host(t_closed)
   kernel_ms = ev0.elapsed_ms(ev1)
   nonfinite = int(batch.get_nonfinite().sum())
   b_final = batch.get_b()
@@ -294,13 +304,17 @@ def bench_config2(args, env):
       "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
       "config": {"workload": WORKLOAD_SHORT[2] % (C, nz), "columns_per_gpu": C, "nz": nz,
                  "model_steps_per_step": F, "kernel": kname,
-                 "parallelism": "ensemble sharded over %d GPU(s), RCCL all-gather of the final "
-                                "state" % world},
+                 "parallelism": "ensemble sharded over %d GPU(s), RCCL gather (%s) of the final "
+                                "state" % (world, getattr(args, "gather", "all"))},
       "roofline": {"bound": "fp64-valu", "achieved": sig(tf), "peak": FP64_PEAK_TFLOPS,
                    "unit": "TFLOP/s", "frac": sig(tf / FP64_PEAK_TFLOPS, 4),
                    "traffic": cnt.get("hbm_bytes_per_launch"), "kernel_us": sig(launch_s * 1e6),
                    "issue_frac": cnt.get("issue_frac"), "counters": prof_round,
                    "alg_bytes": alg_bytes, "alg_hbm_GBps": sig(alg_bytes / launch_s / 1e9)},
+      "timing": {"on_stream_ms_per_step": sig(kernel_ms / K), "ms_per_step_incl_closing_barrier":
+                 sig(elapsed_closed * 1e3 / K), "gather": getattr(args, "gather", "all"),
+                 "gather_overlap": not getattr(args, "gather_inline", False),
+                 "collectives": getattr(diag, "ncollectives", 0)},
       "nonfinite": nonfinite, "checksum": float(np.sum(b_final)),
       "contracted": {"value": sig(C * F / (tol_ms * 1e-3)), "kernel_us": sig(tol_ms * 1e3),
                      "frac": sig(flop / (tol_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
@@ -371,6 +385,7 @@ def make_ensemble(config, env, members, comm=None, n_total=None, **kw):
   kw = dict(kw, stream=stream)
   if comm is not None:
     kw.update(comm=comm, n_total=n_total)
+    kw.update(env.get("gather_kw", {}))
   if config == 3:
     cfg = configs.config3(N=n_total, members=sl)
     ens = pymoc_amd.TwoColEnsemble(cfg, diag_iters=240, arith=env.get("arith", "exact"), **kw)
@@ -439,8 +454,13 @@ def kernel_breakdown(config, env, members, nsteps, warm_blocks, **kw):
   return kern, roof
 
 
-def bench_coupled(config, args, env, members, nsteps=None, warm_blocks=None, sharded=False, **kw):
-  """Time a coupled config.  nsteps=None: K MOC intervals (headline mode)."""
+def bench_coupled(config, args, env, members, nsteps=None, warm_blocks=None, sharded=False,
+                  record=None, **kw):
+  """Time a coupled config.  nsteps=None: K MOC intervals (headline mode).
+  `record` (config 5): attach the diagnostics recorder -- the seven time series of
+  run_JansenNadeau_2018.py:192-226 sampled every Diag_iters steps for `record` members ("all" or
+  a count, gathered on the device) -- and end the timed region when the series are in host
+  memory."""
   pymoc_amd = env["pymoc_amd"]
   stream, comm, rank, world = env["stream"], env["comm"], env["rank"], env["world"]
   use_comm = comm if sharded else None
@@ -449,9 +469,15 @@ def bench_coupled(config, args, env, members, nsteps=None, warm_blocks=None, sha
   M = ens.M
   steps = nsteps if nsteps is not None else args.steps * M
   warm = (warm_blocks if warm_blocks is not None else args.warmup) * M
+  if record is not None:
+    from pymoc_amd.diagnostics import JN2018Diagnostics
+    sel = None if record == "all" else np.linspace(0, members - 1, int(record)).astype(int)
+    ens.recorder = JN2018Diagnostics(ens, ens.diag_iters, warm + steps + ens.diag_iters,
+                                     members=sel, flush_every=1)
   ens.run(warm)
   if use_comm is not None:
     ens.gather_diagnostics()  # RCCL channel set-up of this collective: not timed
+    ens.diag.wait()
     comm.max_host(0.0)
   stream.sync()
   comm.barrier(stream)
@@ -463,9 +489,14 @@ def bench_coupled(config, args, env, members, nsteps=None, warm_blocks=None, sha
   if use_comm is not None:
     ens.gather_diagnostics()  # the final output gather
   stream.sync()
+  if use_comm is not None:
+    ens.diag.wait()           # ... landed (it runs on the communication stream)
+  if record is not None:
+    ens.recorder.ts.wait()    # the time series are in (page-locked) host memory
+  t_local = time.perf_counter() - t0
   comm.barrier(stream)
   pymoc_amd.synchronize()
-  el = comm.max_host(time.perf_counter() - t0)
+  el = comm.max_host(t_local)
   bad = ens.nonfinite_members()
   tot = world * members if sharded else members
   res = {"members_per_gpu": members, "nz": int(ens.nz), "model_steps": steps, "M": M,
@@ -499,9 +530,10 @@ def headline_coupled(config, args, env):
       "data": "synthetic",
       "config": {"workload": WORKLOAD_SHORT[config] % (members, nz), "members_per_gpu": members,
                  "nz": nz, "model_steps_per_step": M,
-                 "parallelism": "ensemble sharded over %d GPU(s); RCCL all-gather of "
+                 "parallelism": "ensemble sharded over %d GPU(s); RCCL gather (%s, %s) of "
                                 "{b_basin,b_north,Psi_AMOC,Psi_SO} every %s model steps and at "
-                                "the end" % (world, diag_iters)},
+                                "the end" % (world, args.gather, "in line" if args.gather_inline
+                                             else "on a communication stream", diag_iters)},
       "roofline": roof,
   }
   out.update(res)
@@ -534,6 +566,12 @@ def coupled_block(c, args, env, cpu):
       del e2
     except ValueError:
       blk["fused_run"] = None  # the phases' LDS does not fit at this shape
+  if c == 5:  # the diagnostics recorder on: device-resident time series, asynchronous copies
+    blk["recorder"] = {}
+    for name, rec in (("sel64", 64), ("all", "all")):
+      rr, e2 = bench_coupled(5, args, env, n, nsteps=steps, warm_blocks=10, record=rec)
+      blk["recorder"][name] = rr["steps_per_s"]
+      del e2
   if c in cpu:
     ncol = SIZES[c]["ncol"]
     blk["cpu1"] = sig(cpu[c]["value"] / ncol)
@@ -561,6 +599,11 @@ def main():
                   help="config 2 at N=1: skip the configs 3-5 entries")
   ap.add_argument("--cpu-workers", type=int, default=0, help="cap of the all-core baseline")
   ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget per baseline leg")
+  ap.add_argument("--gather", choices=("all", "root"), default="root",
+                  help="diagnostic exchange: ncclAllGather, or point-to-point gather to rank 0 "
+                       "(the writer; what the reference's output cadence needs)")
+  ap.add_argument("--gather-inline", action="store_true",
+                  help="run the exchange on the compute stream (round 4's behaviour; A/B)")
   ap.add_argument("--force-rccl", action="store_true",
                   help="use the RCCL communicator even with one rank (plumbing check)")
   args = ap.parse_args()
@@ -599,7 +642,10 @@ def main():
   comm = (sharding.RcclCommunicator(stream=stream) if (args.force_rccl and world == 1)
           else sharding.make_communicator(stream=stream))
   env = dict(pymoc_amd=pymoc_amd, configs=configs, DeviceArray=DeviceArray, Event=Event,
-             stream=stream, comm=comm, rank=rank, world=world)
+             stream=stream, comm=comm, rank=rank, world=world,
+             gather_kw=dict(gather=args.gather, gather_overlap=not args.gather_inline),
+             make_gather=lambda cm, n, ntot, fields, st, mode, overlap: sharding.DiagnosticGather(
+                 cm, n, ntot, fields, stream=st, mode=mode, overlap=overlap))
 
   if args.config == 2:
     out = bench_config2(args, env)

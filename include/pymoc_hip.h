@@ -54,6 +54,32 @@ int pm_memset(void *dptr, int value, size_t bytes, pm_stream_t stream);
 int pm_memcpy_h2d(void *dst, const void *src, size_t bytes, pm_stream_t stream);
 int pm_memcpy_d2h(void *dst, const void *src, size_t bytes, pm_stream_t stream);
 int pm_memcpy_d2d(void *dst, const void *src, size_t bytes, pm_stream_t stream);
+/* Page-locked host memory and a device-to-host copy that does NOT synchronise: the copy is
+ * ordered on `stream`, the caller reads `dst` after pm_stream_sync / pm_event_sync.  `dst` must
+ * come from pm_host_alloc and stay alive until then (the one exception to "no host pointer is
+ * retained": the caller owns the buffer and the sync point).  Used by the diagnostic time
+ * series, which the reference fills every Diag_iters steps
+ * (examples/run_JansenNadeau_2018.py:192-198, 218-226) and reads after the loop (:268-272).   */
+int pm_host_alloc(void **hptr, size_t bytes);
+int pm_host_free(void *hptr);
+int pm_memcpy_d2h_async(void *dst_pinned, const void *src, size_t bytes, pm_stream_t stream);
+
+/* Row gather on the device: for every item k < nitems (<= PM_PACK_MAX_ITEMS) and row r < nrows
+ *   items[k].dst[r][0:nlev] = items[k].src[ sel ? sel[r] : r ][0:nlev]
+ * (src rows `src_stride` doubles apart, dst rows dense), ONE launch.  `sel` is a device array
+ * of int32 row numbers or NULL.  This is how a diagnostic sample -- the reference's
+ * `AMOC_save[:, k] = AMOC.Psi`, ... of run_JansenNadeau_2018.py:219-225 -- is appended to the
+ * device-resident time series (selected members only), and how the per-rank send buffer of the
+ * diagnostic exchange is packed.                                                             */
+#define PM_PACK_MAX_ITEMS 8
+typedef struct pm_row_copy {
+  const double *src;   /* [.][src_stride] */
+  double *dst;         /* [nrows][nlev]   */
+  int32_t nlev;
+  int32_t src_stride;
+} pm_row_copy;
+int pm_rows_pack(const pm_row_copy *items, int32_t nitems, const int32_t *sel, int32_t nrows,
+                 pm_stream_t stream);
 
 int pm_stream_create(pm_stream_t *stream);
 /* priority > 0: the device's highest stream priority (its workgroups are dispatched before those
@@ -558,6 +584,13 @@ int pm_comm_destroy(pm_comm_t comm);
 /* recv[nranks][count] <- send[count] of every rank (fp64, device pointers) */
 int pm_comm_allgather(pm_comm_t comm, const void *send, void *recv, size_t count,
                       pm_stream_t stream);
+/* gather to ONE rank: recv[nranks][count] on `root` <- send[count] of every rank (point-to-point
+ * ncclSend / ncclRecv in one group; the root's own block is a device copy).  `recv` is only
+ * read on the root and may be NULL elsewhere.  The diagnostic exchange needs no more than this:
+ * one process writes the output (the reference's script is that process).  With nranks = 1 the
+ * root sends to itself through RCCL when `self_loop` != 0 (plumbing rehearsal), else copies.   */
+int pm_comm_gather_root(pm_comm_t comm, const void *send, void *recv, size_t count, int32_t root,
+                        int32_t self_loop, pm_stream_t stream);
 /* elementwise max over ranks (fp64, device pointers; in place allowed) */
 int pm_comm_allreduce_max(pm_comm_t comm, const void *send, void *recv, size_t count,
                           pm_stream_t stream);

@@ -131,6 +131,14 @@ class pm_jn2018(C.Structure):
   ]
 
 
+PM_PACK_MAX_ITEMS = 8
+
+
+class pm_row_copy(C.Structure):
+  """Mirror of `struct pm_row_copy` (include/pymoc_hip.h)."""
+  _fields_ = [("src", c_dp), ("dst", c_dp), ("nlev", C.c_int32), ("src_stride", C.c_int32)]
+
+
 class pm_run_schedule(C.Structure):
   """Mirror of `struct pm_run_schedule` (include/pymoc_hip.h)."""
   _fields_ = [("n_first", C.c_int32), ("n_updates", C.c_int32), ("m_steps", C.c_int32),
@@ -171,6 +179,10 @@ SIGNATURES = {
     "pm_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pm_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pm_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pm_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "pm_host_free": (C.c_int, [C.c_void_p]),
+    "pm_memcpy_d2h_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pm_rows_pack": (C.c_int, [C.c_void_p, C.c_int32, c_dp, C.c_int32, C.c_void_p]),
     "pm_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "pm_stream_create_priority": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "pm_stream_destroy": (C.c_int, [C.c_void_p]),
@@ -216,6 +228,8 @@ SIGNATURES = {
     "pm_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "pm_comm_destroy": (C.c_int, [C.c_void_p]),
     "pm_comm_allgather": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_size_t, C.c_void_p]),
+    "pm_comm_gather_root": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_size_t, C.c_int32, C.c_int32,
+                                      C.c_void_p]),
     "pm_comm_allreduce_max": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_size_t, C.c_void_p]),
     "pm_comm_barrier": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pm_selftest_fastdiv": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32,

@@ -16,6 +16,10 @@ struct NcclApi {
   int (*CommDestroy)(nccl_comm);
   int (*AllGather)(const void *, void *, size_t, int, nccl_comm, hipStream_t);
   int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm, hipStream_t);
+  int (*Send)(const void *, size_t, int, int, nccl_comm, hipStream_t);
+  int (*Recv)(void *, size_t, int, int, nccl_comm, hipStream_t);
+  int (*GroupStart)(void);
+  int (*GroupEnd)(void);
   const char *(*GetErrorString)(int);
   bool ok = false;
 };
@@ -35,9 +39,14 @@ inline NcclApi &nccl() {
   api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
   api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
   api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
+  api.Send = (decltype(api.Send))dlsym(h, "ncclSend");
+  api.Recv = (decltype(api.Recv))dlsym(h, "ncclRecv");
+  api.GroupStart = (decltype(api.GroupStart))dlsym(h, "ncclGroupStart");
+  api.GroupEnd = (decltype(api.GroupEnd))dlsym(h, "ncclGroupEnd");
   api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
   api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather &&
-           api.AllReduce && api.GetErrorString;
+           api.AllReduce && api.GetErrorString && api.Send && api.Recv && api.GroupStart &&
+           api.GroupEnd;
   return api;
 }
 

@@ -255,6 +255,65 @@ int pm_memcpy_d2d(void *dst, const void *src, size_t bytes, pm_stream_t stream) 
   return PM_OK;
 }
 
+int pm_host_alloc(void **hptr, size_t bytes) {
+  PM_REQUIRE(hptr, "hptr is NULL");
+  *hptr = nullptr;
+  if (bytes == 0) return PM_OK;
+  PM_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+  return PM_OK;
+}
+int pm_host_free(void *hptr) {
+  if (hptr) PM_HIP(hipHostFree(hptr));
+  return PM_OK;
+}
+int pm_memcpy_d2h_async(void *dst_pinned, const void *src, size_t bytes, pm_stream_t stream) {
+  if (!bytes) return PM_OK;
+  PM_REQUIRE(dst_pinned && src, "NULL pointer");
+  PM_HIP(hipMemcpyAsync(dst_pinned, src, bytes, hipMemcpyDeviceToHost, resolve_stream(stream)));
+  return PM_OK;
+}
+
+namespace pm {
+struct PackItems {
+  pm_row_copy it[PM_PACK_MAX_ITEMS];
+};
+// one wave per row (rows are 0.4 - 4 KB: whole rows move as coalesced runs), blockIdx.y = item
+static __global__ void __launch_bounds__(256) k_rows_pack(PackItems p, const int32_t *__restrict__ sel,
+                                                   int nrows) {
+  const pm_row_copy c = p.it[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+  const int nwaves = (int)gridDim.x * 4;
+  for (int r = wave; r < nrows; r += nwaves) {
+    const size_t sr = sel ? (size_t)sel[r] : (size_t)r;
+    const double *__restrict__ s = c.src + sr * (size_t)c.src_stride;
+    double *__restrict__ d = c.dst + (size_t)r * (size_t)c.nlev;
+    for (int l = lane; l < c.nlev; l += 64) d[l] = s[l];
+  }
+}
+}  // namespace pm
+int pm_rows_pack(const pm_row_copy *items, int32_t nitems, const int32_t *sel, int32_t nrows,
+                 pm_stream_t stream) {
+  PM_REQUIRE(nitems >= 0 && nitems <= PM_PACK_MAX_ITEMS, "nitems %d outside [0, %d]", nitems,
+             PM_PACK_MAX_ITEMS);
+  PM_REQUIRE(nrows >= 0, "nrows %d < 0", nrows);
+  if (nitems == 0 || nrows == 0) return PM_OK;
+  PM_REQUIRE(items, "items is NULL");
+  pm::PackItems p;
+  memset(&p, 0, sizeof(p));
+  for (int k = 0; k < nitems; ++k) {
+    PM_REQUIRE(items[k].src && items[k].dst, "item %d: NULL pointer", k);
+    PM_REQUIRE(items[k].nlev >= 1 && items[k].src_stride >= items[k].nlev,
+               "item %d: nlev %d, src_stride %d", k, items[k].nlev, items[k].src_stride);
+    p.it[k] = items[k];
+  }
+  const unsigned gx = (unsigned)((nrows + 3) / 4 < 4096 ? (nrows + 3) / 4 : 4096);
+  hipLaunchKernelGGL(pm::k_rows_pack, dim3(gx, (unsigned)nitems), dim3(256), 0,
+                     resolve_stream(stream), p, sel, nrows);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
 int pm_stream_create(pm_stream_t *stream) {
   PM_REQUIRE(stream, "stream is NULL");
   hipStream_t s;
@@ -300,7 +359,7 @@ int pm_event_record(pm_event_t event, pm_stream_t stream) {
   return PM_OK;
 }
 namespace pm {
-__global__ void k_twocol_forcing(size_t half, const double *__restrict__ psi_iso,
+static __global__ void k_twocol_forcing(size_t half, const double *__restrict__ psi_iso,
                                  const double *__restrict__ psi_so, double *__restrict__ wA) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= 2 * half) return;
@@ -441,7 +500,7 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
   }
 }
 
-__global__ void k_column_weff(pm_columns c, const double *__restrict__ wA,
+static __global__ void k_column_weff(pm_columns c, const double *__restrict__ wA,
                               double *__restrict__ weff) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   const size_t n = (size_t)c.ncols * c.nz;
@@ -702,6 +761,35 @@ int pm_comm_allgather(pm_comm_t comm, const void *send, void *recv, size_t count
   PM_REQUIRE(comm && send && recv, "NULL argument");
   Comm *c = (Comm *)comm;
   PM_NCCL(nccl().AllGather(send, recv, count, NCCL_FLOAT64, c->comm, resolve_stream(stream)));
+  return PM_OK;
+}
+
+int pm_comm_gather_root(pm_comm_t comm, const void *send, void *recv, size_t count, int32_t root,
+                        int32_t self_loop, pm_stream_t stream) {
+  PM_REQUIRE(comm && send, "NULL argument");
+  Comm *c = (Comm *)comm;
+  PM_REQUIRE(root >= 0 && root < c->nranks, "root %d outside [0, %d)", root, c->nranks);
+  PM_REQUIRE(c->rank != root || recv, "recv is NULL on the root");
+  hipStream_t st = resolve_stream(stream);
+  if (count == 0) return PM_OK;
+  const bool loop = self_loop && c->nranks == 1;
+  if (c->rank == root && !loop)  // the root's own block never leaves the device
+    PM_HIP(hipMemcpyAsync((double *)recv + (size_t)root * count, send, count * sizeof(double),
+                          hipMemcpyDeviceToDevice, st));
+  if (c->nranks == 1 && !loop) return PM_OK;
+  PM_NCCL(nccl().GroupStart());
+  int r = 0;
+  if (c->rank == root) {
+    for (int p = 0; p < c->nranks && r == 0; ++p)
+      if (p != root || loop)
+        r = nccl().Recv((double *)recv + (size_t)p * count, count, NCCL_FLOAT64, p, c->comm, st);
+    if (loop && r == 0) r = nccl().Send(send, count, NCCL_FLOAT64, root, c->comm, st);
+  } else {
+    r = nccl().Send(send, count, NCCL_FLOAT64, root, c->comm, st);
+  }
+  const int re = nccl().GroupEnd();
+  if (r != 0) return fail(PM_ENCCL, "ncclSend/ncclRecv failed: %s", nccl().GetErrorString(r));
+  if (re != 0) return fail(PM_ENCCL, "ncclGroupEnd failed: %s", nccl().GetErrorString(re));
   return PM_OK;
 }
 

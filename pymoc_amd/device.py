@@ -234,5 +234,62 @@ class DeviceArray(object):
       pass
 
 
+class PinnedArray(object):
+  """A page-locked host array (hipHostMalloc) as the target of asynchronous device-to-host
+  copies: `dev.download_async(pinned, stream)` returns at once, `pinned.array` is valid after
+  the stream (or an event recorded behind the copy) has been synchronised."""
+
+  def __init__(self, shape, dtype=np.float64):
+    _lib.require_device()
+    self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+    self.dtype = np.dtype(dtype)
+    self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+    p = C.c_void_p()
+    check(lib.pm_host_alloc(C.byref(p), self.nbytes))
+    self.ptr = p.value or 0
+    if self.nbytes:
+      buf = (C.c_char * self.nbytes).from_address(self.ptr)
+      self.array = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape)
+    else:
+      self.array = np.empty(self.shape, self.dtype)
+
+  def free(self):
+    if getattr(self, "ptr", 0):
+      self.array = None
+      lib.pm_host_free(self.ptr)
+      self.ptr = 0
+
+  def __del__(self):
+    try:
+      self.free()
+    except Exception:
+      pass
+
+
+def download_async(src_ptr, nbytes, pinned, stream=None, offset=0):
+  """`nbytes` from device address `src_ptr` into `pinned` at byte `offset`, ordered on `stream`,
+  no host synchronisation."""
+  if offset + nbytes > pinned.nbytes:
+    raise ValueError("pinned buffer too small")
+  check(lib.pm_memcpy_d2h_async(pinned.ptr + offset, src_ptr, nbytes, _sh(stream)))
+
+
+def rows_pack(items, nrows, sel=None, stream=None):
+  """One launch of pm_rows_pack: items = [(src address, dst address, nlev, src_stride)], rows
+  `sel` (a device int32 array / address, or None = rows 0..nrows-1)."""
+  from ._lib import pm_row_copy, PM_PACK_MAX_ITEMS
+  for i0 in range(0, len(items), PM_PACK_MAX_ITEMS):
+    chunk = items[i0:i0 + PM_PACK_MAX_ITEMS]
+    arr = (pm_row_copy * len(chunk))()
+    for k, (src, dst, nlev, stride) in enumerate(chunk):
+      arr[k].src, arr[k].dst, arr[k].nlev, arr[k].src_stride = src, dst, int(nlev), int(stride)
+    selp = None if sel is None else (sel if isinstance(sel, int) else sel.ptr)
+    check(lib.pm_rows_pack(arr, len(chunk), selp, int(nrows), _sh(stream)))
+
+
+def _addr(x):
+  return x if isinstance(x, int) else x.ptr
+
+
 def synchronize():
   check(lib.pm_device_sync())

@@ -147,7 +147,7 @@ class TwoColEnsemble(object):
 
   def __init__(self, cfg, stream=None, lanes_per_col=0, comm=None, n_total=None,
                diag_iters=None, keep_history=False, arith="exact", overlap_updates=True,
-               fused_run=None):
+               fused_run=None, gather="all", gather_overlap=True):
     """`fused_run`: carry the members through whole stretches of the loop -- many [refresh the
     overturning, MOC_up_iters steps] intervals -- in ONE launch of the persistent per-member
     kernel (pm_twocol_run), ending a launch only where the diagnostics are gathered.  Same device
@@ -159,7 +159,9 @@ class TwoColEnsemble(object):
     `comm` (a pymoc_amd.sharding communicator) makes this rank's members one shard of an
     `n_total`-member ensemble: stepping is unchanged (members never interact) and
     {b_basin, b_north, Psi, Psi_SO} are all-gathered on device buffers every `diag_iters`
-    steps (default cfg['Diag_iters']) and by `gather_diagnostics()` at the end of a run.
+    steps (default cfg['Diag_iters']) and by `gather_diagnostics()` at the end of a run;
+    `gather="root"` sends them to rank 0 only, `gather_overlap` runs the exchange on a
+    communication stream of its own beside the stepping (sharding.DiagnosticGather).
     `arith="contracted"`: the columns step in the opt-in tolerance mode (ColumnBatch.steps)."""
     z = cfg['z']
     nz = z.size
@@ -175,7 +177,8 @@ class TwoColEnsemble(object):
     if comm is not None or keep_history:
       self.diag = DiagnosticGather(comm, n, n if n_total is None else n_total,
                                    [(k, nz) for k in ('b_basin', 'b_north', 'Psi', 'Psi_SO')],
-                                   stream=stream, keep_history=keep_history)
+                                   stream=stream, keep_history=keep_history, mode=gather,
+                                   overlap=gather_overlap)
     kap = _rows(cfg['kappa'], n, nz)
     # rows [0, n): basin columns, rows [n, 2n): northern columns
     self.cols = ColumnBatch(
@@ -366,13 +369,13 @@ class JN2018Ensemble(object):
 
   def __init__(self, cfg, stream=None, lanes_per_col=0, use_graph=False, fused=None,
                comm=None, n_total=None, diag_iters=None, keep_history=False, arith="exact",
-               shared_coef=True, fused_run=None):
+               shared_coef=True, fused_run=None, gather="all", gather_overlap=True):
     """`fused_run`: whole stretches of the loop -- many [PsiSO.solve, AMOC.solve / Psibz,
     MOC_up_iters steps] intervals -- in ONE launch of the persistent per-member kernel
     (pm_jn2018_run), ending a launch only where diagnostics are sampled or gathered;
     bit-identical to the launch sequence; needs the fused step loop's conditions and the phases'
     LDS within 160 KB.  None = off (measured slower than the launch sequence: DESIGN.md section 6).
-    `comm`, `n_total`, `diag_iters`: as for TwoColEnsemble; the gather happens where the
+    `comm`, `n_total`, `diag_iters`, `gather`, `gather_overlap`: as for TwoColEnsemble; the gather happens where the
     script samples its diagnostics (`if ii % Diag_iters == 0`, right after the MOC update,
     run_JansenNadeau_2018.py:218-226; default Diag_iters = 10 MOC_up_iters, :99).
     `arith="contracted"`: the columns of the fused loop step in the opt-in tolerance mode
@@ -444,7 +447,8 @@ class JN2018Ensemble(object):
     if comm is not None or keep_history:
       self.diag = DiagnosticGather(comm, n, n if n_total is None else n_total,
                                    [(k, nz) for k in ('b_basin', 'b_north', 'Psi', 'Psi_SO')],
-                                   stream=stream, keep_history=keep_history)
+                                   stream=stream, keep_history=keep_history, mode=gather,
+                                   overlap=gather_overlap)
 
   def gather_diagnostics(self, step=None):
     self.diag.gather(dict(b_basin=self.cols.b.ptr, b_north=self.cols.b.ptr + self._off,

@@ -179,6 +179,16 @@ class RcclCommunicator(object):
     self._lib.check(self._lib.lib.pm_comm_allgather(self.handle, send.ptr, recv.ptr, count,
                                                     self._sh(stream)))
 
+  def gather_root_device(self, send, recv, root=0, stream=None):
+    """recv[world][count] on `root` <- send[count] of every rank (ncclSend / ncclRecv); `recv`
+    may be None on the other ranks."""
+    count = int(np.prod(send.shape))
+    if self.rank == root and (recv is None or recv.nbytes != send.nbytes * self.world):
+      raise ValueError("recv on the root must hold world x send")
+    self._lib.check(self._lib.lib.pm_comm_gather_root(
+        self.handle, send.ptr, recv.ptr if recv is not None else None, count, int(root),
+        1 if self.always_collective else 0, self._sh(stream)))
+
   def allgather_host(self, arr):
     from .device import DeviceArray
     arr = np.ascontiguousarray(arr, dtype=np.float64)
@@ -214,25 +224,50 @@ def gather_members(comm, local, n_members):
 
 
 class DiagnosticGather(object):
-  """The one exchange step of the path: all-gather of per-member diagnostic fields at the
+  """The one exchange step of the path: the gather of per-member diagnostic fields at the
   drivers' output cadence (`if ii % Diag_iters == 0`, run_JansenNadeau_2018.py:218-226) and
   at the end of a run.
 
-  Every rank packs its fields into ONE send buffer laid out [field][pad][nlev] (pad = the
-  largest shard, so ragged shards gather with equal counts) with device-to-device copies and
-  issues ONE collective into recv[world][field][pad][nlev] -- fewer, larger messages suit
-  the per-link-bound xGMI mesh; no host staging.  Communicators without `allgather_device`
-  (the gloo test vehicle, which has no device) go through `allgather_host` on NumPy sources
-  with the same layout, which is what the CPU multi-process tests exercise.
+  Every rank packs its fields into a send buffer laid out [field][pad][nlev] (pad = the
+  largest shard, so ragged shards exchange equal counts) with ONE row-gather launch
+  (pm_rows_pack) and issues ONE collective into recv[world][field][pad][nlev] -- fewer, larger
+  messages suit the per-link-bound xGMI mesh; no host staging.
+
+  OFF THE CRITICAL PATH (round 5).  The pack runs on the compute stream (it must see the state
+  of this step); the collective runs on a COMMUNICATION STREAM of its own that waits for the
+  pack's event, so stepping continues while the bytes move.  Two send buffers alternate: the
+  pack of gather k+1 only waits for the collective of gather k-1 (which read the same buffer).
+  `last()`, `history`, `wait()` synchronise with the communication stream.  `overlap=False`
+  puts the collective back on the compute stream (the round-4 behaviour, kept for A/B runs).
+
+  mode "all":  ncclAllGather -- every rank ends up with every member (the default; what a
+               user who continues on all ranks with the gathered fields needs);
+  mode "root": point-to-point gather to rank `root` (pm_comm_gather_root) -- what the
+               reference's cadence needs (one process writes the output): each rank SENDS its
+               block once instead of receiving world-1 blocks; `last()` / `history` hold data on
+               the root only (None elsewhere).
+
+  `keep_history`: every gather is also copied to page-locked host memory by an asynchronous
+  device-to-host copy on the communication stream (no host synchronisation inside the loop).
+
+  Communicators without `allgather_device` (the gloo test vehicle, which has no device) go
+  through `allgather_host` on NumPy sources with the same layout, synchronously, which is what
+  the CPU multi-process tests exercise.
 
   fields: sequence of (name, nlev)."""
 
-  def __init__(self, comm, n_local, n_total, fields, stream=None, keep_history=False):
+  def __init__(self, comm, n_local, n_total, fields, stream=None, keep_history=False,
+               mode="all", root=0, overlap=True):
+    if mode not in ("all", "root"):
+      raise ValueError("mode must be 'all' or 'root'")
     self.comm = comm if comm is not None else SingleCommunicator()
     self.fields = [(str(k), int(v)) for k, v in fields]
     self.n_local, self.n_total = int(n_local), int(n_total)
     self.stream = stream
+    self.mode, self.root, self.overlap = mode, int(root), bool(overlap)
     world, rank = self.comm.world, self.comm.rank
+    if not (0 <= self.root < world):
+      raise ValueError("root %d outside world of %d" % (self.root, world))
     self.counts = [hi - lo for lo, hi in (member_range(self.n_total, world, r)
                                           for r in range(world))]
     if self.counts[rank] != self.n_local:
@@ -245,39 +280,90 @@ class DiagnosticGather(object):
       off += self.pad * nlev
     self.count = off  # doubles per rank
     self.keep_history = keep_history
-    self.history = []  # [(step, {field: [n_total, nlev]})] when keep_history
+    self._history = []   # finished records: (step, {field: [n_total, nlev]} | None)
+    self._pending = []   # records still in flight: (step, PinnedArray)
     self.ngathers = 0
-    self.ncollectives = 0  # device collectives issued (RCCL all-gathers)
+    self.ncollectives = 0  # device collectives issued (RCCL all-gathers / gathers to root)
     self._send = self._recv = None
-    self._host = None  # last gathered [world][count] in host mode
+    self._slot = 0
+    self._last_dev = None  # device array holding the most recent gather
+    self._host = None      # last gathered [world][count] in host mode
+    self._host_valid = False
+    self._comm_stream = None
+
+  # ------------------------------------------------------------------- helpers
+  @property
+  def receives(self):
+    """Does this rank end up with the gathered data?"""
+    return self.mode == "all" or self.comm.rank == self.root
 
   def _collective_always(self):
     return bool(getattr(self.comm, "always_collective", False))
+
+  def _collective(self):
+    return self.comm.world > 1 or self._collective_always()
 
   def due(self, step, diag_iters):
     return diag_iters is not None and diag_iters > 0 and step % int(diag_iters) == 0
 
   # ---------------------------------------------------------------- device path
-  def _device_buffers(self):
-    from .device import DeviceArray
-    if self._send is None:
-      self._send = DeviceArray.zeros((self.count,), stream=self.stream)
-      self._recv = (self._send if (self.comm.world == 1 and not self._collective_always()) else
-                    DeviceArray((self.comm.world, self.count)))
-    return self._send, self._recv
+  def _device_setup(self):
+    from .device import DeviceArray, Event, Stream
+    if self._send is not None:
+      return
+    self._send = [DeviceArray.zeros((self.count,), stream=self.stream) for _ in range(2)]
+    if self._collective() and self.receives:
+      self._recv = DeviceArray((self.comm.world, self.count))
+    self._comm_stream = Stream() if self.overlap else self.stream
+    self._ev_packed = Event()
+    self._ev_sent = [Event(), Event()]
 
-  def _gather_device(self, sources):
+  @staticmethod
+  def _wait(stream, event):
     from ._lib import check, lib
-    from .device import _sh
-    send, recv = self._device_buffers()
-    for name, nlev in self.fields:
-      src = sources[name]
-      ptr = src if isinstance(src, int) else src.ptr
-      check(lib.pm_memcpy_d2d(send.ptr + 8 * self.offsets[name], ptr,
-                              8 * self.n_local * nlev, _sh(self.stream)))
-    if self.comm.world > 1 or self._collective_always():
-      self.comm.allgather_device(send, recv, self.stream)
+    check(lib.pm_stream_wait_event(stream.handle if stream is not None else None, event.handle))
+
+  def _gather_device(self, sources, step):
+    from .device import PinnedArray, download_async, rows_pack, _addr
+    self._device_setup()
+    slot = self._slot
+    self._slot ^= 1
+    send, cs = self._send[slot], self._comm_stream
+    if cs is not self.stream:
+      # the collective (or host copy) that last read this send buffer, two gathers ago
+      self._wait(self.stream, self._ev_sent[slot])
+    rows_pack([(_addr(sources[name]), send.ptr + 8 * self.offsets[name], nlev, nlev)
+               for name, nlev in self.fields], self.n_local, stream=self.stream)
+    if cs is not self.stream:
+      self._ev_packed.record(self.stream)
+      self._wait(cs, self._ev_packed)
+    out = send
+    if self._collective():
+      if self.mode == "all":
+        self.comm.allgather_device(send, self._recv, cs)
+      else:
+        self.comm.gather_root_device(send, self._recv, self.root, cs)
       self.ncollectives += 1
+      out = self._recv
+    self._last_dev = out if self.receives else None
+    if self.keep_history:
+      if self.receives:
+        pin = PinnedArray((out.nbytes // 8,))
+        download_async(out.ptr, out.nbytes, pin, cs)
+        self._pending.append((step, pin))
+      else:
+        self._pending.append((step, None))
+    if cs is not self.stream:
+      self._ev_sent[slot].record(cs)
+
+  def wait(self):
+    """Block until every gather issued so far has landed (end of a run; the bench's timed
+    region ends behind it)."""
+    if self._comm_stream is not None:
+      self._comm_stream.sync()
+    elif self._send is not None:
+      from ._lib import check, lib
+      check(lib.pm_stream_sync(None))
 
   # ------------------------------------------------------------------ host path
   def _to_host(self, src, nlev):
@@ -289,13 +375,17 @@ class DiagnosticGather(object):
     check(lib.pm_memcpy_d2h(out.ctypes.data, ptr, out.nbytes, _sh(self.stream)))
     return out
 
-  def _gather_host(self, sources):
+  def _gather_host(self, sources, step):
     buf = np.zeros(self.count)
     for name, nlev in self.fields:
       a = np.ascontiguousarray(sources[name], dtype=np.float64).reshape(self.n_local, nlev)
       o = self.offsets[name]
       buf[o:o + self.n_local * nlev] = a.ravel()
-    self._host = np.asarray(self.comm.allgather_host(buf)).reshape(self.comm.world, self.count)
+    g = np.asarray(self.comm.allgather_host(buf)).reshape(self.comm.world, self.count)
+    self._host = g if self.receives else None
+    self._host_valid = True
+    if self.keep_history:
+      self._history.append((step, self._assemble(g) if self.receives else None))
 
   def gather(self, sources, step=None):
     """sources: {field: DeviceArray | device address (int) | ndarray [n_local, nlev]}."""
@@ -303,28 +393,51 @@ class DiagnosticGather(object):
     if host or (self.comm.world > 1 and not hasattr(self.comm, "allgather_device")):
       if not host:  # device state but a host-only communicator: stage through the host
         sources = {k: self._to_host(sources[k], nlev) for k, nlev in self.fields}
-      self._gather_host(sources)
+      self._gather_host(sources, step)
     else:
-      self._host = None
-      self._gather_device(sources)
+      self._host, self._host_valid = None, False
+      self._gather_device(sources, step)
     self.ngathers += 1
-    if self.keep_history:
-      self.history.append((step, self.last()))
 
-  def last(self):
-    """{field: [n_total, nlev]} of the most recent gather, shard padding removed."""
-    if self._host is not None:
-      g = self._host
-    elif self._recv is not None:
-      g = self._recv.download(stream=self.stream).reshape(self.comm.world, self.count)
-    else:
-      raise RuntimeError("nothing gathered yet")
+  # --------------------------------------------------------------------- results
+  def _assemble(self, g):
+    g = np.asarray(g).reshape(-1, self.count)
     out = {}
     for name, nlev in self.fields:
       o = self.offsets[name]
-      blk = g[:, o:o + self.pad * nlev].reshape(self.comm.world, self.pad, nlev)
+      blk = g[:, o:o + self.pad * nlev].reshape(g.shape[0], self.pad, nlev)
       out[name] = assemble(blk, self.counts)
     return out
+
+  def _drain(self):
+    if self._pending:
+      self.wait()
+      for step, pin in self._pending:
+        if pin is None:
+          self._history.append((step, None))
+        else:
+          self._history.append((step, self._assemble(pin.array.copy())))
+          pin.free()
+      self._pending = []
+
+  @property
+  def history(self):
+    """[(step, {field: [n_total, nlev]})] of every gather so far (keep_history); the dict is
+    None on ranks that do not receive (mode 'root')."""
+    self._drain()
+    return self._history
+
+  def last(self):
+    """{field: [n_total, nlev]} of the most recent gather, shard padding removed (None on a
+    rank that does not receive)."""
+    if self._host_valid:
+      return None if self._host is None else self._assemble(self._host)
+    if self._send is None:
+      raise RuntimeError("nothing gathered yet")
+    if self._last_dev is None:
+      return None
+    self.wait()
+    return self._assemble(self._last_dev.download(stream=self._comm_stream))
 
   @property
   def bytes_per_rank(self):

@@ -62,8 +62,9 @@ class ColumnBatch(object):
 
 class Diag(object):
   def __init__(self, comm, n): self.comm, self.ngathers, self.bytes_per_rank, self.n = comm, 0, 8 * n, n
-  def gather(self):
+  def gather(self, sources=None, step=None):
     self.comm.allgather_host(np.zeros(self.n)); self.ngathers += 1
+  def wait(self): pass
 
 class Ensemble(object):
   M, nz, ny, nb, diag_iters = 36, 200, 51, 500, 360
@@ -82,10 +83,11 @@ fake = types.SimpleNamespace(ColumnBatch=ColumnBatch, TwoColEnsemble=Ensemble, J
                              synchronize=lambda: None)
 comm = Comm()
 env = dict(pymoc_amd=fake, configs=configs, DeviceArray=DeviceArray, Event=Event, stream=Stream(),
-           comm=comm, rank=comm.rank, world=comm.world)
+           comm=comm, rank=comm.rank, world=comm.world,
+           make_gather=lambda cm, n, ntot, fields, st, mode, overlap: Diag(cm, n))
 bench.kernel_breakdown = lambda config, env, members, nsteps, warm_blocks: ({}, {"bound": "stub"})
 args = types.SimpleNamespace(members=8, nz=100, steps_per_launch=10, steps=3, warmup=1, lanes=0,
-                             force_rccl=False, no_single_step=True)
+                             force_rccl=False, no_single_step=True, gather="root", gather_inline=False)
 outs = {}
 outs["config2"] = bench.bench_config2(args, env)
 for c in (3, 4, 5):
@@ -126,4 +128,4 @@ def test_bench_rank_logic_world2_collectives_pair_up(tmp_path):
   # rank 0 alone reports; whole-job value counts both ranks' members
   assert all(res[0]["printed"].values()) and not any(res[1]["printed"].values())
   assert all(v == 2 for v in res[0]["n_gpus"].values())
-  assert res[0]["log"].count("allgather") >= 1 + 3 * 2  # config 2's final gather + cadence / final gathers
+  assert res[0]["log"].count("allgather") >= 2 + 3 * 2  # config 2's warm-up + final gather, cadence / final gathers

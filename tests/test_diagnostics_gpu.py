@@ -57,3 +57,53 @@ def test_ensemble_pickup_roundtrip(gpu, tmp_path):
   assert np.array_equal(p["arr_0"], st["b_basin"]) and np.array_equal(p["arr_2"], st["bs_SO"])
   b = gpu.JN2018Ensemble(diagnostics.load_pickup(c, f))
   assert np.array_equal(b.state()["b_north"], st["b_north"])
+
+
+class _BlockingRecorder(object):
+  """Round 4's recorder, kept here as the check: seven synchronous whole-ensemble downloads per
+  sample, members picked on the host."""
+
+  def __init__(self, ens, Diag_iters, members):
+    self.ens, self.Diag_iters, self.members, self.samples = ens, Diag_iters, members, []
+
+  def maybe_record(self, ii):
+    if ii % self.Diag_iters:
+      return
+    e, m = self.ens, self.members
+    b = e.cols.get_b()
+    self.samples.append(dict(
+        AMOC=e.tw.Psi.download()[m], AMOC_b=e.tw.psib.download()[m],
+        bgrid=e.tw.bgrid.download()[m], b_basin=b[:e.n][m], b_north=b[e.n:][m],
+        bs_SO=e.ml.bs.download()[m], Psi_SO=e.so.Psi.download()[m]))
+
+
+@pytest.mark.parametrize("members,flush_every", [(None, 0), ([5, 0, 17, 17], 2)])
+def test_device_time_series_equals_blocking_downloads(gpu, members, flush_every):
+  """The device-resident diagnostic time series (one row-gather launch per sample on the compute
+  stream, asynchronous copies to pinned memory on a side stream) holds exactly what blocking
+  downloads at the same instants return -- all members, and a selection gathered on the device."""
+  c = configs.config5(N=24, nz=81, dt_days=30.)
+  c["rest_mask"] = np.repeat(c["rest_mask"][None], 24, axis=0)
+  Diag, total = 24, 24 * 7 + 5
+  s = gpu.Stream()
+  a, b = gpu.JN2018Ensemble(c, stream=s), gpu.JN2018Ensemble(c, stream=s)
+  a.recorder = diagnostics.JN2018Diagnostics(a, Diag, total, members=members,
+                                             flush_every=flush_every)
+  sel = np.arange(24) if members is None else np.asarray(members)
+  b.recorder = _BlockingRecorder(b, Diag, sel)
+  a.run(total)
+  b.run(total)
+  assert a.recorder.nd == 7 and len(b.recorder.samples) == 8  # (the reference drops sample nd)
+  for k in diagnostics.JN2018Diagnostics._FIELDS:
+    got = getattr(a.recorder, k)
+    assert got.shape[0] == sel.size and got.shape[2] == 7
+    for j in range(7):
+      assert np.array_equal(got[:, :, j], b.recorder.samples[j][k], equal_nan=True), (k, j)
+  # the series can be read mid-run and the run continued (records never written stay zero)
+  a2 = gpu.JN2018Ensemble(c, stream=s)
+  a2.recorder = diagnostics.JN2018Diagnostics(a2, Diag, total, members=members)
+  a2.run(2 * Diag + 1)
+  mid = a2.recorder.b_basin.copy()
+  assert np.array_equal(mid[:, :, :3], a.recorder.b_basin[:, :, :3]) and not mid[:, :, 3:].any()
+  a2.run(total - 2 * Diag - 1)
+  assert np.array_equal(a2.recorder.AMOC_b, a.recorder.AMOC_b, equal_nan=True)

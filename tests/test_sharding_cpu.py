@@ -167,8 +167,13 @@ def test_diagnostic_gather_single_rank_host_path():
   last = g.last()
   assert np.array_equal(last["a"], a) and np.array_equal(last["b"], b)
   assert g.history[0][0] == 0 and g.ngathers == 1 and g.bytes_per_rank == 8 * 25
+  g.wait()  # nothing in flight in host mode: a no-op
   with pytest.raises(ValueError):
     sharding.DiagnosticGather(None, 4, 5, [("a", 3)])
+  with pytest.raises(ValueError):
+    sharding.DiagnosticGather(None, 5, 5, [("a", 3)], mode="ring")
+  with pytest.raises(ValueError):
+    sharding.DiagnosticGather(None, 5, 5, [("a", 3)], mode="root", root=1)
 
 
 DIAG_WORKER = r'''
@@ -183,8 +188,9 @@ comm = GlooCommunicator()
 lo, hi = sharding.member_range(N, comm.world, comm.rank)
 cfg = configs.config3(N=N, members=(lo, hi))
 nz = cfg["z"].size
+mode = os.environ.get("PM_MODE", "all")
 diag = sharding.DiagnosticGather(comm, hi - lo, N, [(k, nz) for k in ("b_basin", "b_north", "Psi", "Psi_SO")],
-                                 keep_history=True)
+                                 keep_history=True, mode=mode)
 # the coupled loop of TwoColEnsemble with the ORACLE as the stepper (no GPU here): gather after
 # the update of every step ii with ii % D == 0, and once more at the end
 snaps = [ii + 1 for ii in range(steps) if ii % D == 0] + [steps]
@@ -193,6 +199,8 @@ for s in snaps:
   st = {k: np.stack([r[s][k] for r in runs]) if runs else np.zeros((0, nz))
         for k in ("b_basin", "b_north", "Psi", "Psi_SO")}
   diag.gather(st, step=s)
+if mode == "root" and comm.rank != 0:  # only the writer rank holds gathered data
+  assert diag.last() is None and all(h[1] is None for h in diag.history) and not diag.receives
 if comm.rank == 0:
   np.savez(os.environ["PM_OUT"], steps=np.array([h[0] for h in diag.history]),
            **{"%s_%d" % (k, i): h[1][k] for i, h in enumerate(diag.history) for k in h[1]})
@@ -200,8 +208,8 @@ comm.close()
 '''
 
 
-@pytest.mark.parametrize("world,N", [(2, 6), (3, 5)])
-def test_gloo_diagnostic_gather_cadence_matches_single_process(tmp_path, world, N):
+@pytest.mark.parametrize("world,N,mode", [(2, 6, "all"), (3, 5, "all"), (3, 5, "root")])
+def test_gloo_diagnostic_gather_cadence_matches_single_process(tmp_path, world, N, mode):
   """The coupled drivers' Diag_iters gather across ranks (ragged shards included) must
   deliver, at every cadence point, exactly the fields of the unsharded ensemble."""
   from oracle import drivers
@@ -212,7 +220,7 @@ def test_gloo_diagnostic_gather_cadence_matches_single_process(tmp_path, world, 
   for r in range(world):
     env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PM_ROOT=ROOT, PM_OUT=out,
-               PM_N=str(N), OMP_NUM_THREADS="1")
+               PM_N=str(N), PM_MODE=mode, OMP_NUM_THREADS="1")
     procs.append(subprocess.Popen([sys.executable, "-c", DIAG_WORKER], env=env))
   for p in procs:
     assert p.wait(timeout=300) == 0

@@ -123,6 +123,38 @@ def test_sharded_coupled_driver_gathers_at_diag_cadence(gpu, tmp_path, cfgno, wo
     assert np.array_equal(ens.diag.history[-1][1][k], st[k], equal_nan=True), k
 
 
+@pytest.mark.parametrize("cfgno", [4, 5])
+def test_exchange_on_its_own_stream_equals_inline_exchange(gpu, cfgno):
+  """Round 5: the diagnostic exchange runs on a communication stream behind an event of the
+  compute stream, with two alternating send buffers, while the stepping goes on.  Every gather
+  of such a run must equal, bit for bit, the gather of a run that packs and exchanges in line
+  on the compute stream (round 4's behaviour) -- a gather every MOC interval here, so that a
+  pack is always queued right behind the steps that follow the previous one."""
+  from pymoc_amd import configs
+  s = gpu.Stream()
+  runs = []
+  for overlap in (True, False):
+    if cfgno == 4:
+      ens = gpu.TwoColEnsemble(dict(configs.config4(N=64), bvp_refine=8), stream=s,
+                               diag_iters=24, keep_history=True, gather_overlap=overlap)
+      ens.run(200)
+    else:
+      ens = gpu.JN2018Ensemble(configs.config5(N=24), stream=s, diag_iters=36,
+                               keep_history=True, gather_overlap=overlap)
+      ens.run(300)
+    ens.gather_diagnostics()
+    runs.append(ens)
+  ha, hb = runs[0].diag.history, runs[1].diag.history
+  assert [x for x, _ in ha] == [x for x, _ in hb] and len(ha) >= 9
+  for (sa, da), (_, db) in zip(ha, hb):
+    for k in da:
+      assert np.array_equal(da[k], db[k], equal_nan=True), (sa, k)
+  st = runs[0].state()
+  for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
+    assert np.array_equal(ha[-1][1][k], st[k], equal_nan=True), k
+    assert np.array_equal(runs[0].diag.last()[k], st[k], equal_nan=True), k
+
+
 def test_explicit_stream_equals_default_stream(gpu):
   """Every fill, upload, launch and download of a driver must be ordered on the stream the
   caller passes: a run on an explicit (non-blocking) Stream is bit-identical to the
@@ -144,7 +176,9 @@ def test_explicit_stream_equals_default_stream(gpu):
 
 @pytest.mark.parametrize("args,nfields", [
     (["--config", "4", "--members", "512", "--steps", "20", "--warmup", "2"], 4),
+    (["--config", "4", "--members", "512", "--steps", "20", "--warmup", "2", "--gather", "all"], 4),
     (["--config", "5", "--members", "256", "--steps", "20", "--warmup", "2"], 4),
+    (["--config", "5", "--members", "256", "--steps", "20", "--warmup", "2", "--gather-inline"], 4),
     (["--config", "2", "--steps", "3", "--warmup", "1", "--no-single-step"], 0),
 ])
 def test_bench_under_torch_distributed_run_with_rccl_one_rank(gpu, args, nfields):

@@ -254,4 +254,44 @@ def test_rccl_communicator_single_rank(gpu):
   assert np.array_equal(recv.download()[0], a)
   assert np.array_equal(sharding.gather_members(comm, a, 6), a)
   assert comm.max_host(3.5) == 3.5
+  # gather to the root through ncclSend / ncclRecv: with one rank the root sends to itself
+  # (always_collective), the only way the point-to-point path can run on a one-GPU box
+  recv2 = DeviceArray((1, 6, 100))
+  comm.gather_root_device(send, recv2, root=0)
+  comm.barrier()
+  assert np.array_equal(recv2.download()[0], a)
+  # ... and the coupled drivers' exchange object on top of it, both modes, on its own stream
+  for mode in ("all", "root"):
+    g = sharding.DiagnosticGather(comm, 6, 6, [("a", 100), ("b", 40)], mode=mode,
+                                  keep_history=True)
+    bsrc = DeviceArray.from_host(np.arange(240.).reshape(6, 40))
+    for k in range(3):  # three gathers back to back: both send buffers get reused
+      send.upload(a + k)
+      g.gather(dict(a=send, b=bsrc), step=k)
+    assert g.ncollectives == 3
+    last = g.last()
+    assert np.array_equal(last["a"], a + 2) and np.array_equal(last["b"], bsrc.download())
+    assert [s for s, _ in g.history] == [0, 1, 2]
+    assert all(np.array_equal(d["a"], a + k) for k, (_, d) in enumerate(g.history))
   comm.close()
+
+
+def test_rows_pack_gathers_selected_rows(gpu):
+  """pm_rows_pack: dst[r] = src[sel[r]] for several fields in one launch (the diagnostic
+  recorder's append and the exchange's send-buffer pack)."""
+  from pymoc_amd.device import DeviceArray, rows_pack
+  rng = np.random.default_rng(5)
+  a, b = rng.standard_normal((37, 100)), rng.standard_normal((37, 51))
+  da, db = DeviceArray.from_host(a), DeviceArray.from_host(b)
+  sel = np.array([36, 0, 5, 5, 17], dtype=np.int32)
+  dsel = DeviceArray.from_host(sel)
+  out = DeviceArray.zeros((5 * 100 + 5 * 51 + 37 * 60,))
+  rows_pack([(da.ptr, out.ptr, 100, 100), (db.ptr, out.ptr + 8 * 500, 51, 51)], 5, sel=dsel)
+  # no selection, a row prefix of a wider array (src_stride > nlev)
+  rows_pack([(da.ptr, out.ptr + 8 * (500 + 255), 60, 100)], 37)
+  h = out.download()
+  assert np.array_equal(h[:500].reshape(5, 100), a[sel])
+  assert np.array_equal(h[500:755].reshape(5, 51), b[sel])
+  assert np.array_equal(h[755:].reshape(37, 60), a[:, :60])
+  with pytest.raises(gpu._lib.PmError):
+    rows_pack([(da.ptr, out.ptr, 100, 50)], 5)  # stride shorter than the row
