@@ -20,7 +20,17 @@ oracle: oracle/libpymoc_oracle.so
 oracle/libpymoc_oracle.so: oracle/pymoc_oracle.c oracle/pymoc_oracle.h
 	gcc -O2 -ffp-contract=off -fPIC -shared -std=c99 -Wall -o $@ oracle/pymoc_oracle.c -lm
 
+# host-side sanitizer target: the oracle built with ASan + UBSan; run the
+# golden tests against it with
+#   make oracle-asan && PYMOC_ORACLE_LIB=oracle/libpymoc_oracle_asan.so \
+#     LD_PRELOAD=$$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 \
+#     python -m pytest tests/test_oracle_golden.py -q
+oracle-asan: oracle/libpymoc_oracle_asan.so
+oracle/libpymoc_oracle_asan.so: oracle/pymoc_oracle.c oracle/pymoc_oracle.h
+	gcc -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined \
+	  -ffp-contract=off -fPIC -shared -std=c99 -Wall -o $@ oracle/pymoc_oracle.c -lm
+
 clean:
 	rm -rf pymoc_amd/libpymoc_hip.so oracle/libpymoc_oracle.so $(CSRC)/build
 
-.PHONY: all lib oracle clean
+.PHONY: all lib oracle oracle-asan clean

@@ -59,6 +59,7 @@ SIZES = {  # per-GPU members and run length of each config (SURVEY.md section 8d
     3: dict(members=4096, nsteps=2400, ncol=2),
     4: dict(members=8192, nsteps=2400, ncol=2),
     5: dict(members=4096, nsteps=3600, ncol=2),
+    6: dict(members=2048, nsteps=2400, ncol=3),  # SURVEY 8f row N1 (two-basin), not a BASELINE config
 }
 
 # ------------------------------------------------------------------------- flop models
@@ -110,8 +111,8 @@ def _cpu_worker(job):
                                   c["N2min"], chunk)
       done += chunk
     return (hi - lo) * done, time.perf_counter() - t0
-  cfg = {3: configs.config3, 4: configs.config4, 5: configs.config5}[config](
-      N=n_total, members=(lo, hi))
+  cfg = {3: configs.config3, 4: configs.config4, 5: configs.config5,
+         6: configs.config_twobasin}[config](N=n_total, members=(lo, hi))
   nsteps = size["nsteps"]
   units, j = 0, 0
   t0 = time.perf_counter()
@@ -121,6 +122,8 @@ def _cpu_worker(job):
       D.run_twocol(m, nsteps, ())
     elif config == 4:
       D.run_twocol(m, nsteps, (), so=True)
+    elif config == 6:
+      D.run_twobasin(m, nsteps, ())
     else:
       D.run_jn2018(m, nsteps, ())
     units += size["ncol"] * nsteps
@@ -151,7 +154,8 @@ def cpu_baseline(config, nz, budget_1=6.0, budget_all=6.0, max_workers=0):
   what = {2: "oracle C port, 250-step launches of the column batch",
           3: "oracle, full 2400-step member runs",
           4: "oracle, full 2400-step member runs (adaptive GM mesh)",
-          5: "oracle, full 3600-step member runs"}[config]
+          5: "oracle, full 3600-step member runs",
+          6: "oracle, full 2400-step member runs"}[config]
   base = {"value": sig(u1 / t1), "unit": unit, "cores": 1, "kind": "port",
           "sample": "%s, members [0,%d), %.1f s" % (what, min(n, 64), t1),
           "all_cores": {"value": sig(rate_all), "cores": workers,
@@ -210,6 +214,8 @@ WORKLOAD_SHORT = {
        "on solve_bvp's adaptive mesh (configs.config4; A_basin >= 4.5e13: G18)",
     5: "BASELINE configs[4]: %d run_JansenNadeau_2018.py members per GPU, nz=%d, dt=10 d, ny=51, "
        "MOC_up_iters=36, nb=500 (configs.config5; db <= 8e-4: G18)",
+    6: "SURVEY 8f row N1: %d twobasin_NadeauJansen.py members per GPU (3 columns, 2 thermal winds, "
+       "2 SO sectors), nz=%d, MOC_up_iters=24, nb=500 (configs.config_twobasin)",
 }
 
 
@@ -336,13 +342,10 @@ def bench_config2(args, env):
                                 stream=stream)
     wAb = DeviceArray.from_host(cb["wA"], stream=stream)
     # the C-ABI default first: no hints, every array streamed (48 nz B per column-step)
-    hints = big._flags_host.copy()
-    big._flags_host = (hints & ~np.int32(pymoc_amd._lib.PM_COL_UNIFORM_AREA)).astype(np.int32)
-    big.flags.upload(big._flags_host, stream)
+    big.use_hints(uniform_area=False)
     msb = time_calls(lambda: big.steps(wAb, dt, 1, lanes_per_col=args.lanes), 20, stream,
                      Event, warm=3)
-    big._flags_host = hints
-    big.flags.upload(hints, stream)
+    big.use_hints()
     # forcing precombined once per overturning update (PM_OP_WEFF) + uniform Area:
     # b, weff, kappa in, b out = 32 nz B per column-step
     weffb = big.combine_forcing(wAb)
@@ -392,6 +395,9 @@ def make_ensemble(config, env, members, comm=None, n_total=None, **kw):
   elif config == 4:
     cfg = dict(configs.config4(N=n_total, members=sl), bvp_refine=env.get("bvp_refine", 0))
     ens = pymoc_amd.TwoColEnsemble(cfg, arith=env.get("arith", "exact"), **kw)
+  elif config == 6:
+    cfg = configs.config_twobasin(N=n_total, members=sl)
+    ens = pymoc_amd.TwoBasinEnsemble(cfg, diag_iters=240, arith=env.get("arith", "exact"), **kw)
   else:
     cfg = configs.config5(N=n_total, members=sl)
     cfg["rest_mask"] = np.repeat(cfg["rest_mask"][None], members, axis=0)
@@ -402,7 +408,9 @@ def make_ensemble(config, env, members, comm=None, n_total=None, **kw):
 KERNEL_MODELS = {
     # per LAUNCH of the kernel: (flop, what one launch is)
     "k_thermwind": lambda n, nz, ny, nb, M: n * flops_thermwind_update(nz, nb),
-    "k_column_steps": lambda n, nz, ny, nb, M: 2 * n * M * flops_column_step(nz),
+    # Psi_SO.solve + thermal wind of a member in one launch: the thermal wind's count
+    "k_so_tw_update": lambda n, nz, ny, nb, M: n * flops_thermwind_update(nz, nb),
+    "k_column_steps": lambda n, nz, ny, nb, M, ncol=2: ncol * n * M * flops_column_step(nz),
     "k_jn2018_steps": lambda n, nz, ny, nb, M: n * M * (2 * flops_column_step(nz) +
                                                         flops_so_ml_step(ny)),
 }
@@ -414,8 +422,9 @@ def kernel_breakdown(config, env, members, nsteps, warm_blocks, **kw):
   ({kernel: [launches, avg us]}, roofline of the kernel with the largest total)."""
   from pymoc_amd.device import LaunchTimer
   # (config 4: Psi_SO.solve and the thermal wind one after the other here -- side by side, as the
-  # driver runs them, each is stretched by the other and neither duration is the kernel's own)
-  if config == 4:
+  # driver runs them, each is stretched by the other and neither duration is the kernel's own;
+  # likewise the two-basin update's two pairs)
+  if config in (4, 6):
     kw = dict(kw, overlap_updates=False)
   cfg, ens = make_ensemble(config, env, members, **kw)
   ens.run(warm_blocks * ens.M)
@@ -439,7 +448,8 @@ def kernel_breakdown(config, env, members, nsteps, warm_blocks, **kw):
         cnt = vv
   issued = cnt["fp64_flop_issued_per_launch"] / (us * 1e-6) / 1e12 if cnt else None
   if dom in KERNEL_MODELS:
-    tf = KERNEL_MODELS[dom](n, nz, ny, nb, M) / (us * 1e-6) / 1e12
+    extra = {"ncol": SIZES[config]["ncol"]} if dom == "k_column_steps" else {}
+    tf = KERNEL_MODELS[dom](n, nz, ny, nb, M, **extra) / (us * 1e-6) / 1e12
   else:
     # the adaptive GM solve has no closed-form count: its figure is the fp64 flop the SQ counted
     # as issued (replayed counters), over this run's average kernel time
@@ -547,7 +557,8 @@ def coupled_block(c, args, env, cpu):
   res, ens = bench_coupled(c, args, env, n, nsteps=steps, warm_blocks=10)
   st = ens.state()
   blk = {"members": n, "steps": steps, "steps_per_s": res["steps_per_s"],
-         "nonfinite": res["nonfinite"], "checksum": float(np.nansum(st["b_basin"]))}
+         "nonfinite": res["nonfinite"],
+         "checksum": float(np.nansum(st["b_Atl" if c == 6 else "b_basin"]))}
   del ens, st
   kern, roof = kernel_breakdown(c, env, n, steps, 10)
   blk.update(dom=roof["kernel"], dom_us=roof["kernel_us"], frac=roof["frac"],
@@ -586,7 +597,7 @@ def main():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=20, help="timed bench steps")
   ap.add_argument("--warmup", type=int, default=5, help="untimed bench steps")
-  ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
+  ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5, 6))
   ap.add_argument("--steps-per-launch", type=int, default=1000,
                   help="config 2: model time steps fused in one launch (= one bench step)")
   ap.add_argument("--members", "--columns", type=int, default=0,
@@ -629,7 +640,7 @@ def main():
   cpu = {}
   want_coupled = args.config == 2 and world == 1 and not args.no_coupled
   if world == 1 and rank == 0 and not args.no_cpu_baseline:
-    for c in ([args.config] + ([3, 4, 5] if want_coupled else [])):
+    for c in ([args.config] + ([3, 4, 5, 6] if want_coupled else [])):
       cpu[c] = cpu_baseline(c, args.nz if c == 2 else 100, args.cpu_seconds, args.cpu_seconds,
                             args.cpu_workers)
 
@@ -651,7 +662,7 @@ def main():
     out = bench_config2(args, env)
     blocks = {}
     if want_coupled and out is not None:
-      for c in (3, 4, 5):
+      for c in (6, 3, 4, 5):  # (c3 / c4 / c5 stay at the very end of the line)
         blocks["c%d" % c] = coupled_block(c, args, env, cpu)
   else:
     out = headline_coupled(args.config, args, env)

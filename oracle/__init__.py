@@ -56,8 +56,13 @@ _lib = None
 def lib():
   global _lib
   if _lib is None:
-    build()
-    _lib = C.CDLL(_SO)
+    # PYMOC_ORACLE_LIB: another build of pymoc_oracle.c, e.g. `make oracle-asan`'s sanitizer build
+    alt = os.environ.get("PYMOC_ORACLE_LIB")
+    if alt:
+      _lib = C.CDLL(os.path.abspath(alt))
+    else:
+      build()
+      _lib = C.CDLL(_SO)
     _lib.orc_np_sum.restype = C.c_double
     _lib.orc_brentq_interp.restype = C.c_double
     _lib.orc_psi_so_ys.restype = C.c_double

@@ -180,7 +180,24 @@ class ColumnBatch(object):
     bit = np.int32(_lib.PM_COL_UNIFORM_AREA)  # every column's Area is one number (set_static)
     self._flags_host = (self._flags_host | bit if self.uniform_area
                         else self._flags_host & ~bit).astype(np.int32)
-    self.flags.upload(self._flags_host, self.stream)
+    off = np.int32(self.__dict__.get("_hints_off", 0))
+    self.flags.upload((self._flags_host & ~off).astype(np.int32), self.stream)
+
+  def use_hints(self, uniform_area=True, static_in_range=True):
+    """Switch the per-column hints the host derives from the static operands on or off
+    (PM_COL_UNIFORM_AREA: a column's Area is one number, read with its scalars;
+    PM_COL_STATIC_IN_RANGE: the static operands lie inside the exact-division window, so a launch
+    tests only the state and the forcing).  Without them the kernels take the C-ABI's default
+    path -- every array read, every operand tested; results are bit-identical either way.  The
+    hints are re-derived whenever the static operands or parameters change."""
+    self._hints_off = ((0 if uniform_area else _lib.PM_COL_UNIFORM_AREA) |
+                       (0 if static_in_range else _lib.PM_COL_STATIC_IN_RANGE))
+    self._upload_flags()
+
+  @property
+  def has_bzbot(self):
+    """Does any column use the bottom-gradient boundary condition (column.py:232-233)?"""
+    return bool(np.any(self._flags_host & _lib.PM_COL_BZBOT))
 
   def set_ksel(self, ksel):
     self.ksel.upload(_per_col(ksel, self.ncols, np.int32), self.stream)

@@ -33,6 +33,7 @@ PER_MEMBER = {
         "b_basin0", "b_north0"),
     5: ("bs", "bs_north", "KGM", "tau", "surflux", "b_rest", "bs_SO_init", "bs_SO0",
         "b_basin0", "b_north0"),
+    6: ("tau", "K", "A_Pac", "A_Atl", "A_north"),  # config_twobasin
 }
 
 

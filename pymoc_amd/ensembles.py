@@ -210,7 +210,7 @@ class TwoColEnsemble(object):
       self._side = Stream(high_priority=os.environ.get("PYMOC_SIDE_PRIORITY", "0") == "1")
       self._ev_fork, self._ev_join = Event(), Event()
     can_fuse = (self.so is None and arith == "exact" and self.cols.uniform_area and
-                not np.any(self.cols._flags_host & _lib.PM_COL_BZBOT) and
+                not self.cols.has_bzbot and
                 _run_fits(0, nz, self.nb, 0))
     if fused_run and not can_fuse:
       raise ValueError("fused_run needs: no SO channel, exact arithmetic, Area constant in z, no "
@@ -613,15 +613,33 @@ class TwoBasinEnsemble(object):
   """twobasin_NadeauJansen.py: Atlantic, northern-sinking and Pacific columns; AMOC
   (Atl vs north) and zonal (Atl vs Pac) thermal-wind overturnings mapped to isopycnal space;
   one Southern-Ocean overturning per basin sector.  Columns are stored Atl rows [0,n),
-  north rows [n,2n), Pac rows [2n,3n)."""
+  north rows [n,2n), Pac rows [2n,3n).
 
-  def __init__(self, cfg, stream=None, lanes_per_col=0):
+  An update (:111-122) is four independent solves of the columns' current profiles:
+  {SO_Atl.solve, AMOC.solve / Psibz} and {SO_Pac.solve, ZOC.solve / Psibz}.  Each pair is ONE
+  launch (pm_so_tw_update: Psi_SO.solve and the thermal wind of a member by one wavefront) and
+  the two pairs run SIDE BY SIDE on two streams (`overlap_updates`), joined by an event before
+  the forcing kernel (:103-105) -- the same device functions as four separate launches,
+  bit-identical results.
+  `comm`, `n_total`, `diag_iters`, `keep_history`, `gather`, `gather_overlap`: as for
+  TwoColEnsemble; the exchanged fields are what the script samples every `plot_iters` steps
+  (:124-133): the three columns' b and the four overturnings.  `arith="contracted"`: the columns
+  step in the opt-in tolerance mode."""
+
+  FIELDS = ("b_Atl", "b_north", "b_Pac", "Psi_AMOC", "Psi_ZOC", "Psi_SO_Atl", "Psi_SO_Pac")
+
+  def __init__(self, cfg, stream=None, lanes_per_col=0, comm=None, n_total=None,
+               diag_iters=None, keep_history=False, arith="exact", overlap_updates=True,
+               gather="all", gather_overlap=True):
+    if arith not in ("exact", "contracted"):
+      raise ValueError("arith must be 'exact' or 'contracted'")
     z, y = cfg['z'], cfg['y']
     nz, ny = z.size, y.size
     n = np.size(cfg['tau']) if np.ndim(cfg['tau']) else 1
-    self.n, self.nz = n, nz
+    self.n, self.nz, self.ny = n, nz, ny
     self.dt, self.M, self.nb = float(cfg['dt']), int(cfg['MOC_up_iters']), int(cfg['nb'])
-    self.lanes, self.stream = lanes_per_col, stream
+    self.lanes, self.stream, self.arith = lanes_per_col, stream, arith
+    self.timer = None  # optional device.LaunchTimer
     kap = _rows(cfg['kappa'], n, nz)
     rows = lambda v: _rows(v, n, nz)  # noqa: E731
     self.cols = ColumnBatch(
@@ -643,20 +661,63 @@ class TwoBasinEnsemble(object):
     self.wA = DeviceArray.zeros((3 * n, nz), stream=stream)
     self._off = n * nz * 8
     self.ii = 0
+    self.diag_iters = (cfg.get('plot_iters', cfg.get('Diag_iters', 10 * self.M))
+                       if diag_iters is None else diag_iters)
+    self.diag = None
+    if comm is not None or keep_history:
+      self.diag = DiagnosticGather(comm, n, n if n_total is None else n_total,
+                                   [(k, nz) for k in self.FIELDS], stream=stream,
+                                   keep_history=keep_history, mode=gather,
+                                   overlap=gather_overlap)
+    self._pairs = nz <= 256   # pm_so_tw_update covers the shape
+    self._overlap = bool(overlap_updates)
+    if self._overlap:
+      from .device import Event, Stream
+      self._side = Stream()
+      self._ev_fork, self._ev_join = Event(), Event()
     # initial diagnostics (:58-79): AMOC against b2 = 0.01*b_Atl, the rest on the initial columns
     b2 = DeviceArray.from_host(rows(cfg['b2_init']), stream=stream)
     self._update(b_north=b2.ptr)
+    if stream is not None:
+      stream.sync()  # b2 is released on return
+    else:
+      _lib.check(_lib.lib.pm_stream_sync(None))
+
+  def _solve_pair(self, so, tw, b_so, b1, b2, stream, names):
+    """{Psi_SO.solve on b_so, thermal wind of (b1, b2)} on `stream`: one launch when the shape
+    allows, else two."""
+    import ctypes as C
+    if self._pairs:
+      ds = so.descriptor(b_so, self.bs_SO)
+      dw = tw.descriptor(b1, b2, store_psib=False)
+      with launch_span(self.timer, "k_so_tw_update", stream):
+        _lib.check(_lib.lib.pm_so_tw_update(C.byref(ds), C.byref(dw), _TW_ALL, _sh(stream)))
+      return
+    keep_so, keep_tw = so.stream, tw.stream
+    so.stream = tw.stream = stream
+    try:
+      with launch_span(self.timer, "k_psi_so", stream):
+        so.update(b_so, self.bs_SO)
+      with launch_span(self.timer, "k_thermwind", stream):
+        tw.update(b1, b2, ops=_TW_ALL, store_psib=False)
+    finally:
+      so.stream, tw.stream = keep_so, keep_tw
 
   def _update(self, b_north=None):
     from ._lib import check, lib
-    from .device import _sh
     bA = self.cols.b.ptr
     bN = self.cols.b.ptr + self._off if b_north is None else b_north
     bP = self.cols.b.ptr + 2 * self._off
-    self.amoc.update(bA, bN, ops=_TW_ALL, store_psib=False)
-    self.zoc.update(bA, bP, ops=_TW_ALL, store_psib=False)
-    self.so_atl.update(bA, self.bs_SO)
-    self.so_pac.update(bP, self.bs_SO)
+    if self._overlap:
+      self._ev_fork.record(self.stream)     # the columns' steps before this update
+      self._side.wait(self._ev_fork)
+      self._solve_pair(self.so_pac, self.zoc, bP, bA, bP, self._side, "pac")
+      self._ev_join.record(self._side)
+      self._solve_pair(self.so_atl, self.amoc, bA, bA, bN, self.stream, "atl")
+      check(lib.pm_stream_wait_event(_sh(self.stream), self._ev_join.handle))
+    else:
+      self._solve_pair(self.so_atl, self.amoc, bA, bA, bN, self.stream, "atl")
+      self._solve_pair(self.so_pac, self.zoc, bP, bA, bP, self.stream, "pac")
     w = self.wA.ptr
     check(lib.pm_twobasin_forcing(self.n, self.nz, self.amoc.psibz1.ptr, self.zoc.psibz1.ptr,
                                   self.so_atl.Psi.ptr, self.amoc.psibz2.ptr,
@@ -668,11 +729,23 @@ class TwoBasinEnsemble(object):
     while remaining > 0:
       nxt = self.ii if self.ii % self.M == 0 else (self.ii // self.M + 1) * self.M
       n = min(nxt - self.ii + 1, remaining)
-      self.cols.steps(self.wA, self.dt, n, lanes_per_col=self.lanes)
+      with launch_span(self.timer, "k_column_steps" if n >= 3 else "k_column_steps_short",
+                       self.stream):
+        self.cols.steps(self.wA, self.dt, n, lanes_per_col=self.lanes, arith=self.arith)
       self.ii += n
       remaining -= n
       if (self.ii - 1) % self.M == 0:
         self._update()
+        if self.diag is not None and self.diag.due(self.ii - 1, self.diag_iters):
+          self.gather_diagnostics(self.ii - 1)
+
+  def gather_diagnostics(self, step=None):
+    """Gather the seven fields the script samples every plot_iters steps (:124-133)."""
+    b = self.cols.b.ptr
+    self.diag.gather(dict(b_Atl=b, b_north=b + self._off, b_Pac=b + 2 * self._off,
+                          Psi_AMOC=self.amoc.Psi, Psi_ZOC=self.zoc.Psi,
+                          Psi_SO_Atl=self.so_atl.Psi, Psi_SO_Pac=self.so_pac.Psi),
+                     step=self.ii if step is None else step)
 
   def state(self):
     b, n = self.cols.get_b(), self.n

@@ -373,8 +373,7 @@ def test_precombined_forcing_and_uniform_area_bitwise(gpu, nsteps):
     return b
   plain, pre = make(), make()
   assert pre.uniform_area and (pre._flags_host & 8).all() and (pre._flags_host & 4).all()
-  plain._flags_host &= ~np.int32(8 | 4)   # no hints: every array is read, every operand tested
-  plain.flags.upload(plain._flags_host)
+  plain.use_hints(uniform_area=False, static_in_range=False)  # every array read, every operand tested
   wA = gpu.DeviceArray.from_host(c["wA"])
   weff = pre.combine_forcing(wA)
   for _ in range(3):

@@ -233,3 +233,70 @@ def test_gloo_diagnostic_gather_cadence_matches_single_process(tmp_path, world, 
     for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
       ref = np.stack([r[s][k] for r in runs])
       assert np.array_equal(got["%s_%d" % (k, i)], ref), (s, k)
+
+
+TWOBASIN_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["PM_ROOT"]); sys.path.insert(0, os.path.join(os.environ["PM_ROOT"], "tests"))
+from oracle import drivers
+from gloo_comm import GlooCommunicator
+from pymoc_amd import configs, sharding
+from pymoc_amd.ensembles import TwoBasinEnsemble
+N, steps, D = int(os.environ["PM_N"]), 50, 24
+comm = GlooCommunicator()
+lo, hi = sharding.member_range(N, comm.world, comm.rank)
+cfg = configs.config_twobasin(N=N, members=(lo, hi))
+nz = cfg["z"].size
+F = TwoBasinEnsemble.FIELDS
+diag = sharding.DiagnosticGather(comm, hi - lo, N, [(k, nz) for k in F], keep_history=True,
+                                 mode=os.environ["PM_MODE"])
+# TwoBasinEnsemble.run's cadence with the ORACLE as the stepper: gather after the update that
+# follows step ii when ii % D == 0, and once more at the end
+snaps = [ii + 1 for ii in range(steps) if ii % D == 0] + [steps]
+keys = ("tau", "K", "A_Pac", "A_Atl", "A_north")
+def member(j):
+  m = dict(cfg)
+  for k in keys:
+    m[k] = cfg[k][j]
+  return m
+runs = [drivers.run_twobasin(member(j), steps, set(snaps)) for j in range(hi - lo)]
+for s in snaps:
+  diag.gather({k: np.stack([r[s][k] for r in runs]) for k in F}, step=s)
+if comm.rank == 0:
+  np.savez(os.environ["PM_OUT"], steps=np.array([h[0] for h in diag.history]),
+           **{"%s_%d" % (k, i): h[1][k] for i, h in enumerate(diag.history) for k in h[1]})
+comm.close()
+'''
+
+
+@pytest.mark.parametrize("mode", ["all", "root"])
+def test_gloo_twobasin_gather_world2(tmp_path, mode):
+  """SURVEY 8f row N1 sharded: the seven fields twobasin_NadeauJansen.py samples (:124-133),
+  gathered at the driver's cadence from two ranks, equal the unsharded members' fields."""
+  from oracle import drivers
+  from pymoc_amd import configs
+  from pymoc_amd.ensembles import TwoBasinEnsemble
+  N, world = 5, 2
+  out = str(tmp_path / "tb.npz")
+  port = _free_port()
+  procs = []
+  for r in range(world):
+    env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PM_ROOT=ROOT, PM_OUT=out,
+               PM_N=str(N), PM_MODE=mode, OMP_NUM_THREADS="1")
+    procs.append(subprocess.Popen([sys.executable, "-c", TWOBASIN_WORKER], env=env))
+  for p in procs:
+    assert p.wait(timeout=300) == 0
+  got = np.load(out)
+  steps = list(got["steps"])
+  assert steps == [1, 25, 49, 50]
+  cfg = configs.config_twobasin(N=N)
+  for j in range(N):
+    m = dict(cfg)
+    for k in ("tau", "K", "A_Pac", "A_Atl", "A_north"):
+      m[k] = cfg[k][j]
+    ref = drivers.run_twobasin(m, 50, set(steps))
+    for i, s in enumerate(steps):
+      for k in TwoBasinEnsemble.FIELDS:
+        assert np.array_equal(got["%s_%d" % (k, i)][j], ref[s][k]), (j, s, k)

@@ -71,6 +71,10 @@ if cfgno == 4:
   cfg = dict(configs.config4(N=N, members=(lo, hi)), bvp_refine=8)
   ens = pymoc_amd.TwoColEnsemble(cfg, comm=comm, n_total=N, diag_iters=48, keep_history=True)
   ens.run(100)
+elif cfgno == 6:
+  cfg = configs.config_twobasin(N=N, members=(lo, hi))
+  ens = pymoc_amd.TwoBasinEnsemble(cfg, comm=comm, n_total=N, diag_iters=48, keep_history=True)
+  ens.run(100)
 else:
   cfg = configs.config5(N=N, members=(lo, hi))
   ens = pymoc_amd.JN2018Ensemble(cfg, comm=comm, n_total=N, diag_iters=72, keep_history=True)
@@ -84,7 +88,7 @@ comm.close()
 '''
 
 
-@pytest.mark.parametrize("cfgno,world,N", [(4, 2, 40), (5, 3, 10)])
+@pytest.mark.parametrize("cfgno,world,N", [(4, 2, 40), (5, 3, 10), (6, 2, 21)])
 def test_sharded_coupled_driver_gathers_at_diag_cadence(gpu, tmp_path, cfgno, world, N):
   """Coupled drivers with a communicator: the Diag_iters gathers of a sharded run (2-3
   processes on the one GPU, gloo carrying the collective) equal, gather for gather and bit
@@ -105,6 +109,10 @@ def test_sharded_coupled_driver_gathers_at_diag_cadence(gpu, tmp_path, cfgno, wo
                              keep_history=True)
     ens.run(100)
     want_steps = [0, 48, 96, 100]
+  elif cfgno == 6:
+    ens = gpu.TwoBasinEnsemble(configs.config_twobasin(N=N), diag_iters=48, keep_history=True)
+    ens.run(100)
+    want_steps = [0, 48, 96, 100]
   else:
     ens = gpu.JN2018Ensemble(configs.config5(N=N), diag_iters=72, keep_history=True)
     ens.run(150)
@@ -113,13 +121,14 @@ def test_sharded_coupled_driver_gathers_at_diag_cadence(gpu, tmp_path, cfgno, wo
   got = np.load(out)
   assert list(got["steps"]) == want_steps
   assert [s for s, _ in ens.diag.history] == want_steps
+  fields = ens.FIELDS if cfgno == 6 else ("b_basin", "b_north", "Psi", "Psi_SO")
   for i, (s, d) in enumerate(ens.diag.history):
-    for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
+    for k in fields:
       # config 5 (N = 10) contains member 2, which the reference itself loses at step 37
       assert np.array_equal(got["%s_%d" % (k, i)], d[k], equal_nan=True), (s, k)
   # the last gather is the state itself
   st = ens.state()
-  for k in ("b_basin", "b_north", "Psi", "Psi_SO"):
+  for k in fields:
     assert np.array_equal(ens.diag.history[-1][1][k], st[k], equal_nan=True), k
 
 

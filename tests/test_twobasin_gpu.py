@@ -38,3 +38,39 @@ def test_twobasin_sweep_members_vs_reference(gpu):
   for k in ("b_Atl", "b_north", "b_Pac", "Psi_AMOC", "Psi_ZOC", "Psi_SO_Atl"):
     assert relerr(st[k][idx], g["sweep_" + k]) <= 1e-10, k
   assert ens.nonfinite_members().size == 0
+
+
+def test_twobasin_update_pairs_side_by_side_equal_four_launches(gpu):
+  """Round 5: an update is two one-launch pairs {Psi_SO.solve, thermal wind} on two streams; the
+  result equals four separate launches in the script's order bit for bit, and so do the gathers
+  of the seven sampled fields at the driver's cadence."""
+  c = configs.config_twobasin(N=96)
+  s = gpu.Stream()
+  a = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48)
+  b = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48, overlap_updates=False)
+  d = gpu.TwoBasinEnsemble(c, keep_history=True, diag_iters=48, overlap_updates=False)
+  d._pairs = False  # four separate launches (what round 4 ran)
+  for e in (a, b, d):
+    e.run(130)
+    e.gather_diagnostics()
+  sa = a.state()
+  for e in (b, d):
+    st = e.state()
+    for k in FIELDS:
+      assert np.array_equal(sa[k], st[k]), k
+    assert [x for x, _ in e.diag.history] == [x for x, _ in a.diag.history] == [0, 48, 96, 130]
+    for (_, ha), (_, hb) in zip(a.diag.history, e.diag.history):
+      for k in FIELDS:
+        assert np.array_equal(ha[k], hb[k]), k
+  for k in FIELDS:
+    assert np.array_equal(a.diag.history[-1][1][k], sa[k]), k
+
+
+def test_twobasin_contracted_columns_within_tolerance(gpu):
+  c = configs.config_twobasin(N=64)
+  a, b = gpu.TwoBasinEnsemble(c), gpu.TwoBasinEnsemble(c, arith="contracted")
+  a.run(600)
+  b.run(600)
+  sa, sb = a.state(), b.state()
+  for k in FIELDS:
+    assert relerr(sb[k], sa[k]) <= 1e-11, k
