@@ -394,6 +394,12 @@ int pm_jn2018_bc_switch(const pm_jn2018_bc *bc, pm_stream_t stream);
                                 per member from HBM.  The CALLER vouches for it (verifying it on
                                 the device would read the rows it is meant to save); the Python
                                 driver compares the host arrays.                                */
+#define PM_JN_SPLIT_LANES 8  /* OPT-IN lane layout of the uniform-Area kernel (round 5): the two
+                                columns of a member step together, basin on lanes 0..31 and
+                                north on lanes 32..63 with ceil(nz/32) levels per lane, instead
+                                of one after the other on 64 lanes each.  Same arithmetic per
+                                level, bit-identical results; 65 <= nz <= 128 or 193 <= nz <= 224,
+                                other shapes ignore the hint.                                  */
 typedef struct pm_jn2018 {
   int32_t n, hints, reserved1, reserved2;
   pm_columns cols;

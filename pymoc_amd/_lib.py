@@ -61,7 +61,7 @@ class pm_thermwind(C.Structure):
 (PM_SO_HAS_C, PM_SO_BVP_WITH_EK, PM_SO_HAS_HSILL, PM_SO_HAS_HEK, PM_SO_HAS_HTAPERTOP,
  PM_SO_HAS_HTAPERBOT, PM_SO_TAU_ARRAY) = 1, 2, 4, 8, 16, 32, 64
 PM_SO_OP_EKMAN, PM_SO_OP_GM, PM_SO_OP_SOLVE = 1, 2, 3
-PM_JN_UNIFORM_AREA, PM_JN_CONTRACTED, PM_JN_SHARED_COEF = 1, 2, 4
+PM_JN_UNIFORM_AREA, PM_JN_CONTRACTED, PM_JN_SHARED_COEF, PM_JN_SPLIT_LANES = 1, 2, 4, 8
 
 
 class pm_psi_so(C.Structure):

@@ -1013,6 +1013,819 @@ __global__ __launch_bounds__(64) void k_jn2018_ieee(pm_jn2018 a, double dt, int 
   }
 }
 
+// =============================================================================================
+// Round 5: the SPLIT lane layout.  One wavefront still owns one member, but the two columns of
+// the member step TOGETHER: lanes 0..31 hold the basin column, lanes 32..63 the northern one,
+// P = ceil(nz / 32) consecutive levels per lane.  One pass of the column arithmetic then advances
+// both columns -- at nz = 200 that is 7 level slots (32 x 7 = 224, 89 % of the lanes' slots are
+// real levels) instead of 2 x 4 slots at 64 x 4 = 256 (78 %): an eighth fewer vector instructions
+// in the column phase, one joint convective-pattern test instead of two, and every coefficient in
+// registers (the northern column's kappa no longer comes from LDS).  The arithmetic per level is
+// the same as in jf_vertadvdiff, operation by operation: bit-identical.
+//   * block-shared grid tables are indexed by (lane & 31, slot): both halves read the same entry;
+//   * per-column scalars (bs, N2min, zconv, Area and its reciprocal pair) sit in the wave's LDS
+//     block at `half * S_COL`, read with a per-lane address;
+//   * the wave shifts of the 3-point stencil cross the half boundary only into padding /
+//     boundary levels, whose table entries (1/dz = 0, 1/dzc = 0, weff = 0) null them exactly;
+//   * the bottom-BC switch runs in lane 0 on the basin's levels 0, 1 and the northern ones
+//     brought over by v_permlane32_swap; the northern bottom value goes back the same way;
+//   * rows move between HBM and the slot layout THROUGH LDS: global loads and stores are
+//     lane-contiguous (coalesced 512-byte runs), the transposition is an LDS write + read.
+// Shapes: 4 <= nz <= 224, ny <= 64, uniform Area (as k_jn2018_fast); nz > 224 keeps that kernel.
+// The IEEE follow-up launch (k_jn2018_ieee) is shared: a member outside the exact-division window
+// stops here with its state in HBM, whatever the lane layout was.
+template <int P>
+struct JsLds {
+  static constexpr int HP = (P + 1) / 2;   // slot pairs
+  static constexpr int NT = 64 * HP;       // doubles per table: entry (hl, p) at ((p/2)*32 + hl)*2 + (p&1)
+  static constexpr int NLEV = 32 * P + (32 * P) % 2;  // levels incl. padding
+  static constexpr int T_Z = 0, T_DZ = NT, T_RDZ = 2 * NT, T_RDZL = 3 * NT, T_DZC = 4 * NT,
+                       T_RDZC = 5 * NT, T_RDZCL = 6 * NT;
+  static constexpr int PCR = 7 * NT;
+  static constexpr int KML = PCR + JF_PCR_DOUBLES;
+  static constexpr int PROG = KML + K_N;
+  static constexpr int WAVE0 = PROG + 8;
+  // per wave: b_basin[level] (np.interp's xp, and the basin half of every row transposition),
+  // Psi_mod[level], a staging row (the northern half of a transposition), {surflux/h,
+  // rest_mask*v_pist/h}[64], b_rest[64], Psi_s[64], the member's scalars
+  // (W_ST doubles as the cache of the northern column's adjusted values bs + N2min (z - zc) inside
+  // the step loop, in the tables' slot-pair layout: 32 lanes x 2 HP doubles)
+  static constexpr int NST = NLEV > 64 * HP ? NLEV : 64 * HP;
+  static constexpr int W_BB = 0, W_PM = NLEV, W_ST = 2 * NLEV, W_F = 2 * NLEV + NST,
+                       W_BR = W_F + 128, W_PS = W_F + 192, W_S = W_F + 256;
+  static constexpr int PER_WAVE = W_S + S_N;
+  static constexpr int TOTAL = WAVE0 + JF_WAVES * PER_WAVE;
+};
+
+template <int P>
+__device__ __forceinline__ int js_entry(int hl, int p) {
+  return ((p >> 1) * 32 + hl) * 2 + (p & 1);
+}
+__device__ __forceinline__ double2 js_pair(const double *T, int hl, int h) {
+  return *reinterpret_cast<const double2 *>(T + (h * 32 + hl) * 2);
+}
+
+template <int P>
+struct JsCol {
+  double b[P];          // both columns' state: lanes 0..31 basin, 32..63 north; padding JF_PAD
+  double wn[P], wp[P];  // upwind split of -weff (contracted mode: cu, cl)
+  double kap[P];
+};
+
+template <int P>
+__device__ __forceinline__ void js_block_tables(const pm_jn2018 &a, double dt, double *lds,
+                                                int wave, int lane) {
+  using L = JsLds<P>;
+  const int nz = a.cols.nz, ny = a.ml.ny;
+  for (int e = threadIdx.x; e < L::NT; e += blockDim.x) {
+    const double *z = a.cols.z;
+    const int h = e >> 6, hl = (e >> 1) & 31, q = e & 1;
+    const int p = 2 * h + q;
+    const int i = (p < P) ? hl * P + p : nz;  // (the unused half of an odd P's last pair: padding)
+    const int ic = i < nz ? i : nz - 1;
+    const int iu = ic + 1 < nz ? ic + 1 : nz - 1;
+    const int id = ic > 0 ? ic - 1 : 0;
+    const double zc = z[ic];
+    const double dz = z[iu] - zc;
+    const double dzc = 0.5 * (dz + (zc - z[id]));
+    const bool has_up = i < nz - 1, interior = i >= 1 && i <= nz - 2;
+    const double rdz = has_up ? 1.0 / dz : 0.0;
+    const double rdzc = interior ? 1.0 / dzc : 0.0;
+    lds[L::T_Z + e] = zc;
+    lds[L::T_DZ + e] = dz;
+    lds[L::T_RDZ + e] = rdz;
+    lds[L::T_RDZL + e] = has_up ? recip_lo(dz, rdz) : 0.0;
+    lds[L::T_DZC + e] = dzc;
+    lds[L::T_RDZC + e] = rdzc;
+    lds[L::T_RDZCL + e] = interior ? recip_lo(dzc, rdzc) : 0.0;
+  }
+  if (wave == 0) {
+    if (lane < 16) reinterpret_cast<int *>(lds + L::PROG)[lane] = 0;
+    const double ml_h = a.ml.h, ml_L = a.ml.L, dy = a.ml.y[1] - a.ml.y[0];
+    const double ms_s = a.ml.Ks * dt / (dy * dy);  // SO_ML.py:191
+    jf_build_pcr(lds + L::PCR, ny, ms_s, lane);
+    if (lane == 0) {
+      double *K = lds + L::KML;
+      const double rh = 1.0 / ml_h, rL = 1.0 / ml_L, rdy = 1.0 / dy;
+      K[K_H] = ml_h;
+      K[K_RH] = rh;
+      K[K_RHL] = recip_lo(ml_h, rh);
+      K[K_L] = ml_L;
+      K[K_RL] = rL;
+      K[K_RLL] = recip_lo(ml_L, rL);
+      K[K_DY] = dy;
+      K[K_RDY] = rdy;
+      K[K_RDYL] = recip_lo(dy, rdy);
+      K[K_SH] = ms_s / 2.;
+      K[K_1MS] = 1 - ms_s;
+    }
+  }
+}
+
+// rows in the lane-contiguous layout.  VEC (rows 16-byte aligned, nz even: decided by the
+// launcher): element k of a lane = level 128 (k / 2) + 2 lane + (k & 1), two 16-byte accesses per
+// row; else level 64 k + lane, four 8-byte accesses.
+constexpr int JS_CH = 4;  // covers nz <= 256
+template <bool VEC>
+__device__ __forceinline__ int js_ci(int k, int lane) {
+  return VEC ? 128 * (k >> 1) + 2 * lane + (k & 1) : 64 * k + lane;
+}
+template <bool VEC>
+__device__ __forceinline__ void js_load_chunks(double (&g)[JS_CH], const double *__restrict__ row,
+                                               int lane, int nz) {
+  if constexpr (VEC) {
+#pragma unroll
+    for (int kk = 0; kk < JS_CH / 2; ++kk) {
+      const int i0 = 128 * kk + 2 * lane;
+      const double2 v = *reinterpret_cast<const double2 *>(row + (i0 < nz - 2 ? i0 : nz - 2));
+      g[2 * kk] = v.x;
+      g[2 * kk + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < JS_CH; ++k) {
+      const int i = 64 * k + lane;
+      g[k] = row[i < nz ? i : nz - 1];
+    }
+  }
+}
+// into a level-ordered LDS row; levels >= nz go to `dump` (16 bytes nobody reads): no branches
+template <bool VEC>
+__device__ __forceinline__ void js_stage(double *stage, double *dump, const double (&g)[JS_CH],
+                                         int lane, int nz) {
+  if constexpr (VEC) {
+#pragma unroll
+    for (int kk = 0; kk < JS_CH / 2; ++kk) {
+      const int i0 = 128 * kk + 2 * lane;
+      double *dst = i0 < nz ? stage + i0 : dump;
+      *reinterpret_cast<double2 *>(dst) = make_double2(g[2 * kk], g[2 * kk + 1]);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < JS_CH; ++k) {
+      const int i = 64 * k + lane;
+      double *dst = i < nz ? stage + i : dump;
+      *dst = g[k];
+    }
+  }
+}
+
+// Column.convect for both columns at once (column.py:251-271, do_conv = True).  wsh = the lane's
+// column's scalar block (ws + half * S_COL); adjn = the wave's cache of the NORTHERN column's
+// adjusted values bs + N2min (z - zc) under the cached pattern, slot-pair layout (the basin column
+// almost never convects: while it does, the values are formed per step).
+template <int P>
+struct JsConv {
+  unsigned long long cm[P];
+  bool any;    // some level of either column convects under the cached pattern
+  bool any_b;  // ... of the basin column
+  bool valid;
+};
+
+template <int P>
+__device__ __forceinline__ void js_convect(double (&b)[P], JsConv<P> &s, const double *lds,
+                                           double *wsh, double *adjn, int lane, int hl, int nz) {
+  using L = JsLds<P>;
+  const double bs = wsh[S_BS];
+  const bool north = lane >= 32;
+  unsigned long long m[P], acc = 0ull;
+  bool cvp[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    cvp[p] = b[p] > bs;  // column.py:264 (padding: never)
+    m[p] = __builtin_amdgcn_ballot_w64(cvp[p]);
+    acc |= m[p] ^ s.cm[p];
+  }
+  if (__builtin_expect(acc != 0ull || !s.valid, 0)) {
+    JF_RARE(1)
+    // new pattern: per column, zc = z at the highest non-convecting level (column.py:265-267)
+    unsigned long long anym = 0ull;
+    int jmax_b = 0, jmax_n = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      anym |= m[p];
+      const int nv = (nz - p + P - 1) / P;  // lanes of a half whose slot p is a real level (<= 32)
+      const unsigned int vmask = nv >= 32 ? ~0u : ((1u << nv) - 1u);
+      const unsigned int nb_ = ~(unsigned int)(m[p] & 0xffffffffull) & vmask;
+      const unsigned int nn_ = ~(unsigned int)(m[p] >> 32) & vmask;
+      if (nb_ != 0u) {
+        const int j = (31 - __clz((int)nb_)) * P + p;
+        jmax_b = j > jmax_b ? j : jmax_b;
+      }
+      if (nn_ != 0u) {
+        const int j = (31 - __clz((int)nn_)) * P + p;
+        jmax_n = j > jmax_n ? j : jmax_n;
+      }
+      s.cm[p] = m[p];
+    }
+    const bool any_b = (anym & 0xffffffffull) != 0ull, any_n = (anym >> 32) != 0ull;
+    s.any = anym != 0ull;
+    s.any_b = any_b;
+    s.valid = true;
+    const bool half = north;
+    const int jm = half ? jmax_n : jmax_b;
+    const double zv = lds[L::T_Z + js_entry<P>(jm / P, jm % P)];
+    if (hl == 0) wsh[S_ZC] = zv;  // (only read where the column's pattern has convecting levels)
+    const double n2 = wsh[S_N2];
+    const bool none_here = half ? !any_n : !any_b;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (none_here && hl * P + p == nz - 1) b[p] = bs;  // column.py:271
+      // the northern column's adjusted values under this pattern (column.py:268)
+      const double adj = bs + n2 * (lds[L::T_Z + js_entry<P>(hl, p)] - zv);
+      if (half) adjn[js_entry<P>(hl, p)] = adj;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (s.any) {
+    JF_RARE(6)
+    // the northern half takes its cached values where it convects
+#pragma unroll
+    for (int h = 0; h < L::HP; ++h) {
+      const double2 a2 = js_pair(adjn, hl, h);
+      b[2 * h] = (cvp[2 * h] && north) ? a2.x : b[2 * h];
+      if (2 * h + 1 < P) {
+        const int p1 = 2 * h + 1 < P ? 2 * h + 1 : 0;
+        b[p1] = (cvp[p1] && north) ? a2.y : b[p1];
+      }
+    }
+    if (__builtin_expect(s.any_b, 0)) {
+      // the basin column convects (rare): its lanes are patched in place with values formed here
+      const double2 nc = *reinterpret_cast<const double2 *>(wsh + S_N2);  // {N2min, zc}
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const double adj = bs + nc.x * (lds[L::T_Z + js_entry<P>(hl, p)] - nc.y);  // column.py:268
+        b[p] = (cvp[p] && !north) ? adj : b[p];
+      }
+    }
+  }
+}
+
+// Column.vertadvdiff of both columns (jf_vertadvdiff's operations per level).
+template <int P>
+__device__ __forceinline__ void js_vertadvdiff(JsCol<P> &c, const double *lds, const double *wsh,
+                                               int hl, double dt) {
+  using L = JsLds<P>;
+  constexpr int HP = L::HP;
+  double bz[P];  // (b[i+1]-b[i])/dz[i] (column.py:235)
+  const double nb0 = from_next_lane_z(c.b[0]);
+#pragma unroll
+  for (int h = 0; h < HP; ++h) {
+    const double2 dz = js_pair(lds + L::T_DZ, hl, h), y = js_pair(lds + L::T_RDZ, hl, h),
+                  yl = js_pair(lds + L::T_RDZL, hl, h);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = 2 * h + q;
+      if (p < P) {
+        const double up = (p < P - 1) ? c.b[p + 1 < P ? p + 1 : p] : nb0;
+        bz[p] = div_by_recip2(up - c.b[p], q ? dz.y : dz.x, q ? y.y : y.x, q ? yl.y : yl.x);
+      }
+    }
+    if (P > 2) __builtin_amdgcn_sched_barrier(0);  // one slot pair's tables live at a time
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const double pbz = from_prev_lane_z(bz[P - 1]);
+  const double area = wsh[S_AREA];
+  const double2 ra = *reinterpret_cast<const double2 *>(wsh + S_RAREA);  // {1/area, its low part}
+#pragma unroll
+  for (int h = 0; h < HP; ++h) {
+    const double2 dzc = js_pair(lds + L::T_DZC, hl, h), y = js_pair(lds + L::T_RDZC, hl, h),
+                  yl = js_pair(lds + L::T_RDZCL, hl, h);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = 2 * h + q;
+      if (p < P) {
+        const double dn = (p > 0) ? bz[p > 0 ? p - 1 : 0] : pbz;
+        const double bzz =
+            div_by_recip2(bz[p] - dn, q ? dzc.y : dzc.x, q ? y.y : y.x, q ? yl.y : yl.x);  // :238
+        const double flx = __builtin_fma(c.wn[p], bz[p], c.wp[p] * dn);  // column.py:242-246
+        const double adv = div_by_recip2(flx, area, ra.x, ra.y);
+        c.b[p] = c.b[p] + dt * (adv + c.kap[p] * bzz);  // column.py:245-249
+      }
+    }
+    if (P > 2) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int P>
+__device__ __forceinline__ void js_vertadvdiff_contracted(JsCol<P> &c) {
+  const double nb0 = from_next_lane_z(c.b[0]);
+  double d_up[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) d_up[p] = ((p < P - 1) ? c.b[p + 1 < P ? p + 1 : p] : nb0) - c.b[p];
+  const double pd = from_prev_lane_z(d_up[P - 1]);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const double d_dn = (p > 0) ? d_up[p > 0 ? p - 1 : 0] : pd;
+    c.b[p] = __builtin_fma(c.wn[p], d_up[p], __builtin_fma(c.wp[p], d_dn, c.b[p]));
+  }
+}
+
+template <int P, bool CT, bool VEC>
+__device__ __forceinline__ int js_member_run(const pm_jn2018 &a, double dt, int nsteps, int m_raw,
+                                              double *lds, int wave, int lane) {
+  using L = JsLds<P>;
+  const bool m_ok = m_raw < a.n;
+  const int m = m_ok ? m_raw : a.n - 1;
+  const int n = a.n, nz = a.cols.nz, ny = a.ml.ny;
+  const int half = lane >> 5, hl = lane & 31;
+  double *wl = lds + L::WAVE0 + wave * L::PER_WAVE;
+  double *ws = wl + L::W_S;
+  double *dump = ws + 14;  // two unused doubles of the scalar block
+  const int col = m + half * n;  // this lane's column
+
+  JsCol<P> c;
+  JsConv<P> cv;
+  int ksel_b, ksel_n;
+  bool hint_ok = true, range_ok = in_fast_div_range_or_lost(dt);
+  const bool shared = (a.hints & PM_JN_SHARED_COEF) != 0;
+  int cbits;
+  int ml_ind = nz, first_pos = nz;  // SO_ML.py:228-229, :95
+  bool ml_ok;
+  JfMl q;
+  q.bs = 0.;
+  q.jh = 0;
+  {
+    const pm_columns &cc = a.cols;
+    // ---- all rows of the launch's start requested at once, lane-contiguous
+    double gb[JS_CH], gn[JS_CH], ab[JS_CH], an[JS_CH], gp[JS_CH];
+    const size_t arow_b = (size_t)(shared ? 0 : m) * nz, arow_n = (size_t)(shared ? n : n + m) * nz;
+    const size_t bzr = (size_t)m * nz, by = (size_t)m * ny;
+    js_load_chunks<VEC>(gb, cc.b + (size_t)m * nz, lane, nz);
+    js_load_chunks<VEC>(gn, cc.b + (size_t)(n + m) * nz, lane, nz);
+    js_load_chunks<VEC>(ab, cc.area + arow_b, lane, nz);
+    js_load_chunks<VEC>(an, cc.area + arow_n, lane, nz);
+    js_load_chunks<VEC>(gp, a.Psi_SO + bzr, lane, nz);
+    const double a0b = cc.area[arow_b], a0n = cc.area[arow_n];
+    const double a0 = half ? a0n : a0b;
+    ksel_b = cc.ksel[m];
+    ksel_n = cc.ksel[n + m];
+    {  // Area constant in z?  operands inside the exact-division window?
+      bool same = true, ok = in_fast_div_range_or_lost(a0) && a0 != 0.0 &&
+                             in_fast_div_range_or_lost(cc.bs[col]) &&
+                             in_fast_div_range_or_lost(cc.N2min[col]) &&
+                             in_fast_div_range_or_lost(cc.bbot[col]);
+#pragma unroll
+      for (int k = 0; k < JS_CH; ++k) {
+        const bool real = js_ci<VEC>(k, lane) < nz;
+        same = same && (!real || (ab[k] == a0b && an[k] == a0n));
+        ok = ok && (!real || (in_fast_div_range_or_lost(gb[k]) && in_fast_div_range_or_lost(gn[k])));
+      }
+      hint_ok = __ballot(!same) == 0ull;
+      range_ok = range_ok && __ballot(!ok) == 0ull;
+    }
+    if (hl == 0) {
+      double *wsc = ws + half * S_COL;
+      const double ra = 1.0 / a0;
+      wsc[S_BS] = cc.bs[col];
+      wsc[S_N2] = cc.N2min[col];
+      wsc[S_ZC] = 0.;
+      wsc[S_AREA] = a0;
+      wsc[S_RAREA] = ra;
+      wsc[S_RAREAL] = recip_lo(a0, ra);
+    }
+    // ---- state into the slot layout: basin through W_BB, north through the staging row
+    js_stage<VEC>(wl + L::W_BB, dump, gb, lane, nz);
+    js_stage<VEC>(wl + L::W_ST, dump, gn, lane, nz);
+    __builtin_amdgcn_wave_barrier();
+    {
+      const double *src = wl + (half ? L::W_ST : L::W_BB);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = hl * P + p;
+        const double v = src[i < nz ? i : nz - 1];  // (unconditional read, then a select)
+        c.b[p] = i < nz ? v : JF_PAD;
+        cv.cm[p] = 0ull;
+      }
+      cv.any = false;
+      cv.any_b = false;
+      cv.valid = false;
+    }
+    // static conditions of the BC switch: bit 0 Psi_SO[1] < 0, bit 1 Psi_SO[1] >= 0, bit 2
+    // Psi_res_b[1] > 0, bit 3 Psi_res_n[1] < 0
+    const double PsiSO1 = a.Psi_SO[bzr + 1], Pb1 = a.Psi_res_b[bzr + 1], Pn1 = a.Psi_res_n[bzr + 1];
+    cbits = (PsiSO1 < 0 ? 1 : 0) | (PsiSO1 >= 0 ? 2 : 0) | (Pb1 > 0 ? 4 : 0) | (Pn1 < 0 ? 8 : 0);
+    // ---- mixed layer: Psi_mod (SO_ML.py:228-230) is Psi_b with its leading zeros filled
+#pragma unroll
+    for (int k = 0; k < JS_CH; ++k) {
+      const int i = js_ci<VEC>(k, lane);
+      const bool real = i < nz;
+      const unsigned long long nzm = __ballot(real && gp[k] != 0.), pm_ = __ballot(real && gp[k] > 0.);
+      // (lowest set lane = lowest level of this element in both layouts)
+      if (nzm) {
+        const int j = js_ci<VEC>(k, (int)__ffsll((long long)nzm) - 1);
+        ml_ind = j < ml_ind ? j : ml_ind;
+      }
+      if (pm_) {
+        const int j = js_ci<VEC>(k, (int)__ffsll((long long)pm_) - 1);
+        first_pos = j < first_pos ? j : first_pos;
+      }
+    }
+    ml_ok = ml_ind < nz;  // all-zero Psi_b: IndexError in the reference
+    const double fillv = ml_ok ? a.Psi_SO[bzr + ml_ind] : 0.;
+    {
+      double pmv[JS_CH];
+#pragma unroll
+      for (int k = 0; k < JS_CH; ++k) pmv[k] = (js_ci<VEC>(k, lane) < ml_ind) ? fillv : gp[k];
+      js_stage<VEC>(wl + L::W_PM, dump, pmv, lane, nz);
+    }
+    double f1 = 0., f2 = 0., br = 0.;
+    if (lane < ny) {
+      q.bs = a.ml.bs[by + lane];
+      if (ml_ok) {  // loop-invariant parts of the surface-flux tendency (SO_ML.py:250-252)
+        const double ml_h = a.ml.h;
+        f1 = a.ml.surflux[by + lane] / ml_h;
+        f2 = a.ml.rest_mask[by + lane] * a.ml.v_pist / ml_h;
+        br = a.ml.b_rest[by + lane];
+      }
+    }
+    wl[L::W_F + 2 * lane] = f1;
+    wl[L::W_F + 2 * lane + 1] = f2;
+    wl[L::W_BR + lane] = br;
+    if (lane == 0) ws[S_BBOT0] = a.cols.bbot[m];
+  }
+  __syncthreads();  // the block's tables (js_block_tables) are complete
+  {  // the grid's part of the operand window (z, dz, dzc)
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = hl * P + p, e = js_entry<P>(hl, p);
+      const double zv = lds[L::T_Z + e], dzv = lds[L::T_DZ + e], dzcv = lds[L::T_DZC + e];
+      ok = ok && (i >= nz || (in_fast_div_range_or_lost(zv) &&
+                              (i >= nz - 1 || (in_fast_div_range_or_lost(dzv) && dzv != 0.0)) &&
+                              in_fast_div_range_or_lost(dzcv) && dzcv != 0.0));
+    }
+    range_ok = range_ok && __ballot(!ok) == 0ull;
+  }
+  int status = ml_ok ? 0 : 1;
+  bool ps_valid = false;
+  const bool lane0 = lane == 0;
+  const bool ml_act = lane < ny, ml_int = lane >= 1 && lane <= ny - 2;
+
+  int s = hint_ok ? 0 : nsteps;
+  bool skipped = false;
+  while (s < nsteps) {
+    {
+      // ---- coefficients of the sets in use: kappa, weff = wA - d(A kappa)/dz of both columns;
+      // six lane-contiguous rows, transposed one array at a time (basin half through W_BB --
+      // rewritten by the first step anyway --, northern half through the staging row)
+      jf_kargs ka = jf_args();
+      bool coef_ok = true;
+      cv.valid = false;  // (the transposes below overwrite the cache of adjusted values in W_ST)
+      const double *kappa = ka->cols.kappa, *dAk = ka->cols.dAkappa, *wA = ka->wA;
+      const bool shared_rows = (ka->hints & PM_JN_SHARED_COEF) != 0;
+      const size_t sb_b = ((size_t)ksel_b * (2 * n) + (shared_rows ? 0 : m)) * nz;
+      const size_t sb_n = ((size_t)ksel_n * (2 * n) + (shared_rows ? n : n + m)) * nz;
+      __builtin_amdgcn_sched_barrier(0);  // (the launch's first rows are consumed before these are requested)
+      double kb_[JS_CH], kn_[JS_CH], wb_[JS_CH], wn_[JS_CH];
+      js_load_chunks<VEC>(kb_, kappa + sb_b, lane, nz);
+      js_load_chunks<VEC>(kn_, kappa + sb_n, lane, nz);
+      {  // weff = wA - d(A kappa)/dz (column.py:241) while the rows are still lane-contiguous
+        double db_[JS_CH], dn_[JS_CH];
+        js_load_chunks<VEC>(db_, dAk + sb_b, lane, nz);
+        js_load_chunks<VEC>(dn_, dAk + sb_n, lane, nz);
+        js_load_chunks<VEC>(wb_, wA + (size_t)m * nz, lane, nz);
+        js_load_chunks<VEC>(wn_, wA + (size_t)(n + m) * nz, lane, nz);
+#pragma unroll
+        for (int k = 0; k < JS_CH; ++k) {
+          wb_[k] = wb_[k] - db_[k];
+          wn_[k] = wn_[k] - dn_[k];
+        }
+      }
+      const double *src = wl + (half ? L::W_ST : L::W_BB);
+      double rk[P], rw[P];
+      auto transpose = [&](double (&out)[P], const double (&g0)[JS_CH], const double (&g1)[JS_CH]) {
+        __builtin_amdgcn_wave_barrier();
+        js_stage<VEC>(wl + L::W_BB, dump, g0, lane, nz);
+        js_stage<VEC>(wl + L::W_ST, dump, g1, lane, nz);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int i = hl * P + p;
+          out[p] = src[i < nz ? i : nz - 1];
+        }
+      };
+      transpose(rk, kb_, kn_);
+      transpose(rw, wb_, wn_);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int i = hl * P + p;
+        c.kap[p] = rk[p];
+        const double w = rw[p];
+        const bool interior = i >= 1 && i <= nz - 2;
+        const double we = interior ? w : 0.0;
+        c.wn[p] = (we < 0.0) ? -we : 0.0;
+        c.wp[p] = (we < 0.0) ? 0.0 : -we;
+        if constexpr (!CT)
+          coef_ok = coef_ok && in_fast_div_range_or_lost(we) && in_fast_div_range_or_lost(c.kap[p]);
+        if constexpr (CT) {
+          // cu = dt (kappa / (dzc dz) + wn / (A dz)), cl = dt (-kappa / (dzc dz') + wp / (A dz'))
+          // (col_make_contracted, column.hip.h)
+          const int iq = interior ? i : 1;
+          const double dz_up = lds[L::T_DZ + js_entry<P>(iq / P, iq % P)],
+                       dz_dn = lds[L::T_DZ + js_entry<P>((iq - 1) / P, (iq - 1) % P)],
+                       dzc = lds[L::T_DZC + js_entry<P>(iq / P, iq % P)];
+          const double area = ws[half * S_COL + S_AREA];
+          const double cu = dt * (c.kap[p] / (dzc * dz_up) + c.wn[p] / (area * dz_up));
+          const double cl = dt * (-c.kap[p] / (dzc * dz_dn) + c.wp[p] / (area * dz_dn));
+          c.wn[p] = interior ? cu : 0.0;
+          c.wp[p] = interior ? cl : 0.0;
+        }
+      }
+      if constexpr (!CT) {
+        range_ok = range_ok && __ballot(!coef_ok) == 0ull;
+        if (__builtin_expect(!range_ok, 0)) {
+          skipped = true;  // the IEEE follow-up launch takes the member from step s on
+          break;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // BC switch + both columns of step s; false: a coefficient set changed (nothing done yet)
+    // static part of the BC switch (Psi only changes at MOC updates)
+    const bool c_south = (cbits & 1) != 0, c_nosouth = (cbits & 2) != 0, c_pb = (cbits & 4) != 0,
+               c_pn = (cbits & 8) != 0;
+    const int kb_static = c_nosouth ? 0 : (c_south ? 1 : ksel_b);
+    auto columns_step = [&](int lane_o, int hl_o, double *wl, double *ws, double *wsh) -> bool {
+#ifndef JF_NO_PRIO_ROTATE
+      {  // issue priority by lag (see jf_member_run)
+        int *prog = reinterpret_cast<int *>(lds + L::PROG) + (wave & 3) * 4;
+        prog[wave >> 2] = s;
+        const int4 pv = *reinterpret_cast<const int4 *>(prog);
+        const int p0 = __builtin_amdgcn_readfirstlane(pv.x), p1 = __builtin_amdgcn_readfirstlane(pv.y),
+                  p2 = __builtin_amdgcn_readfirstlane(pv.z), p3 = __builtin_amdgcn_readfirstlane(pv.w);
+        const int lo = min(min(p0, p1), min(p2, p3)), hi = max(max(p0, p1), max(p2, p3));
+        if (s <= lo) __builtin_amdgcn_s_setprio(3);
+        else if (s >= hi) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(1);
+      }
+#endif
+      // ---- bottom-BC switch (run_JansenNadeau_2018.py:233-254).  Lane 0 decides the basin's
+      // bottom value, lane 32 the northern one; each needs the OTHER column's level 0 (one
+      // v_permlane32_swap) and its own level 1:
+      //   basin: bn0 if Psi_res_b[1] > 0 and bn0 < bb1 and bn0 < bs_SO[0]   (from the north)
+      //          else bb1 (no bottom water from the south) / bs_SO[0] (from the south) / unchanged
+      //   north: bb0 if Psi_res_n[1] < 0 and bb0 < bn1                      (from the basin)
+      //          else bn1
+      // The static conditions are lane masks (bc_*), the diffusivity sets follow from two bits.
+      double bbot;
+      {
+        const bool north = lane_o >= 32;
+        const double o0 = jf_swap_halves(c.b[0], !north);
+        const bool p1 = o0 < c.b[1], p2 = o0 < q.bs;
+        // (mask algebra on the scalar unit: bit 0 decides for the basin, bit 32 for the north)
+        const bool cnd = p1 && ((north && c_pn) || (!north && c_pb && p2));
+        const unsigned long long cm_ = __builtin_amdgcn_ballot_w64(cnd);
+        const double carry = (s == 0) ? ws[S_BBOT0] : c.b[0];
+        const double alt = (north || c_nosouth) ? c.b[1] : (c_south ? q.bs : carry);
+        bbot = cnd ? o0 : alt;
+        const int kb = (cm_ & 1ull) ? 1 : kb_static;
+        const int kn = (int)((cm_ >> 32) & 1ull);
+        if (__builtin_expect(kb != ksel_b || kn != ksel_n, 0)) {
+          JF_RARE(2)
+          ksel_b = kb;
+          ksel_n = kn;
+          return false;
+        }
+      }
+      // ---- basin.timestep / north.timestep, do_conv=True (:257-258)
+      js_convect<P>(c.b, cv, lds, wsh, wl + L::W_ST, lane_o, hl_o, nz);
+      c.b[0] = (hl_o == 0) ? bbot : c.b[0];  // column.py:232 (after convect: it may write level 0)
+      if constexpr (CT) {
+        js_vertadvdiff_contracted<P>(c);
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+        js_vertadvdiff<P>(c, lds, wsh, hl_o, dt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return true;
+    };
+    if (ml_ok) {
+    for (; s < nsteps; ++s) {
+      int lane_o = lane, woff = wave * L::PER_WAVE;
+      asm volatile("" : "+v"(lane_o), "+s"(woff));
+      const int a4 = lane_o << 2, hl_o = lane_o & 31;
+      double *wl = lds + L::WAVE0 + woff, *ws = wl + L::W_S;
+      double *wsh = ws + (lane_o >> 5) * S_COL;
+      if (__builtin_expect(!columns_step(lane_o, hl_o, wl, ws, wsh), 0)) break;
+      JF_RARE(0)
+      // ---- channel.timestep(b_basin=basin.b, Psi_b=PsiSO.Psi) (:261), ml_step_reg's operations
+      {
+        const double *bb = wl + L::W_BB, *pm = wl + L::W_PM;
+        if (lane_o < 32) {  // basin.b by level for np.interp
+          double *dst = wl + L::W_BB + hl_o * P;
+#pragma unroll
+          for (int p = 0; p < P; ++p) dst[p] = c.b[p];
+        }
+        __builtin_amdgcn_wave_barrier();
+        double ps;
+        {
+          const double x = q.bs;
+          const int j0 = q.jh;  // <= nz - 2
+          const double x0 = bb[j0], x1 = bb[j0 + 1];
+          int j = j0 + (x >= x1 ? 1 : 0) - (x < x0 ? 1 : 0);
+          j = j < 0 ? 0 : (j > nz - 2 ? nz - 2 : j);
+          const double lx = bb[j], hx = bb[j + 1], lf = pm[j], hf = pm[j + 1];
+          const double xlo = bb[0], xhi = bb[nz - 1];
+          const bool hit = (lx <= x) && (x < hx);
+          ps = interp_finish(x, j, lx, hx, lf, hf);
+          const bool isnan_x = x != x, above = x >= xhi, below = x < xlo;
+          if (below) ps = pm[0];
+          if (above) ps = pm[nz - 1];
+          if (isnan_x) ps = x;
+          q.jh = j;
+          const bool search = ml_act && !hit && !isnan_x && !above && !below;
+          if (__builtin_expect(__ballot(search) != 0ull, 0)) {
+            JF_RARE(3)
+            if (search) {  // np.interp's upper-bound search from scratch
+              int lo_i = 0, hi_i = nz;
+              while (lo_i < hi_i) {
+                const int mid = lo_i + ((hi_i - lo_i) >> 1);
+                if (x >= bb[mid])
+                  lo_i = mid + 1;
+                else
+                  hi_i = mid;
+              }
+              const int jb = lo_i - 1;
+              const int jj = (jb == nz - 1) ? nz - 2 : (jb < 0 ? 0 : jb);
+              q.jh = jj;
+              ps = (jb == nz - 1) ? pm[nz - 1]
+                                  : interp_finish(x, jb, bb[jj], bb[jj + 1], pm[jj], pm[jj + 1]);
+            }
+          }
+        }
+        // argmin(bs): first minimum, a NaN wins (np.argmin); 0 when no point lies below point 0
+        int amin = 0;
+        {
+          const double v = ml_act ? q.bs : __builtin_inf();
+          const double v0 = lane_value(q.bs, 0);
+          if (__builtin_expect(__ballot(!(v >= v0)) != 0ull, 0)) {
+            JF_RARE(5)
+            const double mn = wave_min_f64(v);
+            const unsigned long long at_min = __ballot(ml_act && v == mn);
+            const unsigned long long nanm = __ballot(ml_act && v != v);
+            const int mi = at_min ? (int)__ffsll((long long)at_min) - 1 : 0;
+            amin = nanm ? (int)__ffsll((long long)nanm) - 1 : mi;
+          }
+        }
+        if (lane < amin || lane0) ps = 0.;  // :240-243
+        const bool upwell = (__ballot(ps > 0) & 2ull) != 0ull;  // set_boundary_conditions, :93-98
+        if (__builtin_expect(upwell && first_pos >= nz, 0)) {
+          ml_ok = false;  // IndexError in the reference; the mixed layer stops evolving
+          status = 1;
+          ++s;
+          break;
+        } else {
+          __builtin_amdgcn_sched_barrier(0);
+          const double2 *K2 = reinterpret_cast<const double2 *>(lds + L::KML);
+          const double2 k0 = K2[0], k1 = K2[1], k2 = K2[2], k3 = K2[3], k4 = K2[4];
+          const double k_1ms = lds[L::KML + K_1MS];
+          const double2 ff = *reinterpret_cast<const double2 *>(wl + L::W_F + 2 * lane_o);
+          const double brest = wl[L::W_BR + lane_o];
+          const double bsouth = upwell ? bb[first_pos < nz ? first_pos : 0] : 0.;
+          double bs = q.bs;
+          const double bs_up = from_next_lane_z(bs);
+          bs = lane0 ? (upwell ? bsouth : bs_up) : bs;
+          const double bs_dn = from_prev_lane_z(bs);
+          const double flux = ff.x + ff.y * (brest - bs);  // (:250-259)
+          double adv;
+          {
+            const double d = (ps < 0.) ? (bs_up - bs) : (bs - bs_dn);
+            const double num = -ps * 1e6 * d;
+            const double q1 = div_by_recip2(num, k1.x, k0.y, k0.x);
+            const double q2 = div_by_recip2(q1, k2.y, k2.x, k1.y);
+            const double t = div_by_recip2(q2, k4.x, k3.y, k3.x);
+            adv = (ml_int && ps != 0. && ps == ps) ? t : 0.;
+          }
+          bs = bs + dt * (flux + adv);  // every tendency uses the old bs
+          const double bu = from_next_lane_z(bs);
+          if (!upwell) bs = lane0 ? bu : bs;  // no-flux BC re-set (:264-266)
+          {  // Crank-Nicolson diffusion (:191-196): U x = V bs by parallel cyclic reduction
+            const double bl = from_prev_lane_z(bs);
+            const double sh = k4.y;
+            double r = bs;  // rows 0 and ny-1 of V are identity rows
+            if (ml_int) r = sh * bl + k_1ms * bs + sh * bu;
+            if (!ml_act) r = 0.;
+            bs = jf_pcr_solve(r, lds + L::PCR, lane_o, a4);
+          }
+          {
+            const double up = from_next_lane_z(bs);
+            const double v2 = upwell ? bsouth : up;  // final BC re-set (:274)
+            bs = lane0 ? v2 : bs;
+          }
+          q.bs = bs;
+          wl[L::W_PS + lane_o] = ps;
+          ps_valid = true;
+        }
+      }
+    }
+    } else {
+      for (; s < nsteps; ++s) {
+        int lane_o = lane, woff = wave * L::PER_WAVE;
+        asm volatile("" : "+v"(lane_o), "+s"(woff));
+        double *wl = lds + L::WAVE0 + woff, *ws = wl + L::W_S;
+        if (__builtin_expect(!columns_step(lane_o, lane_o & 31, wl, ws, ws + (lane_o >> 5) * S_COL), 0))
+          break;
+      }
+    }
+  }
+
+  // ---- results: slot layout -> level order through LDS -> lane-contiguous stores
+  jf_kargs ka = jf_args();
+  const size_t by = (size_t)m * ny;
+  bool bad = false;
+  {
+    __builtin_amdgcn_wave_barrier();
+    double *dst = wl + (half ? L::W_ST : L::W_BB);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = hl * P + p;
+      if (i < nz) {
+        dst[i] = c.b[p];
+        bad |= !isfinite(c.b[p]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (m_ok && hint_ok) {
+      double *bout = ka->cols.b;
+      if constexpr (VEC) {
+#pragma unroll
+        for (int kk = 0; kk < JS_CH / 2; ++kk) {
+          const int i0 = 128 * kk + 2 * lane;
+          if (i0 < nz) {
+            *reinterpret_cast<double2 *>(bout + (size_t)m * nz + i0) =
+                *reinterpret_cast<const double2 *>(wl + L::W_BB + i0);
+            *reinterpret_cast<double2 *>(bout + (size_t)(n + m) * nz + i0) =
+                *reinterpret_cast<const double2 *>(wl + L::W_ST + i0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < JS_CH; ++k) {
+          const int i = 64 * k + lane;
+          if (i < nz) {
+            bout[(size_t)m * nz + i] = wl[L::W_BB + i];
+            bout[(size_t)(n + m) * nz + i] = wl[L::W_ST + i];
+          }
+        }
+      }
+    }
+  }
+  if (lane < ny) {
+    bad |= !isfinite(q.bs);
+    if (m_ok && hint_ok) {
+      ka->ml.bs[by + lane] = q.bs;
+      double *Psi_s = ka->ml.Psi_s;
+      if (Psi_s && ps_valid) Psi_s[by + lane] = wl[L::W_PS + lane];
+    }
+  }
+  const bool anybad = __ballot(bad) != 0ull;
+  if (hl == 0 && m_ok) {
+    if (hint_ok && s > 0) {  // Column.bbot after the last step = what that step imposed on level 0
+      double *bbot = const_cast<double *>(ka->cols.bbot);
+      int32_t *ksel = const_cast<int32_t *>(ka->cols.ksel);
+      bbot[col] = c.b[0];
+      ksel[col] = half ? ksel_n : ksel_b;
+    }
+    int32_t *nonfinite = ka->cols.nonfinite;
+    if (nonfinite) nonfinite[col] = anybad ? 1 : 0;
+    int32_t *st = ka->ml.status;
+    if (st && lane == 0)
+      st[m] = status | (anybad ? 2 : 0) | (hint_ok ? 0 : 16) | (skipped ? 32 : 0) |
+              (skipped ? (s << 8) : 0);
+  }
+  return s;
+}
+
+template <int P, bool CT, bool VEC>
+__global__ __launch_bounds__(64 * JF_WAVES) JF_OCC_ATTR
+void k_jn2018_split(pm_jn2018 a, double dt, int nsteps) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  js_block_tables<P>(a, dt, lds, wave, lane);
+  js_member_run<P, CT, VEC>(a, dt, nsteps, blockIdx.x * JF_WAVES + wave, lds, wave, lane);
+}
+
+template <int P>
+static void launch_split_kernel(const pm_jn2018 &a, double dt, int nsteps, bool vec, hipStream_t st) {
+  const size_t lds = (size_t)JsLds<P>::TOTAL * sizeof(double);
+  const unsigned grid = (unsigned)((a.n + JF_WAVES - 1) / JF_WAVES);
+  const bool ct = (a.hints & PM_JN_CONTRACTED) != 0;
+#define JS_LAUNCH(CT_, VEC_)                                                                     \
+  hipLaunchKernelGGL((k_jn2018_split<P, CT_, VEC_>), dim3(grid), dim3(64 * JF_WAVES), lds, st, a, \
+                     dt, nsteps)
+  if (ct && vec)
+    JS_LAUNCH(true, true);
+  else if (ct)
+    JS_LAUNCH(true, false);
+  else if (vec)
+    JS_LAUNCH(false, true);
+  else
+    JS_LAUNCH(false, false);
+#undef JS_LAUNCH
+}
+
 template <int P>
 static int launch_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st) {
   const size_t lds = (size_t)JfLds<P>::TOTAL * sizeof(double);
@@ -1022,10 +1835,28 @@ static int launch_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st
   const bool vec = a.cols.nz % P == 0 && al(a.cols.b) && al(a.cols.area) && al(a.cols.kappa) &&
                    al(a.cols.dAkappa) && al(a.wA) && al(a.Psi_SO);
   const bool ct = (a.hints & PM_JN_CONTRACTED) != 0;
+  // round 5: both columns of a member side by side in the wave's two halves (k_jn2018_split).
+  // Opt-in (PM_JN_SPLIT_LANES, or PYMOC_JN_SPLIT=1 for A/B runs): 7 % fewer vector instructions
+  // per launch, measured a tie on config 5; shapes 65..128 and 193..224
+  static const bool env_split = getenv("PYMOC_JN_SPLIT") != nullptr;
+  const int PS = (a.cols.nz + 31) / 32;
+  const bool split = ((a.hints & PM_JN_SPLIT_LANES) || env_split) && (PS == 3 || PS == 4 || PS == 7);
+  if (split) {
+    // 16-byte row accesses: every row starts 16-byte aligned and holds an even number of levels
+    const bool v2 = a.cols.nz % 2 == 0 && al(a.cols.b) && al(a.cols.area) && al(a.cols.kappa) &&
+                    al(a.cols.dAkappa) && al(a.wA) && al(a.Psi_SO);
+    switch (PS) {
+      case 3: launch_split_kernel<3>(a, dt, nsteps, v2, st); break;
+      case 4: launch_split_kernel<4>(a, dt, nsteps, v2, st); break;
+      default: launch_split_kernel<7>(a, dt, nsteps, v2, st); break;
+    }
+  }
 #define JF_LAUNCH(CT_, VEC_)                                                                  \
   hipLaunchKernelGGL((k_jn2018_fast<P, CT_, VEC_>), dim3(grid), dim3(64 * JF_WAVES), lds, st, a, \
                      dt, nsteps)
-  if (ct && vec)
+  if (split)
+    ;
+  else if (ct && vec)
     JF_LAUNCH(true, true);
   else if (ct)
     JF_LAUNCH(true, false);

@@ -369,7 +369,8 @@ class JN2018Ensemble(object):
 
   def __init__(self, cfg, stream=None, lanes_per_col=0, use_graph=False, fused=None,
                comm=None, n_total=None, diag_iters=None, keep_history=False, arith="exact",
-               shared_coef=True, fused_run=None, gather="all", gather_overlap=True):
+               shared_coef=True, fused_run=None, gather="all", gather_overlap=True,
+               split_lanes=False):
     """`fused_run`: whole stretches of the loop -- many [PsiSO.solve, AMOC.solve / Psibz,
     MOC_up_iters steps] intervals -- in ONE launch of the persistent per-member kernel
     (pm_jn2018_run), ending a launch only where diagnostics are sampled or gathered;
@@ -382,11 +383,14 @@ class JN2018Ensemble(object):
     (PM_JN_CONTRACTED; uniform-Area ensembles with ny <= 64 -- others stay exact).
     `shared_coef`: let the fused loop read ONE copy of kappa / d(A kappa)/dz / Area per column
     kind when all members' profiles are identical (checked here on the host arrays;
-    PM_JN_SHARED_COEF); results are bit-identical either way."""
+    PM_JN_SHARED_COEF); results are bit-identical either way.
+    `split_lanes`: the fused loop steps both columns of a member together, one per half of the
+    wavefront (PM_JN_SPLIT_LANES; bit-identical; measured a tie on config 5, hence opt-in)."""
     if arith not in ("exact", "contracted"):
       raise ValueError("arith must be 'exact' or 'contracted'")
     self.arith = arith
     self.shared_coef = bool(shared_coef)
+    self.split_lanes = bool(split_lanes)
     import ctypes as C
     from ._lib import pm_jn2018_bc
     z, y = cfg['z'], cfg['y']
@@ -508,6 +512,8 @@ class JN2018Ensemble(object):
       d.hints |= _lib.PM_JN_CONTRACTED
     if self.shared_coef and self.cols.uniform_area and self.cols.shared_halves:
       d.hints |= _lib.PM_JN_SHARED_COEF
+    if self.split_lanes:
+      d.hints |= _lib.PM_JN_SPLIT_LANES
     d.cols = self.cols.descriptor()
     d.wA, d.Psi_SO = self.wA.ptr, self.so.Psi.ptr
     d.Psi_res_b, d.Psi_res_n = self.tw.psibz1.ptr, self.tw.psibz2.ptr

@@ -226,6 +226,32 @@ def test_jn2018_fused_equals_stepwise_other_shapes(gpu, nz, ny):
     assert np.array_equal(sa[k][ok], sb[k][ok]), (nz, ny, k)
 
 
+@pytest.mark.parametrize("nz,dtd,arith", [(200, 10., "exact"), (199, 10., "exact"), (81, 30., "exact"),
+                                          (100, 30., "exact"), (200, 10., "contracted")])
+def test_jn2018_split_lane_layout_bitwise(gpu, nz, dtd, arith):
+  """PM_JN_SPLIT_LANES (round 5, opt-in): both columns of a member stepping together, one per
+  half of the wavefront (ceil(nz/32) levels per lane; rows moved through LDS, 16-byte accesses
+  for even nz, 8-byte for odd).  Same arithmetic per level: bit-identical to the default fused
+  kernel at every split of a run, lost members included, and so are bbot / ksel / Psi_s."""
+  c = configs.config5(N=96, nz=nz, dt_days=dtd)
+  c["rest_mask"] = np.repeat(c["rest_mask"][None], 96, axis=0)
+  a = gpu.JN2018Ensemble(c, arith=arith, split_lanes=True)
+  b = gpu.JN2018Ensemble(c, arith=arith)
+  for n in (1, 35, 36, 37, 150):
+    a.run(n)
+    b.run(n)
+    sa, sb = a.state(), b.state()
+    assert np.array_equal(a.nonfinite_members(), b.nonfinite_members())
+    ok = np.ones(96, dtype=bool)
+    ok[b.nonfinite_members()] = False
+    for k in sa:
+      assert np.array_equal(sa[k][ok], sb[k][ok]), (n, k)
+    ok2 = np.concatenate([ok, ok])
+    assert np.array_equal(a.cols.bbot.download()[ok2], b.cols.bbot.download()[ok2])
+    assert np.array_equal(a.cols.ksel.download()[ok2], b.cols.ksel.download()[ok2])
+    assert np.array_equal(a.ml.status.download(), b.ml.status.download())
+
+
 @pytest.mark.parametrize("arith", ["exact", "contracted"])
 def test_jn2018_fused_shared_coefficient_rows(gpu, arith):
   """PM_JN_SHARED_COEF: when every member carries the same kappa / Area profiles the fused loop
