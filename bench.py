@@ -222,7 +222,7 @@ WORKLOAD_SHORT = {
 def profile_counters():
   """SQ / TCC counters of separate rocprofv3 --pmc passes, replayed (never measured in a bench
   run): the newest profiles/rNN/counters.json."""
-  for r in ("r04", "r03"):
+  for r in ("r05", "r04", "r03"):
     d = load_json(os.path.join(ROOT, "profiles", r, "counters.json"))
     if d:
       return d, r
@@ -332,6 +332,14 @@ def bench_config2(args, env):
     ms1 = time_calls(lambda: batch.steps(wA, dt, 1, lanes_per_col=args.lanes), 2000, stream,
                      Event, warm=200)
     out["single_step_us"] = sig(ms1 * 1e3)
+    # the same one-step launches replayed from a captured hipGraph of 64 nodes (one host call per
+    # 64 steps): the device-side cost of a kernel boundary, without the host's launch path
+    from pymoc_amd.device import Graph
+    with Graph.capture(stream) as cap:
+      for _ in range(64):
+        batch.steps(wA, dt, 1, lanes_per_col=args.lanes)
+    msg = time_calls(lambda: cap.graph.launch(stream), 40, stream, Event, warm=5)
+    out["single_step_graph_us"] = sig(msg * 1e3 / 64)
   if not args.no_single_step and world == 1 and C == 1024 and nz == 100:
     # the SAME kernel where HBM does bind: one step per launch on an ensemble far beyond the
     # caches (262144 columns: 0.84 ... 1.26 GB cross HBM per launch)
@@ -416,7 +424,7 @@ KERNEL_MODELS = {
 }
 
 
-def kernel_breakdown(config, env, members, nsteps, warm_blocks, **kw):
+def kernel_breakdown(config, env, members, nsteps, warm_blocks, overlap=False, **kw):
   """Run-average duration of every kernel of a coupled config: a fresh ensemble, `warm_blocks`
   untimed MOC intervals, then the full run with HIP events around EVERY launch (LaunchTimer).  Returns
   ({kernel: [launches, avg us]}, roofline of the kernel with the largest total)."""
@@ -425,7 +433,7 @@ def kernel_breakdown(config, env, members, nsteps, warm_blocks, **kw):
   # driver runs them, each is stretched by the other and neither duration is the kernel's own;
   # likewise the two-basin update's two pairs)
   if config in (4, 6):
-    kw = dict(kw, overlap_updates=False)
+    kw = dict(kw, overlap_updates=bool(overlap))
   cfg, ens = make_ensemble(config, env, members, **kw)
   ens.run(warm_blocks * ens.M)
   env["stream"].sync()
@@ -615,6 +623,13 @@ def main():
                        "(the writer; what the reference's output cadence needs)")
   ap.add_argument("--gather-inline", action="store_true",
                   help="run the exchange on the compute stream (round 4's behaviour; A/B)")
+  ap.add_argument("--breakdown-only", action="store_true",
+                  help="coupled config: only the full-length run with HIP events around every "
+                       "launch that the default line's c<N> block takes its kernel averages and "
+                       "roofline from (what profiles/collect_r05.sh traces)")
+  ap.add_argument("--overlap", action="store_true",
+                  help="with --breakdown-only, configs 4 / 6: the update's launches side by side "
+                       "on two streams, as the drivers run them (default there: one after the other)")
   ap.add_argument("--force-rccl", action="store_true",
                   help="use the RCCL communicator even with one rank (plumbing check)")
   args = ap.parse_args()
@@ -658,6 +673,15 @@ def main():
              make_gather=lambda cm, n, ntot, fields, st, mode, overlap: sharding.DiagnosticGather(
                  cm, n, ntot, fields, stream=st, mode=mode, overlap=overlap))
 
+  if args.breakdown_only and args.config != 2:
+    c = args.config
+    n = args.members or SIZES[c]["members"]
+    kern, roof = kernel_breakdown(c, env, n, SIZES[c]["nsteps"], 10, overlap=args.overlap)
+    print(json.dumps({"config": c, "members": n, "steps": SIZES[c]["nsteps"],
+                      "overlap": bool(args.overlap), "kernels": kern, "roofline": roof},
+                     separators=(",", ":")), flush=True)
+    comm.close()
+    return
   if args.config == 2:
     out = bench_config2(args, env)
     blocks = {}

@@ -13,7 +13,9 @@ import os
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpymoc_hip.so")
+# PYMOC_HIP_LIB: another build of the same sources (the phase-clock build of profiles/, an A/B
+# variant); the product loads the library next to this file
+LIB_PATH = os.environ.get("PYMOC_HIP_LIB") or os.path.join(_HERE, "libpymoc_hip.so")
 
 PM_OK, PM_EINVAL, PM_EHIP, PM_ENCCL, PM_ENODEV = 0, 1, 2, 3, 4
 

@@ -691,7 +691,10 @@ __device__ __forceinline__ int jf_member_run(const pm_jn2018 &a, double dt, int 
       // rotated by step number most SIMDs even out, but a wave that falls behind stays behind
       // (one wave in ~15 blocks ended 25 us after its mates).  So each wave publishes its step
       // counter and takes its priority from its rank: the one furthest behind issues first.
-      {
+#ifndef JF_PRIO_EVERY
+#define JF_PRIO_EVERY 1
+#endif
+      if (JF_PRIO_EVERY == 1 || (s & (JF_PRIO_EVERY - 1)) == 0) {
         int *prog = reinterpret_cast<int *>(lds + L::PROG) + (wave & 3) * 4;
         const int sg = s0 + s;  // steps behind this wave (over all launches of a persistent run)
         prog[wave >> 2] = sg;

@@ -407,7 +407,9 @@ def test_config5_teacher_forced_windows_vs_reference(gpu, arith):
   print("config 5, %s: %d of %d teacher-forced windows take another bottom-cell branch than the "
         "reference %s; worst clean window %.2e, worst flip window %.2e" %
         (arith, len(flips), len(rows), flips[:8], wc, wf))
-  assert len(flips) <= len(rows) // 4, flips
+  # measured (profiles/r05/c5_windows.log): exact 0 of 400 (worst clean window 3.6e-14 -- as close
+  # as the oracle's 6e-14), contracted 8 of 400 (worst flip window 1.1e-4); bound = that + margin
+  assert len(flips) <= (2 if arith == "exact" else 24), flips
 
 
 def test_config5_blowup_members_go_at_the_references_step(gpu):
