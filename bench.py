@@ -439,14 +439,15 @@ def kernel_breakdown(config, env, members, nsteps, warm_blocks, overlap=False, *
   env["stream"].sync()
   ens.timer = LaunchTimer()
   ens.run(nsteps)
-  summ = ens.timer.summary()
+  summ = ens.timer.summary(env["stream"])
+  null_us = sig(1e3 * ens.timer.null_ms, 3)
   ens.timer = None
   kern = {k: [n, sig(1e3 * t / n, 4)] for k, (n, t) in summ.items()}
   dom = max((k for k in summ if k != "k_column_steps_short"), key=lambda k: summ[k][1])
   us = 1e3 * summ[dom][1] / summ[dom][0]
   n, nz, M, nb, ny = ens.n, ens.nz, ens.M, ens.nb, getattr(ens, "ny", 0)
   roof = {"bound": "fp64-valu", "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "kernel": dom,
-          "kernel_us": sig(us, 4), "traffic": None}
+          "kernel_us": sig(us, 4), "traffic": None, "event_null_us": null_us}
   prof, prof_round = profile_counters()
   cnt = None
   for kk, vv in prof.items():

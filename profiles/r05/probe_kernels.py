@@ -31,5 +31,5 @@ for c in (args or ["5"]):
     t0 = time.perf_counter(); e.run(steps); st.sync(); dt = time.perf_counter() - t0
     e.timer = LaunchTimer(); e.run(steps)
     print("config", c, arith, "%.4g coupled steps/s" % (e.n * steps / dt),
-          {k: (n, round(1e3 * t / n, 2)) for k, (n, t) in e.timer.summary().items()}, flush=True)
+          {k: (n, round(1e3 * t / n, 2)) for k, (n, t) in e.timer.summary(st).items()}, "null span %.2f us" % (1e3 * e.timer.null_ms), flush=True)
     del e
