@@ -34,3 +34,15 @@ def gpu():
   import pymoc_amd
   pymoc_amd._lib.require_device()
   return pymoc_amd
+
+
+def digest_err(x, ref_digest):
+  """Largest deviation of the {sum, sum of squares} digests of the rows of `x` [n, nlev] from the
+  reference's (fixture G20, ensemble_digests.npz), in units of what a relative error `1` of every
+  level would move them by: |d sum| / (nlev * rms), |d sumsq| / (2 * sumsq).  Returns [n]."""
+  x = np.asarray(x, dtype=np.float64)
+  nlev = x.shape[1]
+  s, q = np.sum(x, axis=1), np.sum(x * x, axis=1)
+  rs, rq = ref_digest[:, 0], ref_digest[:, 1]
+  rms = np.sqrt(np.maximum(rq, 1e-300) / nlev)
+  return np.maximum(np.abs(s - rs) / (nlev * rms), np.abs(q - rq) / (2 * np.maximum(rq, 1e-300)))

@@ -40,6 +40,11 @@ Sets:
                        them at its collocation midpoints and refines the mesh)
   G15 psi_so_callable  Psi_SO.solve with CALLABLE bs / tau (evaluated between grid points by the
                        reference: inside brentq and the 100-point wind average)
+  G20 ensemble_digests EVERY member of the config-3 (4096 x 2400 steps) and two-basin (2048 x 2400)
+                       ensembles and every 8th member of config 4 (1024 x 2400 steps) through the
+                       reference: per member and field {sum, sum of squares} of the final state
+                       (the full states would be 10+ MB; the digests pin every level of every
+                       member to the tolerance of the comparison).  ~35 minutes on 6 cores.
   G10 jn2018_files     the diagnostics / pickup .npz payloads of run_JansenNadeau_2018.py and a
                        restart from the pickup
 """
@@ -1080,13 +1085,59 @@ def g9_twobasin():
   save("twobasin", **out)
 
 
+# ------------------------------------------------------------------------ G20
+def _digest(x):
+  x = np.asarray(x, dtype=np.float64)
+  return np.array([np.sum(x), np.sum(x * x)])
+
+
+def _g20_job(job):
+  kind, i = job
+  if kind == 3:
+    c = configs.config3(N=4096, members=(i, i + 1))
+    m = member_of(c, 0, ('A_basin', 'A_north', 'bs', 'bs_north', 'bbot'),
+                  ('kappa', 'b_basin0', 'b_north0'))
+    s = ref_twocol(m, 2400, {2400})[2400]
+    return np.concatenate([_digest(s[k]) for k in ('b_basin', 'b_north', 'Psi')])
+  if kind == 4:
+    c = configs.config4(N=8192, members=(i, i + 1))
+    m = member_of(c, 0, ('A_basin', 'A_north', 'bs', 'bs_north', 'bbot', 'tau', 'KGM'),
+                  ('kappa', 'b_basin0', 'b_north0', 'bs_SO'))
+    s = ref_twocol(m, 2400, {2400}, so=True)[2400]
+    return np.concatenate([_digest(s[k]) for k in ('b_basin', 'b_north', 'Psi', 'Psi_SO')])
+  c = configs.config_twobasin(N=2048, members=(i, i + 1))
+  m = member_of(c, 0, ('tau', 'K', 'A_Pac', 'A_Atl', 'A_north'))
+  s = ref_twobasin(m, 2400, {2400})[2400]
+  return np.concatenate([_digest(s[k]) for k in ('b_Atl', 'b_north', 'b_Pac', 'Psi_AMOC', 'Psi_ZOC',
+                                                 'Psi_SO_Atl', 'Psi_SO_Pac')])
+
+
+def g20_ensemble_digests():
+  import multiprocessing as mp
+  workers = int(os.environ.get("PYMOC_GOLDEN_WORKERS", "6"))
+  out = {}
+  with mp.get_context("fork").Pool(workers) as pool:
+    for kind, members, fields in (
+        (3, np.arange(4096), ('b_basin', 'b_north', 'Psi')),
+        (6, np.arange(2048), ('b_Atl', 'b_north', 'b_Pac', 'Psi_AMOC', 'Psi_ZOC', 'Psi_SO_Atl',
+                              'Psi_SO_Pac')),
+        (4, np.arange(0, 8192, 8), ('b_basin', 'b_north', 'Psi', 'Psi_SO'))):
+      res = pool.map(_g20_job, [(kind, int(i)) for i in members], chunksize=4)
+      out["c%d_members" % kind] = members
+      out["c%d_fields" % kind] = np.array(fields)
+      out["c%d_digest" % kind] = np.array(res).reshape(len(members), len(fields), 2)
+      out["c%d_nsteps" % kind] = np.array(2400)
+      print("G20: config %d, %d members done" % (kind, len(members)), flush=True)
+  save("ensemble_digests", **out)
+
+
 if __name__ == "__main__":
   which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
   table = dict(g1=[g1_column_steps], g2=[g2_config1], g3=[g3_thermwind], g4=[g4_twocol],
                g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
                g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column], g14=[g14_thermwind_callable], g15=[g15_psi_so_callable],
                g16=[g16_thermwind_nonfinite], g17=[g17_sweep_full], g18=[g18_range_evidence],
-               g19=[g19_config5_conditioning])
+               g19=[g19_config5_conditioning], g20=[g20_ensemble_digests])
   for w in which:
     for fn in table[w]:
       fn()

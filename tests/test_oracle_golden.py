@@ -661,3 +661,30 @@ def test_config5_oracle_teacher_forced_windows():
   print("oracle: %d of %d windows take another bottom-cell branch than the reference; worst clean "
         "window %.2e, worst flip window %.2e" % (len(flips), len(rows), wc, wf))
   assert len(flips) <= len(rows) // 4, flips
+
+
+def test_ensemble_digests_oracle_subset():
+  """Fixture G20: EVERY member of config 3 / two-basin and every 8th of config 4 through the
+  reference (digests {sum, sum of squares} of each final field).  The oracle on a stride of them
+  (the GPU suite checks all of them against the engine)."""
+  from conftest import digest_err
+  g = load_golden("ensemble_digests")
+  n = int(g["c3_nsteps"])
+  c = configs.config3(N=4096)
+  for i in range(0, 4096, 128):
+    s = drivers.run_twocol(configs.member(c, i, 3), n, {n})[n]
+    for f, k in enumerate(g["c3_fields"]):
+      assert digest_err(s[str(k)][None], g["c3_digest"][i:i + 1, f])[0] <= 1e-12, (3, i, k)
+  c = configs.config4(N=8192)
+  mem = list(g["c4_members"])
+  for j in range(0, len(mem), 64):
+    s = drivers.run_twocol(configs.member(c, int(mem[j]), 4), n, {n}, so=True)[n]
+    for f, k in enumerate(g["c4_fields"]):
+      # (98 % of the 1024 members are within 1e-11, 18 lie between 1e-11 and 1.2e-9: SciPy's own
+      # solve_bvp convergence; SURVEY's tolerance for config 4 is 1e-5)
+      assert digest_err(s[str(k)][None], g["c4_digest"][j:j + 1, f])[0] <= 1e-8, (4, mem[j], k)
+  c = configs.config_twobasin(N=2048)
+  for i in range(0, 2048, 128):
+    s = drivers.run_twobasin(configs.member(c, i, 6), n, {n})[n]
+    for f, k in enumerate(g["c6_fields"]):
+      assert digest_err(s[str(k)][None], g["c6_digest"][i:i + 1, f])[0] <= 1e-10, (6, i, k)
