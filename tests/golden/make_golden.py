@@ -45,6 +45,9 @@ Sets:
                        reference: per member and field {sum, sum of squares} of the final state
                        (the full states would be 10+ MB; the digests pin every level of every
                        member to the tolerance of the comparison).  ~35 minutes on 6 cores.
+  G21 c5_ensemble_digests  EVERY member of config 5 (4096, nz = 200) through the reference for 72 and
+                       360 steps (2 and 10 MOC intervals): {sum, sum of squares} of b_basin, b_north,
+                       bs_SO, Psi_SO per member at both steps; non-finite members keep NaN digests
   G10 jn2018_files     the diagnostics / pickup .npz payloads of run_JansenNadeau_2018.py and a
                        restart from the pickup
 """
@@ -1112,6 +1115,28 @@ def _g20_job(job):
                                                  'Psi_SO_Atl', 'Psi_SO_Pac')])
 
 
+def _g21_job(i):
+  c = configs.config5(N=4096, members=(i, i + 1))
+  m = member_of(c, 0, ('bs', 'bs_north', 'KGM', 'tau'),
+                ('surflux', 'b_rest', 'bs_SO_init', 'bs_SO0', 'b_basin0', 'b_north0'))
+  s = ref_jn2018(m, 360, {72, 360}, catch=True)
+  out = np.full((2, 4, 2), np.nan)
+  for a, t in enumerate((72, 360)):
+    if t in s:
+      for f, k in enumerate(('b_basin', 'b_north', 'bs_SO', 'Psi_SO')):
+        out[a, f] = _digest(s[t][k])
+  return out
+
+
+def g21_config5_digests():
+  import multiprocessing as mp
+  workers = int(os.environ.get("PYMOC_GOLDEN_WORKERS", "6"))
+  with mp.get_context("fork").Pool(workers) as pool:
+    res = np.array(pool.map(_g21_job, range(4096), chunksize=8))
+  save("c5_ensemble_digests", steps=np.array([72, 360]),
+       fields=np.array(['b_basin', 'b_north', 'bs_SO', 'Psi_SO']), digest=res)
+
+
 def g20_ensemble_digests():
   import multiprocessing as mp
   workers = int(os.environ.get("PYMOC_GOLDEN_WORKERS", "6"))
@@ -1137,7 +1162,8 @@ if __name__ == "__main__":
                g5=[g5_psi_so], g6=[g6_twocol_so], g7=[g7_so_ml, g7_jn2018],
                g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column], g14=[g14_thermwind_callable], g15=[g15_psi_so_callable],
                g16=[g16_thermwind_nonfinite], g17=[g17_sweep_full], g18=[g18_range_evidence],
-               g19=[g19_config5_conditioning], g20=[g20_ensemble_digests])
+               g19=[g19_config5_conditioning], g20=[g20_ensemble_digests],
+               g21=[g21_config5_digests])
   for w in which:
     for fn in table[w]:
       fn()

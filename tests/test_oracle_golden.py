@@ -688,3 +688,18 @@ def test_ensemble_digests_oracle_subset():
     s = drivers.run_twobasin(configs.member(c, i, 6), n, {n})[n]
     for f, k in enumerate(g["c6_fields"]):
       assert digest_err(s[str(k)][None], g["c6_digest"][i:i + 1, f])[0] <= 1e-10, (6, i, k)
+
+
+def test_config5_ensemble_digests_oracle_subset():
+  """Fixture G21: all 4096 config-5 members through the reference for 72 / 360 steps (digests).
+  The oracle on every 64th member at step 72 (no bottom-cell flip can have acted yet)."""
+  from conftest import digest_err
+  g = load_golden("c5_ensemble_digests")
+  c = configs.config5(N=4096)
+  assert [int(t) for t in g["steps"]] == [72, 360]
+  lost = np.nonzero(~np.isfinite(g["digest"][:, 0]).all(axis=(1, 2)))[0]
+  assert list(lost) == [2, 1268]  # (the members the reference itself loses at step 37)
+  for i in range(0, 4096, 64):
+    s = drivers.run_jn2018(configs.member(c, i, 5), 72, {72})[72]
+    for f, k in enumerate(g["fields"]):
+      assert digest_err(s[str(k)][None], g["digest"][i:i + 1, 0, f])[0] <= 1e-10, (i, str(k))
