@@ -48,6 +48,10 @@ Sets:
   G21 c5_ensemble_digests  EVERY member of config 5 (4096, nz = 200) through the reference for 72 and
                        360 steps (2 and 10 MOC intervals): {sum, sum of squares} of b_basin, b_north,
                        bs_SO, Psi_SO per member at both steps; non-finite members keep NaN digests
+  G22 c2_ensemble_digests  EVERY column of config 2 (1024 x 1000 steps of Column.timestep with its static wA)
+                       through the reference: {sum, sum of squares} of the final b per column (the
+                       headline configuration; K1 is bit-identical to NumPy, so the digests -- NumPy
+                       sums of identical arrays -- must match EXACTLY)
   G10 jn2018_files     the diagnostics / pickup .npz payloads of run_JansenNadeau_2018.py and a
                        restart from the pickup
 """
@@ -1137,6 +1141,24 @@ def g21_config5_digests():
        fields=np.array(['b_basin', 'b_north', 'bs_SO', 'Psi_SO']), digest=res)
 
 
+def _g22_job(i):
+  c2 = configs.config2(N=1024, members=(i, i + 1))
+  col = Column(z=c2['z'], kappa=c2['kappa'][0].copy(), Area=c2['Area'][0].copy(),
+               b=c2['b0'][0].copy(), bs=float(c2['bs'][0]), bbot=float(c2['bbot'][0]),
+               N2min=float(c2['N2min'][0]))
+  for _ in range(1000):
+    col.timestep(wA=c2['wA'][0], dt=c2['dt'], do_conv=bool(c2['do_conv'][0]))
+  return _digest(col.b)
+
+
+def g22_config2_digests():
+  import multiprocessing as mp
+  workers = int(os.environ.get("PYMOC_GOLDEN_WORKERS", "6"))
+  with mp.get_context("fork").Pool(workers) as pool:
+    res = np.array(pool.map(_g22_job, range(1024), chunksize=8))
+  save("c2_ensemble_digests", nsteps=np.array(1000), digest=res)
+
+
 def g20_ensemble_digests():
   import multiprocessing as mp
   workers = int(os.environ.get("PYMOC_GOLDEN_WORKERS", "6"))
@@ -1163,7 +1185,7 @@ if __name__ == "__main__":
                g8=[g8_sweep], g9=[g9_twobasin], g10=[g10_jn2018_files], g11=[g11_single_basin], g12=[g12_equi], g13=[g13_equi_column], g14=[g14_thermwind_callable], g15=[g15_psi_so_callable],
                g16=[g16_thermwind_nonfinite], g17=[g17_sweep_full], g18=[g18_range_evidence],
                g19=[g19_config5_conditioning], g20=[g20_ensemble_digests],
-               g21=[g21_config5_digests])
+               g21=[g21_config5_digests], g22=[g22_config2_digests])
   for w in which:
     for fn in table[w]:
       fn()

@@ -521,3 +521,18 @@ def test_affine_kappa_hint_bitwise(gpu, nsteps, precombined):
   with pytest.raises(ValueError):
     gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"],
                     kappa_affine=(c["kappa_back"] * (1 + 2.0**-52), c["kappa_profile"]), **kw)
+
+
+def test_config2_every_column_vs_reference_digests_exact(gpu):
+  """Fixture G22 (round 5): all 1024 columns of BASELINE's headline configuration went through
+  the REFERENCE for the full 1000 steps; the fixture holds NumPy's {sum, sum of squares} of each
+  final profile.  The engine's 1000 fused steps give exactly those numbers for every column --
+  the bit-identity claim on the whole headline workload, not on 16 of its columns."""
+  g = load_golden("c2_ensemble_digests")
+  c = configs.config2(N=1024)
+  batch = gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"], bs=c["bs"], bbot=c["bbot"],
+                          N2min=c["N2min"], do_conv=c["do_conv"])
+  batch.steps(c["wA"], c["dt"], int(g["nsteps"]))
+  b = batch.get_b()
+  d = np.stack([np.array([np.sum(r), np.sum(r * r)]) for r in b])
+  assert np.array_equal(d, g["digest"])

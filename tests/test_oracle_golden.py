@@ -703,3 +703,15 @@ def test_config5_ensemble_digests_oracle_subset():
     s = drivers.run_jn2018(configs.member(c, i, 5), 72, {72})[72]
     for f, k in enumerate(g["fields"]):
       assert digest_err(s[str(k)][None], g["digest"][i:i + 1, 0, f])[0] <= 1e-10, (i, str(k))
+
+
+def test_config2_every_column_digest_exact():
+  """Fixture G22: all 1024 columns of the headline configuration through the reference for the
+  full 1000 steps.  The oracle's final state gives EXACTLY the reference's {sum, sum of squares}
+  (NumPy sums of bit-identical arrays)."""
+  g = load_golden("c2_ensemble_digests")
+  c = configs.config2(N=1024)
+  b = O.column_ensemble_steps(c["z"], c["kappa"], c["Area"], c["b0"], c["wA"], c["dt"],
+                              c["do_conv"], c["bs"], c["bbot"], c["N2min"], int(g["nsteps"]))
+  d = np.stack([np.array([np.sum(r), np.sum(r * r)]) for r in b])
+  assert np.array_equal(d, g["digest"])
