@@ -137,8 +137,9 @@ __host__ __device__ inline bool tw_overlay(int nz, int nb, int W = 6) {
 }
 // LDS doubles per wave: cells, the psib row unless overlaid, two group-range rows; even, so
 // that every wave's cells stay 16-byte aligned
+__host__ __device__ inline int tw_pad_cells(int nz, int W);
 __host__ __device__ inline int tw_lds_doubles(int nz, int nb, int W = 6) {
-  return (W * nz + (tw_overlay(nz, nb, W) ? 0 : nb) + 2 * ((nz + 7) / 8) + 1) & ~1;
+  return (W * (nz + tw_pad_cells(nz, W)) + (tw_overlay(nz, nb, W) ? 0 : nb) + 2 * ((nz + 7) / 8) + 1) & ~1;
 }
 // RN(fma(r, yh, q)) clamped to [0, 1] by the VOP3 clamp modifier (the last Markstein step and
 // np.clip in one instruction; finite operands only)
@@ -338,6 +339,156 @@ __device__ __forceinline__ void psib_pairwise(const CV &cells, int k0, int n,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 5: the class sums of a member whose cells lie in CHAIN ORDER, class by class.
+//
+// The tiles above evaluate every (cell, class) pair of a group that the pass's class range
+// cuts: 8 x 128 quotients where a class value g cuts ONE cell.  Along BASELINE's runs the
+// upstream cells (bot_k, top_k) of psi_thermwind.py:175-181 are in chain order -- top_k <=
+// bot_{k+1}, every thickness > 0 -- in every update of configs 3 and 6, 95 % of config 4's and,
+// from cell K0 <= 2 on (the bottom cells of a no-flux bottom boundary are degenerate or
+// inverted), in every update of config 5 (profiles/r05/probe_psib_structure.py).  For such a
+// member a class value g has
+//   mask exactly 0 on the cells below the cut cell kz = first k >= K0 with top_k > g
+//       (top_k <= g: fl(top - g) <= 0, the quotient is clipped to 0),
+//   the quotient of psi_thermwind.py:183 on cell kz itself (1 exactly when g <= bot_kz),
+//   mask exactly 1 on every cell above it (g < top_kz <= bot_k: the tiles' all-ones argument),
+// so NumPy's pairwise sum of mask * udydz -- 8 accumulators over the cells k = a (mod 8) of a
+// block of <= 128 cells, a tree, the tail one by one -- only ever holds, per accumulator,
+//   S[k_a] = ((u[k_a] + u[k_a + 8]) + u[k_a + 16]) + ...   (k_a: its first cell above the cut;
+//            zeros added before the first non-zero term change nothing), a table per MEMBER, or
+//   ((term(kz) + u[kz + 8]) + u[kz + 16]) + ...             on the cut cell's own accumulator.
+// Per class: a search for kz, ONE quotient, a chain of <= 11 additions, 8 table reads, the tree
+// and the tail -- instead of 7 instructions for each of ~1500 (cell, class) pairs of a first
+// pass.  Every partial sum is the one NumPy forms (x + 0 = x), so psib stays bit-identical.
+// Cells below K0 <= 2 are taken as they come: a pass whose classes can see them evaluates their
+// accumulators cell by cell with the tiles' own term (psib_cell_terms).  Any other member (a
+// cell out of order further up, non-finite values, nz - 1 > 256) keeps the tiles.
+//
+// Layout: S[k] takes the sixth slot of cell k (the tiles' group ranges have been formed by
+// then); cell nc = nz - 1, which no level owns, is the SENTINEL {top = +inf, u = -0.0, S = 0}: a
+// search may probe it, a chain may add it (x + -0.0 = x for every x), and the cells from the
+// last block's first tail cell on (tw_pad_cells() more than the array had) form a row of zero S
+// for accumulators that have no cell left.
+__host__ __device__ inline int tw_sorted_blocks(int nc) { return nc <= 128 ? 1 : (nc <= 256 ? 2 : 0); }
+__host__ __device__ inline int tw_block_split(int nc) {  // NumPy's split of 128 < nc <= 256 cells
+  int n2 = nc / 2;
+  return n2 - n2 % 8;
+}
+// first cell of the row of zero S (the last block's first tail cell)
+__host__ __device__ inline int tw_zero_row(int nc) {
+  const int k0 = tw_sorted_blocks(nc) == 2 ? tw_block_split(nc) : 0;
+  return k0 + (((nc - k0) >> 3) << 3);
+}
+// cells the array needs beyond its nz so that the zero row is 8 cells long
+__host__ __device__ inline int tw_pad_cells(int nz, int W) {
+  const int nc = nz - 1;
+  if (W != 6 || nc < 16 || tw_sorted_blocks(nc) == 0) return 0;
+  const int over = tw_zero_row(nc) + 8 - nz;
+  return over > 0 ? over : 0;
+}
+
+__device__ __forceinline__ double psib_term1(const PsibCell &c, double g) {
+  const double tt = c.top - g;  // psib_regular_terms for one class
+  double rr = tt * c.yl;
+  const double q = __builtin_fma(tt, c.yh, rr);
+  rr = __builtin_fma(-c.d, q, tt);
+  return fma_clamp01(rr, c.yh, q) * c.u;
+}
+
+// One pass (TW_JT classes per lane, ascending with the lane) over a member in chain order.
+// cell: the W = 6 cells; klo: a cell index no class of the pass cuts below (K0, or the cut of
+// the previous pass's last class); exc: bit e set = cell e < K0 may carry a non-zero term for a
+// class of this pass; kz (out): the cut cells.
+template <int NBLK>
+__device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int klo, unsigned exc,
+                                                 const double (&bg)[TW_JT], double (&res)[TW_JT],
+                                                 int (&kz)[TW_JT]) {
+  const CellView<6> cv{cell, nc + 1};
+  const int SENT = nc, ZROW = tw_zero_row(nc);
+  {  // the cut cell: first k in [klo, nc] with top_k > g (the sentinel's top is +inf)
+    int lo[TW_JT], hi[TW_JT];
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) {
+      lo[j] = klo;
+      hi[j] = nc;
+    }
+    for (int span = nc - klo; span > 0; span >>= 1) {
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) {
+        const int mid = (lo[j] + hi[j]) >> 1;
+        const bool gt = cell[(size_t)mid * 6] > bg[j];
+        hi[j] = gt ? mid : hi[j];
+        lo[j] = gt ? lo[j] : mid + 1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) kz[j] = lo[j];
+  }
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const int n2 = NBLK == 2 ? tw_block_split(nc) : 0;
+    const int k0 = b == 0 ? 0 : n2, n = NBLK == 1 ? nc : (b == 0 ? n2 : nc - n2);
+    const int ng = n >> 3, full = k0 + 8 * ng;
+    double r[8][TW_JT], v[TW_JT];
+    int kst[TW_JT], astar[TW_JT];
+    bool cut[TW_JT];
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) {
+      kst[j] = kz[j] > k0 ? kz[j] : k0;  // the block's first cell that is not below the cut
+      cut[j] = kz[j] >= k0 && kz[j] < full;
+      v[j] = psib_term1(cv.load(cut[j] ? kz[j] : SENT), bg[j]);
+      astar[j] = cut[j] ? (kst[j] & 7) : 8;
+    }
+    // the cut cell's accumulator: its term, then the cells above it, one by one
+    const int kfirst = klo > k0 ? klo : k0;
+    for (int t = 1; t <= ((full - 1 - kfirst) >> 3); ++t) {
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) {
+        const int kk = kz[j] + 8 * t;
+        v[j] += cv.u((cut[j] && kk < full) ? kk : SENT);
+      }
+    }
+    // the other accumulators: S of their first cell at or above kst
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) {
+      const int base8 = kst[j] & ~7, a0 = kst[j] & 7;
+      const int rlo = base8 < full ? base8 : ZROW, rhi = base8 + 8 < full ? base8 + 8 : ZROW;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int row = a < a0 ? rhi : rlo;
+        const double s = cell[(size_t)(row + a) * 6 + 5];
+        r[a][j] = (a == astar[j]) ? v[j] : s;
+      }
+    }
+    if (b == 0 && exc != 0u) {  // wave-uniform: cells below K0 that this pass's classes can see
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if ((exc >> e) & 1u) {
+          double term[TW_JT];
+          for (int t = 0; t < ng; ++t) {
+            psib_cell_terms(cv.load(e + 8 * t), bg, term);
+#pragma unroll
+            for (int j = 0; j < TW_JT; ++j) r[e][j] = (t == 0) ? term[j] : r[e][j] + term[j];
+          }
+        }
+      }
+    }
+    double rb[TW_JT];
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j)
+      rb[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) + ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
+    for (int k = full; k < k0 + n; ++k) {  // NumPy's tail, as the tiles take it
+      double term[TW_JT];
+      psib_cell_terms(cv.load(k), bg, term);
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) rb[j] += term[j];
+    }
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) res[j] = (b == 0) ? rb[j] : res[j] + rb[j];
+  }
+}
+
 // Exclusive running sum of a sequence held in registers (element i = lane i / P, slot i % P;
 // the caller zeroes the slots of elements that do not count): pre[p] <- d_0 + ... + d_{i-1}.
 // Order (restated by the oracle's lane_blocked_scan, so the two stay bit-identical): every
@@ -424,8 +575,9 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   double *s_a = s_cell;                                // [nz]  G of the solve (before Psib)
   double *s_b = s_a + nz;                              // [nz]  I of the solve
   const bool overlay = P >= 3 && tw_overlay(nz, nb, W);
-  double *s_psib = overlay ? s_cell : s_cell + W * nz;  // [nb]
-  double *s_gbot = s_cell + W * nz + (overlay ? 0 : nb);  // [ngrp] min(bot) of each 8-cell group
+  const int ncell = nz + tw_pad_cells(nz, W);  // (the zero row of the chain-order path may need more)
+  double *s_psib = overlay ? s_cell : s_cell + W * ncell;  // [nb]
+  double *s_gbot = s_cell + W * ncell + (overlay ? 0 : nb);  // [ngrp] min(bot) of each 8-cell group
   double *s_gtop = s_gbot + ngrp;                   // [ngrp] max(top)
   const size_t base = (size_t)m * nz;
 
@@ -547,6 +699,14 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   // min(bot) / max(top) of this lane's cells for the group ranges; (-inf, +inf) = "holds a cell
   // that bars its group from the shortcuts"
   double lane_gb = __builtin_inf(), lane_gt = -__builtin_inf();
+  // chain order (psib_sorted_pass): what this lane's cells contribute to the test
+  double c_bot[P], c_top[P];
+  bool c_plain[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    c_bot[p] = c_top[p] = __builtin_inf();  // (slots past the last cell: in order with anything)
+    c_plain[p] = true;
+  }
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const int k = lane * P + p;
@@ -575,8 +735,28 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
         s_cell[4 * nz + k] = u;
       lane_gb = plain ? __builtin_fmin(lane_gb, bot) : -__builtin_inf();
       lane_gt = (plain && lane_gt != __builtin_inf()) ? __builtin_fmax(lane_gt, top) : __builtin_inf();
+      c_bot[p] = bot;
+      c_top[p] = top;
+      c_plain[p] = plain;
     }
   }
+  // K0 = 1 + the highest cell that is not plain or whose top lies above the next cell's bot
+  int K0 = 0;
+  constexpr int TW_NBLK = (W == 6 && P <= 4 && BIG <= 1) ? (BIG == 1 ? 2 : 1) : 0;
+  if constexpr (TW_NBLK != 0) {
+    const double bot_nl = from_next_lane(c_bot[0]);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int k = lane * P + p;
+      const double nbot = (p < P - 1) ? c_bot[p + 1 < P ? p + 1 : p] : ((lane < 63) ? bot_nl : __builtin_inf());
+      const bool bad = k < nz - 1 && !(c_plain[p] && c_top[p] <= nbot);
+      const unsigned long long bm = __ballot(bad);
+      const int kb = bm ? (63 - __builtin_clzll(bm)) * P + p + 1 : 0;
+      K0 = kb > K0 ? kb : K0;
+    }
+  }
+  const bool chain_order = TW_NBLK != 0 && K0 <= 2 && nz - 1 >= 16 &&
+                           tw_sorted_blocks(nz - 1) == TW_NBLK && range_ok && !(mn != mn);
   __builtin_amdgcn_wave_barrier();
   PM_TICK(7)
   const int nc = nz - 1;
@@ -621,6 +801,59 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
     s_gtop[g] = ok ? gt : __builtin_inf();   // never "all masks 0"
   }
   __builtin_amdgcn_wave_barrier();
+  double exc_top[2] = {__builtin_inf(), __builtin_inf()};
+  if constexpr (TW_NBLK != 0) {
+    if (chain_order) {  // wave-uniform
+      const int nc_ = nz - 1, zrow = tw_zero_row(nc_);
+      // sentinel cell and the zero row's sixth slots (the group ranges above were the last
+      // readers of `bot` there)
+      if (lane == 0) {
+        double2 *sc = reinterpret_cast<double2 *>(s_cell + (size_t)nc_ * 6);
+        sc[0] = double2{__builtin_inf(), 1.};
+        sc[1] = double2{1., 0.};
+        sc[2] = double2{-0., 0.};
+      }
+      if (lane < 8 && zrow + lane != nc_) s_cell[(size_t)(zrow + lane) * 6 + 5] = 0.;
+      __builtin_amdgcn_wave_barrier();
+      // S[k] = ((u[k] + u[k+8]) + u[k+16]) + ... over the full 8-cell groups of k's block
+      const int n2 = TW_NBLK == 2 ? tw_block_split(nc_) : 0;
+      double S[P];
+      int sfull[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int k = lane * P + p;
+        const int k0 = (TW_NBLK == 2 && k >= n2) ? n2 : 0;
+        const int n = TW_NBLK == 1 ? nc_ : (k0 == 0 ? n2 : nc_ - n2);
+        sfull[p] = k0 + ((n >> 3) << 3);
+        S[p] = (k < sfull[p]) ? s_cell[(size_t)k * 6 + 4] : 0.;
+      }
+      const int tmax = ((TW_NBLK == 2 ? (n2 > nc_ - n2 ? n2 : nc_ - n2) : nc_) >> 3) - 1;
+      for (int t = 1; t <= tmax; ++t) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int kk = lane * P + p + 8 * t;
+          S[p] += s_cell[(size_t)(kk < sfull[p] ? kk : nc_) * 6 + 4];
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int k = lane * P + p;
+        if (k < zrow) s_cell[(size_t)k * 6 + 5] = S[p];
+      }
+      // cells below K0: a class above a zero-thickness cell (and only that) sees an exact zero
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (e < K0) {
+          const double et = s_cell[e * 6], ed = s_cell[e * 6 + 1], eu = s_cell[e * 6 + 4];
+          const bool quiet = ed == 0. && __builtin_fabs(et) < 1e100 && __builtin_fabs(eu) <= 1.7976931348623157e308;
+          exc_top[e] = quiet ? et : __builtin_inf();
+        } else {
+          exc_top[e] = -__builtin_inf();
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
   PM_TICK(8)
   const CellView<W> cv{s_cell, nz};
   PsibRange rg;
@@ -644,6 +877,7 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
       if (m_ok && a.bgrid) a.bgrid[(size_t)m * nb + i] = lin.at(i);
     }
   }
+  int klo = K0;  // (chain order: no class of the pass cuts a cell below this one)
   for (int i0 = 0; i0 < (all_nan ? 0 : nb); i0 += 64 * TW_JT) {
     // Issue priority falls with the pass: the SIMD's arbiter favours its oldest wave, so four
     // members of equal cost finish 25 / 29 / 34 / 41 us after the launch and the last one runs
@@ -660,7 +894,19 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
       rg.gmin = lin.at(i0);
       rg.gmax = lin.at(ilast < nb ? ilast : nb - 1);
     }
-    if constexpr (BIG == 2) {
+    bool done = false;
+    if constexpr (TW_NBLK != 0) {
+      if (chain_order) {  // wave-uniform
+        const double gmin_p = rg.gmin;
+        const unsigned exc = (!(gmin_p > exc_top[0]) ? 1u : 0u) | (!(gmin_p > exc_top[1]) ? 2u : 0u);
+        int kzc[TW_JT];
+        psib_sorted_pass<TW_NBLK>(s_cell, nc, klo, exc, bg, res, kzc);
+        klo = __builtin_amdgcn_readlane(kzc[TW_JT - 1], 63);
+        done = true;
+      }
+    }
+    if (done) {
+    } else if constexpr (BIG == 2) {
       psib_pairwise<4, CellView<W>>(cv, 0, nc, bg, res, rg PM_TICK_ARG);
     } else if constexpr (BIG == 1) {
       // 128 < nc <= 256: NumPy's recursion is exactly two blocks, both inlined
