@@ -388,57 +388,80 @@ __host__ __device__ inline int tw_pad_cells(int nz, int W) {
   return over > 0 ? over : 0;
 }
 
-__device__ __forceinline__ double psib_term1(const PsibCell &c, double g) {
-  const double tt = c.top - g;  // psib_regular_terms for one class
+// term of one class on one cell of the chain: psib_regular_terms for one (cell, class) pair.
+// DEG (wave-uniform: the member has cells of zero thickness in its chain, yh = NaN there):
+// clip((top - g) / 0, 0, 1) is 1 below the cell's buoyancy, 0 above it and NaN on it (H6).
+__device__ __forceinline__ double psib_deg_term(const PsibCell &c, double tt, double r) {
+  const double m = tt > 0. ? 1. : (tt < 0. ? 0. : __builtin_nan(""));
+  return c.d == 0. ? m * c.u : r;
+}
+__device__ __forceinline__ double psib_term1(const PsibCell &c, double g, bool deg) {
+  const double tt = c.top - g;
   double rr = tt * c.yl;
   const double q = __builtin_fma(tt, c.yh, rr);
   rr = __builtin_fma(-c.d, q, tt);
-  return fma_clamp01(rr, c.yh, q) * c.u;
+  const double r = fma_clamp01(rr, c.yh, q) * c.u;
+  return deg ? psib_deg_term(c, tt, r) : r;
+}
+// ... and the same quotient from RN(1/d) alone (div_by_recip: two Markstein steps, 5
+// instructions), for cells whose `yl` slot holds a table entry (second block of nz - 1 > 128)
+__device__ __forceinline__ double psib_term1_y(const PsibCell &c, double g, bool deg) {
+  const double tt = c.top - g;
+  double q = tt * c.yh;
+  double rr = __builtin_fma(-c.d, q, tt);
+  q = __builtin_fma(rr, c.yh, q);
+  rr = __builtin_fma(-c.d, q, tt);
+  const double r = fma_clamp01(rr, c.yh, q) * c.u;
+  return deg ? psib_deg_term(c, tt, r) : r;
 }
 
 // One pass (TW_JT classes per lane, ascending with the lane) over a member in chain order.
 // cell: the W = 6 cells; klo: a cell index no class of the pass cuts below (K0, or the cut of
 // the previous pass's last class); exc: bit e set = cell e < K0 may carry a non-zero term for a
 // class of this pass; kz (out): the cut cells.
+// S of block b's cells lives in slot 5 (b = 0) or, for the second block of 128 < nc <= 256
+// cells, in slot 3 (`yl`; slot 5 of those cells is zero, so that the first block's reads past
+// its end find zeros).
 template <int NBLK>
-__device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int klo, unsigned exc,
+__device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int klo, int K0,
+                                                 unsigned exc, bool deg,
                                                  const double (&bg)[TW_JT], double (&res)[TW_JT],
                                                  int (&kz)[TW_JT]) {
   const CellView<6> cv{cell, nc + 1};
   const int SENT = nc, ZROW = tw_zero_row(nc);
-  {  // the cut cell: first k in [klo, nc] with top_k > g (the sentinel's top is +inf)
-    int lo[TW_JT], hi[TW_JT];
+  {  // the cut cell: 1 + the last k in [klo - 1, nc) with top_k <= g, by binary lifting (the
+     // tops ascend; the sentinel's top is +inf).  Positions are byte offsets of cells.
+    int pos[TW_JT];
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) {
-      lo[j] = klo;
-      hi[j] = nc;
-    }
-    for (int span = nc - klo; span > 0; span >>= 1) {
+    for (int j = 0; j < TW_JT; ++j) pos[j] = (klo - 1) * 48;
+    const int R = nc - klo, lim = nc * 48;
+    for (int s = R > 0 ? (48 << (31 - __builtin_clz(R))) : 0; s >= 48; s >>= 1) {
 #pragma unroll
       for (int j = 0; j < TW_JT; ++j) {
-        const int mid = (lo[j] + hi[j]) >> 1;
-        const bool gt = cell[(size_t)mid * 6] > bg[j];
-        hi[j] = gt ? mid : hi[j];
-        lo[j] = gt ? lo[j] : mid + 1;
+        const int cand = pos[j] + s;
+        const int c = cand < lim ? cand : lim;
+        const double t = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(cell) + c);
+        pos[j] = (t <= bg[j]) ? cand : pos[j];
       }
     }
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) kz[j] = lo[j];
+    for (int j = 0; j < TW_JT; ++j) kz[j] = (int)((unsigned)(pos[j] + 48) / 48u);
   }
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) {
     const int n2 = NBLK == 2 ? tw_block_split(nc) : 0;
     const int k0 = b == 0 ? 0 : n2, n = NBLK == 1 ? nc : (b == 0 ? n2 : nc - n2);
     const int ng = n >> 3, full = k0 + 8 * ng;
-    double r[8][TW_JT], v[TW_JT];
-    int kst[TW_JT], astar[TW_JT];
+    const int sslot = (NBLK == 2 && b == 1) ? 3 : 5;
+    double v[TW_JT];
+    int kst[TW_JT];
     bool cut[TW_JT];
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) {
       kst[j] = kz[j] > k0 ? kz[j] : k0;  // the block's first cell that is not below the cut
       cut[j] = kz[j] >= k0 && kz[j] < full;
-      v[j] = psib_term1(cv.load(cut[j] ? kz[j] : SENT), bg[j]);
-      astar[j] = cut[j] ? (kst[j] & 7) : 8;
+      const PsibCell c = cv.load(cut[j] ? kz[j] : SENT);
+      v[j] = NBLK == 2 ? psib_term1_y(c, bg[j], deg) : psib_term1(c, bg[j], deg);
     }
     // the cut cell's accumulator: its term, then the cells above it, one by one
     const int kfirst = klo > k0 ? klo : k0;
@@ -449,19 +472,41 @@ __device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int
         v[j] += cv.u((cut[j] && kk < full) ? kk : SENT);
       }
     }
-    // the other accumulators: S of their first cell at or above kst
+    // The other accumulators hold S of the seven cells above kst (accumulator (kst + i) mod 8
+    // has cell kst + i first), the tree pairs accumulators (0,1) (2,3) | (4,5) (6,7): with
+    // s_i = S[kst + i] the pairs are, for an even kst, (v, s1) (s2, s3) (s4, s5) (s6, s7) and for
+    // an odd one (s7, v) (s1, s2) (s3, s4) (s5, s6) -- in accumulator order starting at the cut
+    // cell's own pair, number (kst >> 1) & 3 of the four.  Additions commute, so only which
+    // pairs share a quad matters.  A block without a cut (all of it above: kst = k0; all of it
+    // below: the zero row) takes S[kst] for v.
+    double rb[TW_JT];
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) {
-      const int base8 = kst[j] & ~7, a0 = kst[j] & 7;
-      const int rlo = base8 < full ? base8 : ZROW, rhi = base8 + 8 < full ? base8 + 8 : ZROW;
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const int row = a < a0 ? rhi : rlo;
-        const double s = cell[(size_t)(row + a) * 6 + 5];
-        r[a][j] = (a == astar[j]) ? v[j] : s;
-      }
+      const int row = kst[j] < full ? kst[j] : ZROW;
+      const double *sp = cell + (size_t)row * 6 + sslot;
+      const double s0 = sp[0], s1 = sp[6], s2 = sp[12], s3 = sp[18], s4 = sp[24], s5 = sp[30],
+                   s6 = sp[36], s7 = sp[42];
+      const double vv = cut[j] ? v[j] : s0;
+      const bool odd = (kst[j] & 1) != 0, podd = (kst[j] & 2) != 0;
+      const double p0 = vv + (odd ? s7 : s1);
+      const double qa = s1 + s2, qb = s2 + s3, qc = s3 + s4, qd = s4 + s5, qe = s5 + s6, qf = s6 + s7;
+      const double p1 = odd ? qa : qb, p2 = odd ? qc : qd, p3 = odd ? qe : qf;
+      rb[j] = (p0 + (podd ? p3 : p1)) + (p2 + (podd ? p1 : p3));
     }
     if (b == 0 && exc != 0u) {  // wave-uniform: cells below K0 that this pass's classes can see
+      // (rare passes: the eight accumulators again, those of the cells below K0 cell by cell)
+      double r[8][TW_JT];
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j) {
+        const int base8 = kst[j] & ~7, a0 = kst[j] & 7;
+        const int rlo = base8 < full ? base8 : ZROW, rhi = base8 + 8 < full ? base8 + 8 : ZROW;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const int row = a < a0 ? rhi : rlo;
+          const double s = cell[(size_t)(row + a) * 6 + sslot];
+          r[a][j] = (cut[j] && a == a0) ? v[j] : s;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         if ((exc >> e) & 1u) {
@@ -473,19 +518,26 @@ __device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int
           }
         }
       }
+#pragma unroll
+      for (int j = 0; j < TW_JT; ++j)
+        rb[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) + ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
     }
-    double rb[TW_JT];
+    for (int k = full; k < k0 + n; ++k) {  // NumPy's tail (regular cells), one by one
+      const PsibCell c = cv.load(k);
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j)
-      rb[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) + ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
-    for (int k = full; k < k0 + n; ++k) {  // NumPy's tail, as the tiles take it
-      double term[TW_JT];
-      psib_cell_terms(cv.load(k), bg, term);
-#pragma unroll
-      for (int j = 0; j < TW_JT; ++j) rb[j] += term[j];
+      for (int j = 0; j < TW_JT; ++j)
+        rb[j] += NBLK == 2 ? psib_term1_y(c, bg[j], deg) : psib_term1(c, bg[j], deg);
     }
 #pragma unroll
     for (int j = 0; j < TW_JT; ++j) res[j] = (b == 0) ? rb[j] : res[j] + rb[j];
+  }
+  if (deg) {  // wave-uniform: a class ON a zero-thickness cell's buoyancy (the cell right below
+              // the cut: tops ascend) has a NaN mask there, hence a NaN sum (H6)
+#pragma unroll
+    for (int j = 0; j < TW_JT; ++j) {
+      const double2 td = *reinterpret_cast<const double2 *>(cell + (size_t)(kz[j] > 0 ? kz[j] - 1 : 0) * 6);
+      if (kz[j] > K0 && td.y == 0. && td.x == bg[j]) res[j] = __builtin_nan("");
+    }
   }
 }
 
@@ -701,11 +753,12 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   double lane_gb = __builtin_inf(), lane_gt = -__builtin_inf();
   // chain order (psib_sorted_pass): what this lane's cells contribute to the test
   double c_bot[P], c_top[P];
-  bool c_plain[P];
+  bool c_plain[P], c_flat[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     c_bot[p] = c_top[p] = __builtin_inf();  // (slots past the last cell: in order with anything)
     c_plain[p] = true;
+    c_flat[p] = false;
   }
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -737,7 +790,10 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
       lane_gt = (plain && lane_gt != __builtin_inf()) ? __builtin_fmax(lane_gt, top) : __builtin_inf();
       c_bot[p] = bot;
       c_top[p] = top;
-      c_plain[p] = plain;
+      // (in chain order a cell of zero thickness is as good as a regular one: psib_deg_term)
+      const bool flat = d == 0. && range_ok && __builtin_fabs(top) < 1e100 && ufin;
+      c_plain[p] = plain || flat;
+      c_flat[p] = flat;
     }
   }
   // K0 = 1 + the highest cell that is not plain or whose top lies above the next cell's bot
@@ -753,6 +809,15 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
       const unsigned long long bm = __ballot(bad);
       const int kb = bm ? (63 - __builtin_clzll(bm)) * P + p + 1 : 0;
       K0 = kb > K0 ? kb : K0;
+    }
+  }
+  int deg_hi = -1;  // the highest cell of zero thickness at or above K0
+  if constexpr (TW_NBLK != 0) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const unsigned long long fm = __ballot(c_flat[p] && lane * P + p >= K0);
+      const int kf = fm ? (63 - __builtin_clzll(fm)) * P + p : -1;
+      deg_hi = kf > deg_hi ? kf : deg_hi;
     }
   }
   const bool chain_order = TW_NBLK != 0 && K0 <= 2 && nz - 1 >= 16 &&
@@ -813,7 +878,10 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
         sc[1] = double2{1., 0.};
         sc[2] = double2{-0., 0.};
       }
-      if (lane < 8 && zrow + lane != nc_) s_cell[(size_t)(zrow + lane) * 6 + 5] = 0.;
+      if (lane < 8 && zrow + lane != nc_) {
+        s_cell[(size_t)(zrow + lane) * 6 + 5] = 0.;
+        if (TW_NBLK == 2) s_cell[(size_t)(zrow + lane) * 6 + 3] = 0.;
+      }
       __builtin_amdgcn_wave_barrier();
       // S[k] = ((u[k] + u[k+8]) + u[k+16]) + ... over the full 8-cell groups of k's block
       const int n2 = TW_NBLK == 2 ? tw_block_split(nc_) : 0;
@@ -838,7 +906,12 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int k = lane * P + p;
-        if (k < zrow) s_cell[(size_t)k * 6 + 5] = S[p];
+        if (TW_NBLK == 2 && k >= n2) {  // second block: S in the `yl` slot, zeros in the sixth
+          if (k < zrow) s_cell[(size_t)k * 6 + 3] = S[p];
+          if (k < nc_) s_cell[(size_t)k * 6 + 5] = 0.;
+        } else if (k < zrow) {
+          s_cell[(size_t)k * 6 + 5] = S[p];
+        }
       }
       // cells below K0: a class above a zero-thickness cell (and only that) sees an exact zero
 #pragma unroll
@@ -900,7 +973,10 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
         const double gmin_p = rg.gmin;
         const unsigned exc = (!(gmin_p > exc_top[0]) ? 1u : 0u) | (!(gmin_p > exc_top[1]) ? 2u : 0u);
         int kzc[TW_JT];
-        psib_sorted_pass<TW_NBLK>(s_cell, nc, klo, exc, bg, res, kzc);
+        // (zero-thickness cells matter to a pass that can cut at or right above one, or whose
+        // tail holds one: the cuts ascend with the passes)
+        const bool deg = deg_hi + 1 >= klo || deg_hi >= tw_zero_row(nc);
+        psib_sorted_pass<TW_NBLK>(s_cell, nc, klo, K0, exc, deg, bg, res, kzc);
         klo = __builtin_amdgcn_readlane(kzc[TW_JT - 1], 63);
         done = true;
       }
