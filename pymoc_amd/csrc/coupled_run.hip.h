@@ -41,7 +41,7 @@ constexpr int run_cell_w() { return P == 4 ? 5 : 6; }
 template <int P>
 inline int run_wave_stride(int nz, int nb, int ny, bool with_so) {
   int w = JfLds<P>::PER_WAVE;
-  const int t = tw_lds_doubles(nz, nb, run_cell_w<P>());
+  const int t = tw_lds_doubles(nz, nb, run_cell_w<P>(), false);
   w = t > w ? t : w;
   if (with_so) {
     const int s = so_lds_doubles(nz, ny, false, false);
@@ -215,7 +215,7 @@ void k_twocol_run(pm_twocol_loop r, int wstride) {
   // (one call site per phase: k = -1 is the block of n_first steps that precedes the first refresh)
   for (int k = r.sched.n_first > 0 ? -1 : 0; k < r.sched.n_updates; ++k) {
     if (k >= 0) {
-      tw_member<P, BIG, run_cell_w<P>()>(r.tw, PM_TW_SOLVE | PM_TW_PSIB | PM_TW_PSIBZ, m_raw, wl, lane);
+      tw_member<P, BIG, run_cell_w<P>(), false>(r.tw, PM_TW_SOLVE | PM_TW_PSIB | PM_TW_PSIBZ, m_raw, wl, lane);
       run_phase_fence();
     }
     const int ns = k < 0 ? r.sched.n_first
@@ -247,7 +247,7 @@ __device__ __forceinline__ int jn_run_member(const pm_jn2018 &a, const pm_thermw
     if (k >= 0 && !(skip_diag && k == k0)) {
       so_member<P, false>(so, PM_SO_OP_SOLVE, m_raw, wl, lane);
       run_phase_fence();
-      tw_member<P, BIG, run_cell_w<P>()>(tw, PM_TW_SOLVE | PM_TW_PSIB | PM_TW_PSIBZ, m_raw, wl, lane);
+      tw_member<P, BIG, run_cell_w<P>(), false>(tw, PM_TW_SOLVE | PM_TW_PSIB | PM_TW_PSIBZ, m_raw, wl, lane);
       run_phase_fence();
     }
     int ns = k < 0 ? sched.n_first : ((k == sched.n_updates - 1) ? sched.n_last : sched.m_steps);

@@ -17,6 +17,7 @@
 //    psib is bit-identical to np.sum in the reference, NaN/inf cases included.
 //  * Psibz: np.interp on the uniform bgrid -- direct index + fix-up instead of a search.
 #pragma once
+#include <type_traits>
 #include "common.hip.h"
 
 namespace pm {
@@ -38,16 +39,12 @@ __device__ __forceinline__ double np_clip01(double v) {
 // The interval index starts from a guess, (x - start) * rstep with rstep ~ 1 / step, and is
 // then moved until bgrid[j] <= x < bgrid[j+1] holds with np.linspace's own node values, so the
 // guess only has to be close (a correctly rounded division here cost a sixth of Psibz).
-__device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
-                                                 const double *psib, int nb, double rstep) {
-  if (x != x) return x;
-  const double lval = psib[0], rval = psib[nb - 1];
-  if (nb == 1) return (x < lin.start) ? lval : ((x > lin.start) ? rval : psib[0]);
-  if (x > lin.stop) return rval;
-  if (x < lin.start) return lval;
-  // largest j with bgrid[j] <= x
+// the interval of x on the uniform grid: largest j with bgrid[j] <= x, and the grid's own values
+// at j and j + 1 (callers have dealt with NaN, a single node and x outside [start, stop]); -1:
+// no such node
+__device__ __forceinline__ int interp_uniform_index(double x, const Linspace &lin, int nb,
+                                                    double rstep, double &xj, double &xj1) {
   int j;
-  double xj, xj1;
   if (lin.step > 0. && lin.step < 1e300) {
     // (nb > 1 and step != 0 here: Linspace::at without its special cases)
     auto at = [&](int i) { return i == nb - 1 ? lin.stop : (double)i * lin.step + lin.start; };
@@ -76,10 +73,40 @@ __device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
         hi = mid;
     }
     j = lo - 1;
-    if (j < 0) return lval;
+    if (j < 0) return j;
     xj = lin.at(j);
     xj1 = lin.at(j + 1 < nb ? j + 1 : nb - 1);
   }
+  return j;
+}
+
+// np.interp's value from the interval j = interp_uniform_index(x, ...) >= 0 (x inside the grid)
+__device__ __forceinline__ double interp_uniform_at(double x, int j, const Linspace &lin,
+                                                    const double *psib, int nb) {
+  if (j < 0) return x;  // (a NaN level: the marking pass left it out)
+  if (j == nb - 1) return psib[j];
+  const double xj = lin.at(j), xj1 = lin.at(j + 1);
+  if (xj == x) return psib[j];
+  const double fj = psib[j], fj1 = psib[j + 1];
+  const double slope = (fj1 - fj) / (xj1 - xj);
+  double r = slope * (x - xj) + fj;
+  if (r != r) {  // numpy: nan in one direction, try the other
+    r = slope * (x - xj1) + fj1;
+    if (r != r && fj == fj1) r = fj;
+  }
+  return r;
+}
+
+__device__ __forceinline__ double interp_uniform(double x, const Linspace &lin,
+                                                 const double *psib, int nb, double rstep) {
+  if (x != x) return x;
+  const double lval = psib[0], rval = psib[nb - 1];
+  if (nb == 1) return (x < lin.start) ? lval : ((x > lin.start) ? rval : psib[0]);
+  if (x > lin.stop) return rval;
+  if (x < lin.start) return lval;
+  double xj, xj1;
+  const int j = interp_uniform_index(x, lin, nb, rstep, xj, xj1);
+  if (j < 0) return lval;
   if (j == nb - 1) return psib[j];
   if (xj == x) return psib[j];
   const double fj = psib[j], fj1 = psib[j + 1];
@@ -137,9 +164,15 @@ __host__ __device__ inline bool tw_overlay(int nz, int nb, int W = 6) {
 }
 // LDS doubles per wave: cells, the psib row unless overlaid, two group-range rows; even, so
 // that every wave's cells stay 16-byte aligned
+// ... the group-range rows double as the bit marks (16 words) and the list (TW_LAZY_CAP class
+// numbers, 16 bits each) of the classes Psibz asks for (chain-order members, W = 6)
+constexpr int TW_LAZY_CAP = 256, TW_LAZY_DOUBLES = (64 + 2 * TW_LAZY_CAP) / 8;
+// (chain = false: the tiles only -- the persistent run kernels, whose phases share the LDS)
 __host__ __device__ inline int tw_pad_cells(int nz, int W);
-__host__ __device__ inline int tw_lds_doubles(int nz, int nb, int W = 6) {
-  return (W * (nz + tw_pad_cells(nz, W)) + (tw_overlay(nz, nb, W) ? 0 : nb) + 2 * ((nz + 7) / 8) + 1) & ~1;
+__host__ __device__ inline int tw_lds_doubles(int nz, int nb, int W = 6, bool chain = true) {
+  int rows = 2 * ((nz + 7) / 8);
+  if (chain && W == 6 && rows < TW_LAZY_DOUBLES) rows = TW_LAZY_DOUBLES;
+  return (W * (nz + (chain ? tw_pad_cells(nz, W) : 0)) + (tw_overlay(nz, nb, W) ? 0 : nb) + rows + 1) & ~1;
 }
 // RN(fma(r, yh, q)) clamped to [0, 1] by the VOP3 clamp modifier (the last Markstein step and
 // np.clip in one instruction; finite operands only)
@@ -415,29 +448,43 @@ __device__ __forceinline__ double psib_term1_y(const PsibCell &c, double g, bool
   return deg ? psib_deg_term(c, tt, r) : r;
 }
 
-// One pass (TW_JT classes per lane, ascending with the lane) over a member in chain order.
+// term of one class on ANY cell (psib_cell_terms for one pair): the tiles' quotient on a regular
+// cell, IEEE division and NumPy's NaN-propagating clip on a degenerate or inverted one
+__device__ __forceinline__ double psib_cell_term1(const PsibCell &c, double g) {
+  if (c.yh == c.yh) {
+    const double tt = c.top - g;
+    double rr = tt * c.yl;
+    const double q = __builtin_fma(tt, c.yh, rr);
+    rr = __builtin_fma(-c.d, q, tt);
+    return fma_clamp01(rr, c.yh, q) * c.u;
+  }
+  return np_clip01((c.top - g) / c.d) * c.u;
+}
+
+// One pass (JT classes per lane, ascending with the lane, then with the slot) over a member in
+// chain order.
 // cell: the W = 6 cells; klo: a cell index no class of the pass cuts below (K0, or the cut of
 // the previous pass's last class); exc: bit e set = cell e < K0 may carry a non-zero term for a
 // class of this pass; kz (out): the cut cells.
 // S of block b's cells lives in slot 5 (b = 0) or, for the second block of 128 < nc <= 256
 // cells, in slot 3 (`yl`; slot 5 of those cells is zero, so that the first block's reads past
 // its end find zeros).
-template <int NBLK>
+template <int NBLK, int JT>
 __device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int klo, int K0,
                                                  unsigned exc, bool deg,
-                                                 const double (&bg)[TW_JT], double (&res)[TW_JT],
-                                                 int (&kz)[TW_JT]) {
+                                                 const double (&bg)[JT], double (&res)[JT],
+                                                 int (&kz)[JT]) {
   const CellView<6> cv{cell, nc + 1};
   const int SENT = nc, ZROW = tw_zero_row(nc);
   {  // the cut cell: 1 + the last k in [klo - 1, nc) with top_k <= g, by binary lifting (the
      // tops ascend; the sentinel's top is +inf).  Positions are byte offsets of cells.
-    int pos[TW_JT];
+    int pos[JT];
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) pos[j] = (klo - 1) * 48;
+    for (int j = 0; j < JT; ++j) pos[j] = (klo - 1) * 48;
     const int R = nc - klo, lim = nc * 48;
     for (int s = R > 0 ? (48 << (31 - __builtin_clz(R))) : 0; s >= 48; s >>= 1) {
 #pragma unroll
-      for (int j = 0; j < TW_JT; ++j) {
+      for (int j = 0; j < JT; ++j) {
         const int cand = pos[j] + s;
         const int c = cand < lim ? cand : lim;
         const double t = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(cell) + c);
@@ -445,7 +492,7 @@ __device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int
       }
     }
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) kz[j] = (int)((unsigned)(pos[j] + 48) / 48u);
+    for (int j = 0; j < JT; ++j) kz[j] = (int)((unsigned)(pos[j] + 48) / 48u);
   }
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) {
@@ -453,21 +500,23 @@ __device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int
     const int k0 = b == 0 ? 0 : n2, n = NBLK == 1 ? nc : (b == 0 ? n2 : nc - n2);
     const int ng = n >> 3, full = k0 + 8 * ng;
     const int sslot = (NBLK == 2 && b == 1) ? 3 : 5;
-    double v[TW_JT];
-    int kst[TW_JT];
-    bool cut[TW_JT];
+    double v[JT];
+    int kst[JT];
+    bool cut[JT];
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) {
+    for (int j = 0; j < JT; ++j) {
       kst[j] = kz[j] > k0 ? kz[j] : k0;  // the block's first cell that is not below the cut
       cut[j] = kz[j] >= k0 && kz[j] < full;
       const PsibCell c = cv.load(cut[j] ? kz[j] : SENT);
       v[j] = NBLK == 2 ? psib_term1_y(c, bg[j], deg) : psib_term1(c, bg[j], deg);
     }
-    // the cut cell's accumulator: its term, then the cells above it, one by one
-    const int kfirst = klo > k0 ? klo : k0;
-    for (int t = 1; t <= ((full - 1 - kfirst) >> 3); ++t) {
+    // the cut cell's accumulator: its term, then the cells above it, one by one (the cuts ascend
+    // with the lane and the slot: lane 0 of a slot bounds the slot's chains)
 #pragma unroll
-      for (int j = 0; j < TW_JT; ++j) {
+    for (int j = 0; j < JT; ++j) {
+      const int kl = __builtin_amdgcn_readfirstlane(kz[j]);
+      const int kfirst = kl > k0 ? kl : k0;
+      for (int t = 1; t <= ((full - 1 - kfirst) >> 3); ++t) {
         const int kk = kz[j] + 8 * t;
         v[j] += cv.u((cut[j] && kk < full) ? kk : SENT);
       }
@@ -479,9 +528,9 @@ __device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int
     // cell's own pair, number (kst >> 1) & 3 of the four.  Additions commute, so only which
     // pairs share a quad matters.  A block without a cut (all of it above: kst = k0; all of it
     // below: the zero row) takes S[kst] for v.
-    double rb[TW_JT];
+    double rb[JT];
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) {
+    for (int j = 0; j < JT; ++j) {
       const int row = kst[j] < full ? kst[j] : ZROW;
       const double *sp = cell + (size_t)row * 6 + sslot;
       const double s0 = sp[0], s1 = sp[6], s2 = sp[12], s3 = sp[18], s4 = sp[24], s5 = sp[30],
@@ -495,9 +544,9 @@ __device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int
     }
     if (b == 0 && exc != 0u) {  // wave-uniform: cells below K0 that this pass's classes can see
       // (rare passes: the eight accumulators again, those of the cells below K0 cell by cell)
-      double r[8][TW_JT];
+      double r[8][JT];
 #pragma unroll
-      for (int j = 0; j < TW_JT; ++j) {
+      for (int j = 0; j < JT; ++j) {
         const int base8 = kst[j] & ~7, a0 = kst[j] & 7;
         const int rlo = base8 < full ? base8 : ZROW, rhi = base8 + 8 < full ? base8 + 8 : ZROW;
 #pragma unroll
@@ -510,31 +559,33 @@ __device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         if ((exc >> e) & 1u) {
-          double term[TW_JT];
           for (int t = 0; t < ng; ++t) {
-            psib_cell_terms(cv.load(e + 8 * t), bg, term);
+            const PsibCell c = cv.load(e + 8 * t);
 #pragma unroll
-            for (int j = 0; j < TW_JT; ++j) r[e][j] = (t == 0) ? term[j] : r[e][j] + term[j];
+            for (int j = 0; j < JT; ++j) {
+              const double term = psib_cell_term1(c, bg[j]);
+              r[e][j] = (t == 0) ? term : r[e][j] + term;
+            }
           }
         }
       }
 #pragma unroll
-      for (int j = 0; j < TW_JT; ++j)
+      for (int j = 0; j < JT; ++j)
         rb[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) + ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
     }
     for (int k = full; k < k0 + n; ++k) {  // NumPy's tail (regular cells), one by one
       const PsibCell c = cv.load(k);
 #pragma unroll
-      for (int j = 0; j < TW_JT; ++j)
+      for (int j = 0; j < JT; ++j)
         rb[j] += NBLK == 2 ? psib_term1_y(c, bg[j], deg) : psib_term1(c, bg[j], deg);
     }
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) res[j] = (b == 0) ? rb[j] : res[j] + rb[j];
+    for (int j = 0; j < JT; ++j) res[j] = (b == 0) ? rb[j] : res[j] + rb[j];
   }
   if (deg) {  // wave-uniform: a class ON a zero-thickness cell's buoyancy (the cell right below
               // the cut: tops ascend) has a NaN mask there, hence a NaN sum (H6)
 #pragma unroll
-    for (int j = 0; j < TW_JT; ++j) {
+    for (int j = 0; j < JT; ++j) {
       const double2 td = *reinterpret_cast<const double2 *>(cell + (size_t)(kz[j] > 0 ? kz[j] - 1 : 0) * 6);
       if (kz[j] > K0 && td.y == 0. && td.x == bg[j]) res[j] = __builtin_nan("");
     }
@@ -615,7 +666,7 @@ __device__ __forceinline__ void tw_pass_priority(int pass) {
 // One member's update: `s_cell` = the wave's tw_lds_doubles(nz, nb) doubles of LDS.  The body of
 // k_thermwind, and the diagnostic phase of the persistent run kernels (coupled_run.hip), which
 // call it between two blocks of time steps of the same wave.
-template <int P, int BIG, int W = 6>
+template <int P, int BIG, int W = 6, bool CHAIN = true>
 __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_raw,
                                           double *s_cell, int lane) {
   static_assert(W == 6 || (W == 5 && tw_w5_ok(P)), "cell layout");
@@ -627,7 +678,7 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   double *s_a = s_cell;                                // [nz]  G of the solve (before Psib)
   double *s_b = s_a + nz;                              // [nz]  I of the solve
   const bool overlay = P >= 3 && tw_overlay(nz, nb, W);
-  const int ncell = nz + tw_pad_cells(nz, W);  // (the zero row of the chain-order path may need more)
+  const int ncell = nz + (CHAIN ? tw_pad_cells(nz, W) : 0);  // (the chain-order path's zero row may need more)
   double *s_psib = overlay ? s_cell : s_cell + W * ncell;  // [nb]
   double *s_gbot = s_cell + W * ncell + (overlay ? 0 : nb);  // [ngrp] min(bot) of each 8-cell group
   double *s_gtop = s_gbot + ngrp;                   // [ngrp] max(top)
@@ -798,7 +849,7 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   }
   // K0 = 1 + the highest cell that is not plain or whose top lies above the next cell's bot
   int K0 = 0;
-  constexpr int TW_NBLK = (W == 6 && P <= 4 && BIG <= 1) ? (BIG == 1 ? 2 : 1) : 0;
+  constexpr int TW_NBLK = (CHAIN && W == 6 && P <= 4 && BIG <= 1) ? (BIG == 1 ? 2 : 1) : 0;
   if constexpr (TW_NBLK != 0) {
     const double bot_nl = from_next_lane(c_bot[0]);
 #pragma unroll
@@ -927,6 +978,59 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
       __builtin_amdgcn_wave_barrier();
     }
   }
+  // ---- chain order, and no caller asks for psib itself: only the classes that Psibz's two
+  // np.interp calls read are summed -- the two grid nodes around every level's buoyancy.
+  // BASELINE's ensembles: 70-135 of the 500 classes, ONE pass of two or three classes per lane.
+  // The levels' owners find their intervals (kept for Psibz at <= 2 levels per lane) and mark
+  // the nodes; eight ballots over the marks then list the marked classes in ascending order.
+  bool lazy = false;
+  int n_need = 0;
+  constexpr bool TW_KEEP_J = P <= 2;
+  int jkeep[TW_KEEP_J ? 2 * P : 1];
+  const unsigned short *lazy_list = reinterpret_cast<const unsigned short *>(s_gbot + 8);
+  if constexpr (TW_NBLK != 0) {
+    lazy = chain_order && a.psib == nullptr && a.bgrid == nullptr && (ops & PM_TW_PSIBZ) != 0 &&
+           nb >= 2 && nb <= 512 && lin.step > 0. && lin.step < 1e300;
+    if (lazy) {  // wave-uniform
+      unsigned *marks = reinterpret_cast<unsigned *>(s_gbot);
+      unsigned short *list = reinterpret_cast<unsigned short *>(s_gbot + 8);
+      if (lane < 16) marks[lane] = 0u;
+      __builtin_amdgcn_wave_barrier();
+      const double rstep_m = 1.0 / lin.step;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const double x = c == 0 ? b1[p] : b2[p];
+          int j = -1;
+          if (lane * P + p < nz && x >= lin.start && x <= lin.stop) {  // (false for a NaN)
+            double xj, xj1;
+            j = interp_uniform_index(x, lin, nb, rstep_m, xj, xj1);
+            const int j1 = j + 1 < nb ? j + 1 : nb - 1;
+            atomicOr(&marks[j >> 5], (1u << (j & 31)) | ((j1 >> 5) == (j >> 5) ? 1u << (j1 & 31) : 0u));
+            if ((j1 >> 5) != (j >> 5)) atomicOr(&marks[j1 >> 5], 1u << (j1 & 31));
+          }
+          if constexpr (TW_KEEP_J) jkeep[2 * p + c] = j;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // class 64 t + lane in round t: its place in the list = the marked classes before it
+      const unsigned long long below = (1ull << lane) - 1ull;
+      int count = 0;
+      for (int t = 0; t * 64 < nb; ++t) {
+        const unsigned wl = marks[2 * t], wh = marks[2 * t + 1];  // (16 words: nb <= 512)
+        const unsigned long long mk = ((unsigned long long)wh << 32) | wl;  // wave-uniform
+        if ((mk >> lane) & 1ull) {
+          const int at = count + __builtin_popcountll(mk & below);
+          if (at < TW_LAZY_CAP) list[at] = (unsigned short)(64 * t + lane);
+        }
+        count += __builtin_popcountll(mk);
+      }
+      n_need = count;
+      if (n_need > 192 || n_need < 1) lazy = false;  // (two or three classes per lane)
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
   PM_TICK(8)
   const CellView<W> cv{s_cell, nz};
   PsibRange rg;
@@ -951,7 +1055,33 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
     }
   }
   int klo = K0;  // (chain order: no class of the pass cuts a cell below this one)
-  for (int i0 = 0; i0 < (all_nan ? 0 : nb); i0 += 64 * TW_JT) {
+  if constexpr (TW_NBLK != 0) {
+    if (lazy && !all_nan) {  // wave-uniform: ONE pass over the listed classes, JT per lane
+      auto listed_pass = [&](auto jt_c) {
+        constexpr int JT = decltype(jt_c)::value;
+        double bg[JT], res[JT];
+        int ci[JT], kzc[JT];
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+          const int i = j * 64 + lane;
+          ci[j] = (int)lazy_list[i < n_need ? i : n_need - 1];
+          bg[j] = lin.at(ci[j]);
+        }
+        const double gmin_p = lin.at((int)lazy_list[0]);
+        const unsigned exc = (!(gmin_p > exc_top[0]) ? 1u : 0u) | (!(gmin_p > exc_top[1]) ? 2u : 0u);
+        psib_sorted_pass<TW_NBLK, JT>(s_cell, nc, K0, K0, exc, deg_hi >= K0, bg, res, kzc);
+        if (overlay) __builtin_amdgcn_wave_barrier();  // the cells are dead: the row takes their place
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+          if (j * 64 + lane < n_need) s_psib[ci[j]] = res[j];
+      };
+      if (n_need <= 128)
+        listed_pass(std::integral_constant<int, 2>{});
+      else
+        listed_pass(std::integral_constant<int, 3>{});
+    }
+  }
+  for (int i0 = 0; i0 < ((all_nan || lazy) ? 0 : nb); i0 += 64 * TW_JT) {
     // Issue priority falls with the pass: the SIMD's arbiter favours its oldest wave, so four
     // members of equal cost finish 25 / 29 / 34 / 41 us after the launch and the last one runs
     // alone; a wave that is a pass ahead yields to the ones behind and they finish together.
@@ -976,7 +1106,7 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
         // (zero-thickness cells matter to a pass that can cut at or right above one, or whose
         // tail holds one: the cuts ascend with the passes)
         const bool deg = deg_hi + 1 >= klo || deg_hi >= tw_zero_row(nc);
-        psib_sorted_pass<TW_NBLK>(s_cell, nc, klo, K0, exc, deg, bg, res, kzc);
+        psib_sorted_pass<TW_NBLK, TW_JT>(s_cell, nc, klo, K0, exc, deg, bg, res, kzc);
         klo = __builtin_amdgcn_readlane(kzc[TW_JT - 1], 63);
         done = true;
       }
@@ -1015,7 +1145,7 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   }
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_wave_barrier();
-  if (overlay && !all_nan) {  // the cells are dead: the psib row takes their place
+  if (overlay && !all_nan && !lazy) {  // the cells are dead: the psib row takes their place
 #pragma unroll
     for (int q = 0; q < TW_HELD; ++q)
 #pragma unroll
@@ -1048,8 +1178,14 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   for (int p = 0; p < P; ++p) {
     const int i = lane * P + p;
     if (i < nz && m_ok) {
-      const double p1 = interp_uniform(b1e[p], lin, s_psib, nb, rstep);
-      const double p2 = interp_uniform(b2e[p], lin, s_psib, nb, rstep);
+      double p1, p2;
+      if (TW_KEEP_J && lazy) {  // (the intervals found when the classes were marked)
+        p1 = interp_uniform_at(b1e[p], jkeep[TW_KEEP_J ? 2 * p : 0], lin, s_psib, nb);
+        p2 = interp_uniform_at(b2e[p], jkeep[TW_KEEP_J ? 2 * p + 1 : 0], lin, s_psib, nb);
+      } else {
+        p1 = interp_uniform(b1e[p], lin, s_psib, nb, rstep);
+        p2 = interp_uniform(b2e[p], lin, s_psib, nb, rstep);
+      }
       if (a.psibz1) a.psibz1[base + i] = p1;
       if (a.psibz2) a.psibz2[base + i] = p2;
       if (a.wA1) {  // (Psi_iso_b - SO.Psi) * 1e6   (example_twocol_plusSO.py:105)
