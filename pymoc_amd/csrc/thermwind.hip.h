@@ -1015,13 +1015,17 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
       }
       __builtin_amdgcn_wave_barrier();
       // class 64 t + lane in round t: its place in the list = the marked classes before it
-      const unsigned long long below = (1ull << lane) - 1ull;
+      // (the 16 words come by ONE read and are handed out as scalars: the rounds do not wait
+      // on the LDS; v_mbcnt counts the marks below a lane)
+      const unsigned mw = marks[lane & 15];
       int count = 0;
-      for (int t = 0; t * 64 < nb; ++t) {
-        const unsigned wl = marks[2 * t], wh = marks[2 * t + 1];  // (16 words: nb <= 512)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const unsigned wl = (unsigned)__builtin_amdgcn_readlane((int)mw, 2 * t);
+        const unsigned wh = (unsigned)__builtin_amdgcn_readlane((int)mw, 2 * t + 1);
         const unsigned long long mk = ((unsigned long long)wh << 32) | wl;  // wave-uniform
         if ((mk >> lane) & 1ull) {
-          const int at = count + __builtin_popcountll(mk & below);
+          const int at = count + (int)__builtin_amdgcn_mbcnt_hi(wh, __builtin_amdgcn_mbcnt_lo(wl, 0u));
           if (at < TW_LAZY_CAP) list[at] = (unsigned short)(64 * t + lane);
         }
         count += __builtin_popcountll(mk);
