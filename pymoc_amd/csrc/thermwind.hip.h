@@ -985,8 +985,10 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
   // the nodes; eight ballots over the marks then list the marked classes in ascending order.
   bool lazy = false;
   int n_need = 0;
-  constexpr bool TW_KEEP_J = P <= 2;
-  int jkeep[TW_KEEP_J ? 2 * P : 1];
+  constexpr bool TW_KEEP_J = P <= 4;
+  unsigned jkeep[TW_KEEP_J ? P : 1];  // (j + 1 of a level's two profiles in the halves of a word)
+#pragma unroll
+  for (int p = 0; p < (TW_KEEP_J ? P : 1); ++p) jkeep[p] = 0u;
   const unsigned short *lazy_list = reinterpret_cast<const unsigned short *>(s_gbot + 8);
   if constexpr (TW_NBLK != 0) {
     lazy = chain_order && a.psib == nullptr && a.bgrid == nullptr && (ops & PM_TW_PSIBZ) != 0 &&
@@ -1010,7 +1012,7 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
             atomicOr(&marks[j >> 5], (1u << (j & 31)) | ((j1 >> 5) == (j >> 5) ? 1u << (j1 & 31) : 0u));
             if ((j1 >> 5) != (j >> 5)) atomicOr(&marks[j1 >> 5], 1u << (j1 & 31));
           }
-          if constexpr (TW_KEEP_J) jkeep[2 * p + c] = j;
+          if constexpr (TW_KEEP_J) jkeep[p] |= (unsigned)(j + 1) << (16 * c);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -1184,8 +1186,9 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
     if (i < nz && m_ok) {
       double p1, p2;
       if (TW_KEEP_J && lazy) {  // (the intervals found when the classes were marked)
-        p1 = interp_uniform_at(b1e[p], jkeep[TW_KEEP_J ? 2 * p : 0], lin, s_psib, nb);
-        p2 = interp_uniform_at(b2e[p], jkeep[TW_KEEP_J ? 2 * p + 1 : 0], lin, s_psib, nb);
+        const unsigned jw = jkeep[TW_KEEP_J ? p : 0];
+        p1 = interp_uniform_at(b1e[p], (int)(jw & 0xffffu) - 1, lin, s_psib, nb);
+        p2 = interp_uniform_at(b2e[p], (int)(jw >> 16) - 1, lin, s_psib, nb);
       } else {
         p1 = interp_uniform(b1e[p], lin, s_psib, nb, rstep);
         p2 = interp_uniform(b2e[p], lin, s_psib, nb, rstep);
