@@ -159,6 +159,14 @@ int pm_graph_destroy(pm_graph_t graph);
                               kappa_profile a one-step launch on a large batch keeps only b and
                               weff of a column in flight (24 nz B per column-step)               */
 
+#define PM_COLS_DIV3_PROVEN 2 /* pm_columns.reserved, batch-wide HINT (with PM_COLS_ALL_UNIFORM_AREA): the
+                              caller has established with pm_div3_proven() that EVERY static
+                              denominator of the batch's column step -- the grid spacings z[i+1] -
+                              z[i], the centred spacings 0.5 ((z[i+1] - z[i]) + (z[i] - z[i-1])) and
+                              every column's Area -- admits the 3-instruction exact quotient
+                              (below).  Fused launches then divide in 3 instead of 4 instructions;
+                              results are bit-identical (the quotient is the IEEE one).           */
+
 typedef struct pm_columns {
   int32_t ncols;         /* independent columns in the batch                      */
   int32_t nz;            /* levels per column (2 <= nz <= 1024)                   */
@@ -609,6 +617,37 @@ int pm_comm_barrier(pm_comm_t comm, pm_stream_t stream);
  * mantissas at the all-ones / all-zeros / half-way edges); bitwise mismatches counted. */
 int pm_selftest_fastdiv(uint64_t seed, int32_t blocks, int32_t per_thread, int32_t emax,
                         uint64_t *tested, uint64_t *mismatches);
+
+/* Host function (no device work): *proven = 1 when, for EVERY one of the n denominators, the
+ * 3-instruction quotient  y = RN(1/d); q0 = RN(a y); r = fma(-d, q0, a); q = fma(r, y, q0)  is the
+ * correctly rounded a / d for every numerator a (finite operands whose quotient and residual stay
+ * normal).  Only numerators whose quotient lies within 3 * 2^-53 ulp of a rounding boundary could
+ * fail; for a given d they are the <= ~12 solutions of a congruence on the integer mantissas,
+ * which the function enumerates and runs through the very sequence (pymoc_hip.hip: div3_proof).
+ * Zero, subnormal and non-finite denominators are "not proven".  `candidates` (may be NULL)
+ * receives the number of numerators tested.  What a caller establishes before it sets
+ * PM_COLS_DIV3_PROVEN.  Replaces nothing of the reference (which divides in NumPy); it licenses
+ * a cheaper instruction sequence for column.py:235-247's three divisions.                       */
+int pm_div3_proven(const double *d, int64_t n, int32_t *proven, int64_t *candidates);
+
+/* The proof above takes y = RN(1/d); the kernels form y on the DEVICE, whose fp64 `/` is not
+ * correctly rounded in every case (see pm_selftest_div3).  *ok = 1 when the device's 1.0 / d[i]
+ * equals the host's IEEE quotient bit for bit for all n host-side denominators (one small launch;
+ * the kernels' prologues evaluate the same expression).  A caller sets PM_COLS_DIV3_PROVEN only
+ * when both pm_div3_proven and pm_recip_check hold for the batch's denominators.               */
+int pm_recip_check(const double *d, int64_t n, int32_t *ok);
+
+/* debug/test: the DEVICE's 3-instruction quotient against the HOST's IEEE `/` on the candidate
+ * numerators of `ndenoms` random denominators (uniform mantissas, mantissas next to 1 and 2,
+ * mantissas with trailing zeros; numerators of both signs, rescaled) plus two arbitrary numerators
+ * each: `mismatches` must be 0.  `unproven` = denominators the host proof rejected (their
+ * candidates are tested all the same).  `device_div_off` = pairs on which the device's own
+ * `a / d` differs from the host's quotient: NOT zero on gfx950 -- about 1e-4 of these
+ * near-midpoint quotients come out one ulp off (its final correction does not use a correctly
+ * rounded reciprocal); for an arbitrary operand pair that is a ~1e-19 event.                    */
+int pm_selftest_div3(uint64_t seed, int32_t ndenoms, uint64_t *tested, uint64_t *mismatches,
+                     uint64_t *unproven, uint64_t *device_div_off,
+                     double *one_bad_pair /* {a, d} of a mismatch, or NULL */);
 
 /* debug/test: the wave scans of the GM boundary-value solve (DPP row steps + row joins: element
  * prefix / suffix scans, the affine suffix scan, the node-count prefix sum) against the same

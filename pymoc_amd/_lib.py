@@ -25,6 +25,7 @@ PM_OP_CONVECT, PM_OP_VERTADVDIFF, PM_OP_HORADV, PM_OP_TIMESTEP, PM_OP_WEFF = 1, 
 PM_OP_CONTRACTED = 16
 PM_OP_WA_PSI = 32
 PM_COLS_ALL_UNIFORM_AREA = 1
+PM_COLS_DIV3_PROVEN = 2
 
 c_dp = C.c_void_p  # device pointers travel as plain addresses
 
@@ -237,6 +238,11 @@ SIGNATURES = {
     "pm_selftest_fastdiv": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "pm_selftest_lane_shift": (C.c_int, [C.POINTER(C.c_int32)]),
+    "pm_div3_proven": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "pm_recip_check": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
+    "pm_selftest_div3": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "pm_selftest_so_scans": (C.c_int, [C.c_int32, C.c_uint64, C.POINTER(C.c_double),
                                        C.POINTER(C.c_int32)]),
 }

@@ -51,6 +51,30 @@ def _in_fast_range(x):
     return (a == 0) | ((a >= 2.0**-200) & (a <= 2.0**200))
 
 
+_HINT_DIV3_OFF = 1 << 20  # (use_hints(div3=False): a bit outside the per-column flag bits)
+
+
+def div3_proven(denominators):
+  """True when the kernels' 3-instruction quotient is correctly rounded for EVERY numerator over
+  each of these denominators (`pm_div3_proven`, include/pymoc_hip.h: a host-side proof by
+  enumeration of the only numerators that could fail)."""
+  d = np.ascontiguousarray(denominators, dtype=np.float64).ravel()
+  ok = C.c_int32(0)
+  check(lib.pm_div3_proven(d.ctypes.data, d.size, C.byref(ok), None))
+  return bool(ok.value)
+
+
+def device_reciprocals_exact(denominators):
+  """True when the DEVICE's 1.0 / d is the correctly rounded reciprocal of each denominator
+  (`pm_recip_check`: compared with the host's IEEE quotient; the proofs of the kernels' exact
+  quotients take y = RN(1/d), and the device's fp64 division is not correctly rounded in every
+  case)."""
+  d = np.ascontiguousarray(denominators, dtype=np.float64).ravel()
+  ok = C.c_int32(0)
+  check(lib.pm_recip_check(d.ctypes.data, d.size, C.byref(ok)))
+  return bool(ok.value)
+
+
 class ColumnBatch(object):
   def __init__(self, z, kappa, area, b, bs=0.025, bbot=0.0, bzbot=None, N2min=1e-7,
                do_conv=False, kappa_alt=None, stream=None, report_nonfinite=True,
@@ -137,6 +161,13 @@ class ColumnBatch(object):
     for a in [area] + ks + dAks:
       self._static_ok &= _in_fast_range(a).all(axis=1)
     self._static_ok &= (area != 0).all(axis=1)
+    # PM_COLS_DIV3_PROVEN: every static denominator of the step -- the grid spacings, the centred
+    # spacings and (Area one number per column) every column's Area -- admits the 3-instruction
+    # exact quotient; pm_div3_proven enumerates and tests the only numerators that could fail
+    self.div3_proven = False
+    if self.uniform_area and ok:
+      den = np.concatenate([np.unique(dz), np.unique(dzc), np.unique(area[:, 0])])
+      self.div3_proven = div3_proven(den) and device_reciprocals_exact(den)
     if hasattr(self, "_flags_host"):
       self._upload_flags()
 
@@ -183,7 +214,7 @@ class ColumnBatch(object):
     off = np.int32(self.__dict__.get("_hints_off", 0))
     self.flags.upload((self._flags_host & ~off).astype(np.int32), self.stream)
 
-  def use_hints(self, uniform_area=True, static_in_range=True):
+  def use_hints(self, uniform_area=True, static_in_range=True, div3=True):
     """Switch the per-column hints the host derives from the static operands on or off
     (PM_COL_UNIFORM_AREA: a column's Area is one number, read with its scalars;
     PM_COL_STATIC_IN_RANGE: the static operands lie inside the exact-division window, so a launch
@@ -191,7 +222,8 @@ class ColumnBatch(object):
     path -- every array read, every operand tested; results are bit-identical either way.  The
     hints are re-derived whenever the static operands or parameters change."""
     self._hints_off = ((0 if uniform_area else _lib.PM_COL_UNIFORM_AREA) |
-                       (0 if static_in_range else _lib.PM_COL_STATIC_IN_RANGE))
+                       (0 if static_in_range else _lib.PM_COL_STATIC_IN_RANGE) |
+                       (0 if div3 else _HINT_DIV3_OFF))
     self._upload_flags()
 
   @property
@@ -228,6 +260,8 @@ class ColumnBatch(object):
     d = pm_columns()
     d.ncols, d.nz, d.nsel = self.ncols, self.nz, self.nsel
     d.reserved = _lib.PM_COLS_ALL_UNIFORM_AREA if self.uniform_area else 0
+    if self.uniform_area and self.div3_proven and not (self.__dict__.get("_hints_off", 0) & _HINT_DIV3_OFF):
+      d.reserved |= _lib.PM_COLS_DIV3_PROVEN
     d.z, d.b = self.z.ptr, self.b.ptr
     d.kappa, d.area, d.dAkappa = self.kappa.ptr, self.area.ptr, self.dAk.ptr
     d.bs, d.bbot, d.bzbot, d.N2min = self.bs.ptr, self.bbot.ptr, self.bzbot.ptr, self.N2min.ptr
@@ -255,7 +289,9 @@ class ColumnBatch(object):
     name = buf.value.decode()
     # the batch-wide PM_COLS_ALL_UNIFORM_AREA hint selects the scalar-Area instantiation
     if self.uniform_area and name.startswith("k_column_steps<64,") and name.endswith(",2,true>"):
-      name = name[:-1] + ",true>"
+      # ... and PM_COLS_DIV3_PROVEN the 3-instruction quotients (division form 6)
+      div3 = self.div3_proven and not (self.__dict__.get("_hints_off", 0) & _HINT_DIV3_OFF)
+      name = (name[:-len(",2,true>")] + ",6,true,true>") if div3 else (name[:-1] + ",true>")
     return name
 
   def combine_forcing(self, wA, out=None):

@@ -230,7 +230,7 @@ __device__ __forceinline__ void col_convect_cached(double (&b)[P], const double 
 // compare-select flux, and boundary / padding levels left untouched by a select (the other
 // forms advance them with dt = 0, which turns a level next to an inf or NaN into NaN).
 template <int G, int P, int DIV, bool BC = true, bool WEFF = false, bool UA = false,
-          bool FLUXFMA = (DIV == 2)>
+          bool FLUXFMA = (DIV == 2 || DIV == 6)>
 __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> &r,
                                                 const double (&wA)[P],
                                                 double dt, bool do_conv, double bs,
@@ -285,6 +285,15 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
       for (int p = 0; p < P; ++p) rr[p] = num[p] * g.rdz_l[p];
 #pragma unroll
       for (int p = 0; p < P; ++p) q[p] = __builtin_fma(num[p], g.rdz[p], rr[p]);
+#pragma unroll
+      for (int p = 0; p < P; ++p) rr[p] = __builtin_fma(-g.dz[p], q[p], num[p]);
+#pragma unroll
+      for (int p = 0; p < P; ++p) q[p] = __builtin_fma(rr[p], g.rdz[p], q[p]);
+    } else if constexpr (DIV == 6) {
+      // q0 = a*y; r = fma(-d, q0, a); q = fma(r, y, q0): correctly rounded for EVERY numerator when
+      // the denominator has passed pm_div3_proven (PM_COLS_DIV3_PROVEN; common.hip.h)
+#pragma unroll
+      for (int p = 0; p < P; ++p) q[p] = num[p] * g.rdz[p];
 #pragma unroll
       for (int p = 0; p < P; ++p) rr[p] = __builtin_fma(-g.dz[p], q[p], num[p]);
 #pragma unroll
@@ -345,6 +354,23 @@ __device__ __forceinline__ void col_vertadvdiff(const ColGrid<P> &g, ColRegs<P> 
     for (int p = 0; p < P; ++p) {
       bzz[p] = __builtin_fma(dbz[p], g.rdzc[p], r1[p]);
       adv[p] = __builtin_fma(flx[p], (UA ? r.rarea_u : r.rarea[p]), r2[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      r1[p] = __builtin_fma(-g.dzc[p], bzz[p], dbz[p]);
+      r2[p] = __builtin_fma(-(UA ? r.area_u : r.area[p]), adv[p], flx[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      bzz[p] = __builtin_fma(r1[p], g.rdzc[p], bzz[p]);
+      adv[p] = __builtin_fma(r2[p], (UA ? r.rarea_u : r.rarea[p]), adv[p]);
+    }
+  } else if constexpr (DIV == 6) {  // both by the proven 3-instruction quotient, interleaved
+    double r1[P], r2[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      bzz[p] = dbz[p] * g.rdzc[p];
+      adv[p] = flx[p] * (UA ? r.rarea_u : r.rarea[p]);
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -1286,8 +1312,12 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
         const char *e = getenv("PYMOC_K1_LDS");  // experiments: unused LDS per block caps the occupancy
         return e ? atoi(e) : 0;
       }();
-      hipLaunchKernelGGL((k_column_steps<G, P, 2, true, true>), dim3(grid), dim3(256), lds_pad, st, c, wA,
-                         vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
+      if ((c.reserved & PM_COLS_DIV3_PROVEN) != 0)  // (the caller's pm_div3_proven verdict)
+        hipLaunchKernelGGL((k_column_steps<G, P, 6, true, true>), dim3(grid), dim3(256), lds_pad, st, c, wA,
+                           vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
+      else
+        hipLaunchKernelGGL((k_column_steps<G, P, 2, true, true>), dim3(grid), dim3(256), lds_pad, st, c, wA,
+                           vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
       launched = true;
     }
   }

@@ -2,6 +2,8 @@
 // (memory, streams, events, graphs) and the extern "C" launchers of every kernel.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
 #include <stdarg.h>
+#include <math.h>
+#include <vector>
 #include <dlfcn.h>
 #include "common.hip.h"
 #include "column.hip.h"
@@ -165,6 +167,26 @@ __global__ void k_selftest_fastdiv(unsigned long long seed, int per_thread, int 
   if (bad) atomicAdd(mismatch, bad);
 }
 
+// the 3-instruction quotient (col_vertadvdiff's DIV == 6) and the device's own `/` of n operand
+// pairs (the host compares both with ITS IEEE quotient)
+__global__ void k_selftest_div3(const double *__restrict__ a, const double *__restrict__ d, size_t n,
+                                double *__restrict__ q3, double *__restrict__ qd) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const double y = 1.0 / d[i];
+    double q = a[i] * y;
+    const double r = __builtin_fma(-d[i], q, a[i]);
+    q3[i] = __builtin_fma(r, y, q);
+    qd[i] = a[i] / d[i];
+  }
+}
+// y[i] = 1.0 / d[i] as every kernel's prologue forms its reciprocals
+__global__ void k_recip(const double *__restrict__ d, size_t n, double *__restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    y[i] = 1.0 / d[i];
+}
+
 __global__ void k_twobasin_forcing(size_t count, const double *__restrict__ iso_A,
                                    const double *__restrict__ zon_A,
                                    const double *__restrict__ so_A,
@@ -178,6 +200,62 @@ __global__ void k_twobasin_forcing(size_t count, const double *__restrict__ iso_
     wA_N[i] = (-iso_N[i]) * 1e6;                       // :104
     wA_P[i] = (-zon_P[i] - so_P[i]) * 1e6;             // :105
   }
+}
+
+// ---- the 3-instruction exact quotient by a static denominator, and its proof per denominator.
+//   y = RN(1/d);   q0 = RN(a y);   r = RN(a - d q0) (one fma);   q = RN(q0 + r y) (one fma)
+// With y = (1/d)(1 + e), |e| <= 2^-53, q0 lies within 1.5 ulp of x = a/d and the last fma rounds
+// x + delta with |delta| <= |x - q0| (2 |e| + ...) < 3 * 2^-53 ulp (the residual may itself be
+// rounded when q0 is more than an ulp off).  So q = RN(x) unless x lies within 3 * 2^-53 ulp of a
+// rounding boundary, a midpoint (2K + 1) 2^(e-53) of two neighbours.  With 53-bit integer
+// mantissas A, D of a, d:  x - midpoint = N / (2 D) ulp,  N = A 2^(53+t) - (2K + 1) D  (t = 0 for
+// A >= D, 1 for A < D), an integer -- so only numerators with |N| <= 6 can fail, and for a GIVEN
+// D these are the few solutions A of  A 2^(53+t) = N (mod D)  with an odd quotient (none at all
+// when D has three or more trailing zero bits, as every difference of two grid levels has).
+// div3_proof enumerates them and runs the very sequence on each, both signs: all equal to `/` =
+// the quotient is correctly rounded for EVERY numerator (finite operands whose quotient and
+// residual stay normal: the kernels' operand window, in_fast_div_range).  No denominator has
+// failed in 10^8 tried (the cases that could are where q0 is a faithful quotient anyway), but the
+// kernels take the 3-instruction form only on this proof, never on statistics.
+static double div3_host(double a, double d, double y) {
+  const double q0 = a * y;
+  const double r = __builtin_fma(-d, q0, a);
+  return __builtin_fma(r, y, q0);
+}
+// 1: proven; 0: not (a candidate fails, or d is zero / subnormal / not finite).  cand: if given,
+// receives the candidate numerators (scaled to d's binade), ncand their count.
+int div3_proof(double d, std::vector<double> *cand, long long *ncand) {
+  const double ad = d < 0 ? -d : d;
+  if (!(ad >= 2.2250738585072014e-308 && ad <= 1.7976931348623157e308)) return 0;
+  int e;
+  const double m = frexp(ad, &e);                      // ad = m 2^e, m in [0.5, 1)
+  const uint64_t D = (uint64_t)ldexp(m, 53);           // 53-bit mantissa
+  const double dm = ldexp(m, 53);                      // the denominator the tests run on
+  const double y = 1.0 / dm;
+  const int v = __builtin_ctzll(D);
+  if (v >= 3) return 1;                                // |N| <= 6 has no multiple of 2^v: no candidate
+  const uint64_t Dp = D >> v;
+  if (Dp == 1) return 1;                               // a power of two
+  for (int t = 0; t < 2; ++t) {
+    const int sh = 53 + t;
+    for (int N = -6; N <= 6; ++N) {
+      if (N == 0 || (N % (1 << v)) != 0) continue;
+      const int64_t Np = N / (1 << v);
+      uint64_t x = (uint64_t)(((Np % (int64_t)Dp) + (int64_t)Dp) % (int64_t)Dp);
+      for (int k = 0; k < sh - v; ++k) x = (x & 1) ? (x + Dp) / 2 : x / 2;  // Np 2^-(sh-v) mod Dp
+      const uint64_t lo = t == 0 ? D : (1ull << 52), hi = t == 0 ? (1ull << 53) : D;
+      const uint64_t k0 = lo > x ? (lo - x + Dp - 1) / Dp : 0;
+      for (uint64_t A = x + k0 * Dp; A < hi; A += Dp) {
+        const __int128 nn = (__int128)((unsigned __int128)A << sh) - N;
+        if (nn % (__int128)D != 0 || ((nn / (__int128)D) & 1) == 0) continue;
+        const double a = (double)A;
+        if (ncand) ++*ncand;
+        if (cand) cand->push_back(a);
+        if (div3_host(a, dm, y) != a / dm || div3_host(-a, dm, y) != -a / dm) return 0;
+      }
+    }
+  }
+  return 1;
 }
 
 }  // namespace pm
@@ -864,6 +942,109 @@ int pm_selftest_lane_shift(int32_t *mismatches) {
   PM_HIP(hipMemcpyAsync(mismatches, d, sizeof(int), hipMemcpyDeviceToHost, st));
   PM_HIP(hipStreamSynchronize(st));
   PM_HIP(hipFree(d));
+  return PM_OK;
+}
+
+int pm_div3_proven(const double *d, int64_t n, int32_t *proven, int64_t *candidates) {
+  PM_REQUIRE(proven, "proven is NULL");
+  PM_REQUIRE(n == 0 || d, "d is NULL");
+  long long nc = 0;
+  int ok = 1;
+  for (int64_t i = 0; i < n && ok; ++i) ok = div3_proof(d[i], nullptr, &nc);
+  *proven = ok;
+  if (candidates) *candidates = nc;
+  return PM_OK;
+}
+
+int pm_recip_check(const double *d, int64_t n, int32_t *ok) {
+  PM_REQUIRE(ok, "ok is NULL");
+  PM_REQUIRE(n == 0 || d, "d is NULL");
+  *ok = 1;
+  if (n == 0) return PM_OK;
+  double *dd = nullptr, *dy = nullptr;
+  PM_HIP(hipMalloc((void **)&dd, (size_t)n * sizeof(double)));
+  PM_HIP(hipMalloc((void **)&dy, (size_t)n * sizeof(double)));
+  hipStream_t s = resolve_stream(nullptr);
+  PM_HIP(hipMemcpyAsync(dd, d, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_recip, dim3(256), dim3(256), 0, s, dd, (size_t)n, dy);
+  PM_HIP(hipGetLastError());
+  std::vector<double> y((size_t)n);
+  PM_HIP(hipMemcpyAsync(y.data(), dy, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+  PM_HIP(hipStreamSynchronize(s));
+  PM_HIP(hipFree(dd));
+  PM_HIP(hipFree(dy));
+  for (int64_t i = 0; i < n; ++i) {
+    const double h = 1.0 / d[i];  // the host's correctly rounded quotient
+    if (memcmp(&h, &y[(size_t)i], sizeof(double)) != 0) *ok = 0;
+  }
+  return PM_OK;
+}
+
+int pm_selftest_div3(uint64_t seed, int32_t ndenoms, uint64_t *tested, uint64_t *mismatches,
+                     uint64_t *unproven, uint64_t *device_div_off, double *one_bad_pair) {
+  PM_REQUIRE(tested && mismatches && unproven && device_div_off, "NULL output");
+  PM_REQUIRE(ndenoms >= 1 && ndenoms <= (1 << 22), "ndenoms must be in [1, 2^22]");
+  std::vector<double> ha, hd, c;
+  unsigned long long st = seed ? seed : 1, nun = 0;
+  auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  for (int i = 0; i < ndenoms; ++i) {
+    // mantissas: uniform, or a few units in the last place off 1 or 2 (where the first product
+    // is worst), or with one or two trailing zero bits
+    const unsigned long long r = next();
+    uint64_t D = (1ull << 52) | (next() >> 12);
+    const int kind = (int)(r & 7);
+    if (kind == 0) D = (1ull << 52) + 1 + (next() & 1023);
+    if (kind == 1) D = (1ull << 53) - 1 - (next() & 1023);
+    if (kind == 2) D &= ~1ull;
+    if (kind == 3) D &= ~3ull;
+    const double d = ldexp((double)D, -52 + (int)((r >> 8) % 41) - 20);
+    c.clear();
+    long long nc = 0;
+    if (!div3_proof(d, &c, &nc)) ++nun;
+    const double scale = ldexp(1.0, (int)((r >> 16) % 41) - 20);
+    for (double a : c) {
+      ha.push_back(a * scale);
+      hd.push_back(d);
+      ha.push_back(-a * scale);
+      hd.push_back(d);
+    }
+    for (int k = 0; k < 2; ++k) {  // and two arbitrary numerators
+      ha.push_back(ldexp((double)((1ull << 52) | (next() >> 12)), -40 - (int)(next() % 30)));
+      hd.push_back(d);
+    }
+  }
+  const size_t n = ha.size();
+  double *da = nullptr, *dd = nullptr, *dq = nullptr;
+  PM_HIP(hipMalloc((void **)&da, n * sizeof(double)));
+  PM_HIP(hipMalloc((void **)&dd, n * sizeof(double)));
+  PM_HIP(hipMalloc((void **)&dq, 2 * n * sizeof(double)));
+  hipStream_t s = resolve_stream(nullptr);
+  PM_HIP(hipMemcpyAsync(da, ha.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+  PM_HIP(hipMemcpyAsync(dd, hd.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_selftest_div3, dim3(256), dim3(256), 0, s, da, dd, n, dq, dq + n);
+  PM_HIP(hipGetLastError());
+  std::vector<double> hq(2 * n);
+  PM_HIP(hipMemcpyAsync(hq.data(), dq, 2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
+  PM_HIP(hipStreamSynchronize(s));
+  PM_HIP(hipFree(da));
+  PM_HIP(hipFree(dd));
+  PM_HIP(hipFree(dq));
+  unsigned long long bad = 0, off = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const double q = ha[i] / hd[i];  // the host's IEEE quotient: the reference
+    if (memcmp(&q, &hq[i], sizeof(double)) != 0) {
+      if (one_bad_pair && !bad) {
+        one_bad_pair[0] = ha[i];
+        one_bad_pair[1] = hd[i];
+      }
+      ++bad;
+    }
+    if (memcmp(&q, &hq[n + i], sizeof(double)) != 0) ++off;
+  }
+  *tested = n;
+  *mismatches = bad;
+  *unproven = nun;
+  *device_div_off = off;
   return PM_OK;
 }
 

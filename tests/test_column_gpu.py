@@ -391,6 +391,36 @@ def test_precombined_forcing_and_uniform_area_bitwise(gpu, nsteps):
     assert np.array_equal(pre.get_b()[m], ref), m
 
 
+@pytest.mark.parametrize("nsteps", [3, 24, 250])
+def test_three_instruction_quotient_hint_bitwise(gpu, nsteps):
+  """PM_COLS_DIV3_PROVEN (the host proves the 3-instruction quotient for the batch's grid spacings
+  and Areas: ColumnBatch.div3_proven) selects `k_column_steps<64,P,6,...>`; without the hint the
+  4-instruction form `<64,P,2,...>` runs.  Same bits, and the oracle's."""
+  N = 2048
+  c = configs.config2(N=N)
+
+  def make():
+    return gpu.ColumnBatch(c["z"], c["kappa"], c["Area"], c["b0"], bs=c["bs"], bbot=c["bbot"],
+                           N2min=c["N2min"], do_conv=c["do_conv"])
+  fast, base = make(), make()
+  assert fast.div3_proven
+  base.use_hints(div3=False)
+  assert ",6,true,true>" in fast.kernel_name(nsteps) and ",2,true,true>" in base.kernel_name(nsteps)
+  wA = gpu.DeviceArray.from_host(c["wA"])
+  fast.steps(wA, c["dt"], nsteps)
+  base.steps(wA, c["dt"], nsteps)
+  got = fast.get_b()
+  assert np.array_equal(got, base.get_b())
+  for m in (0, 1, 7, N - 1):
+    ref = c["b0"][m].copy()
+    for _ in range(nsteps):
+      ref = O.column_timestep(c["z"], c["kappa"][m], c["Area"][m], ref, c["wA"][m], c["dt"],
+                              do_conv=bool(c["do_conv"][m]), bs=c["bs"][m],
+                              bbot=float(np.atleast_1d(c["bbot"])[m % np.size(c["bbot"])]),
+                              N2min=c["N2min"][m])
+    assert np.array_equal(got[m], ref), m
+
+
 @pytest.mark.parametrize("lanes", [16, 32, 64])
 @pytest.mark.parametrize("arith", ["exact", "contracted"])
 def test_forcing_formed_from_the_overturning_bitwise(gpu, lanes, arith):
