@@ -408,6 +408,11 @@ int pm_jn2018_bc_switch(const pm_jn2018_bc *bc, pm_stream_t stream);
                                 of one after the other on 64 lanes each.  Same arithmetic per
                                 level, bit-identical results; 65 <= nz <= 128 or 193 <= nz <= 224,
                                 other shapes ignore the hint.                                  */
+#define PM_JN_DIV3_PROVEN 16 /* hint of the uniform-Area kernel: pm_div3_proven and pm_recip_check hold
+                              for every static denominator of the fused loop -- the grid spacings and
+                              centred spacings of z, both columns' Area of every member, and the
+                              mixed layer's h, L and y[1] - y[0]: its quotients then take 3 instead
+                              of 4 instructions (bit-identical)                                    */
 typedef struct pm_jn2018 {
   int32_t n, hints, reserved1, reserved2;
   pm_columns cols;

@@ -65,6 +65,7 @@ class pm_thermwind(C.Structure):
  PM_SO_HAS_HTAPERBOT, PM_SO_TAU_ARRAY) = 1, 2, 4, 8, 16, 32, 64
 PM_SO_OP_EKMAN, PM_SO_OP_GM, PM_SO_OP_SOLVE = 1, 2, 3
 PM_JN_UNIFORM_AREA, PM_JN_CONTRACTED, PM_JN_SHARED_COEF, PM_JN_SPLIT_LANES = 1, 2, 4, 8
+PM_JN_DIV3_PROVEN = 16
 
 
 class pm_psi_so(C.Structure):

@@ -105,7 +105,20 @@ __device__ __forceinline__ double div_by_recip2(double a, double d, double yh, d
   return q;
 }
 
-// Operand window of the two forms above.  With every input of a column step (state, forcing,
+// The same quotient in 3 instructions from RN(1/d) alone.  q0 may be 1.5 ulp off, so this is NOT
+// covered by the theorem above for an arbitrary denominator -- but for a GIVEN d only the few
+// numerators whose quotient lies within 3 * 2^-53 ulp of a rounding boundary could fail, and the
+// host enumerates and tests them (pm_div3_proven, pymoc_hip.hip: div3_proof).  Used only for
+// STATIC denominators that have passed that proof (PM_COLS_DIV3_PROVEN / PM_JN_DIV3_PROVEN) and
+// whose device-side reciprocal the host has checked (pm_recip_check).
+__device__ __forceinline__ double div_by_recip3(double a, double d, double yh) {
+  double q = a * yh;
+  const double r = __builtin_fma(-d, q, a);
+  q = __builtin_fma(r, yh, q);
+  return q;
+}
+
+// Operand window of the forms above.  With every input of a column step (state, forcing,
 // coefficients, grid spacings, dt) either zero or of magnitude in [2^-200, 2^200], every
 // quotient, product and residual of the step stays at least 2^-600 and at most 2^1000 in
 // magnitude or is exactly zero, so no fma of the division sequences rounds into the subnormal

@@ -235,7 +235,9 @@ __device__ __forceinline__ void jf_convect(double (&b)[P], JfConv<P> &s, const d
 
 // Column.vertadvdiff (column.py:210-249) of one column, the bottom value already imposed.
 // Same operations in the same order as col_vertadvdiff<64, P, 2, ..., UA> (column.hip.h).
-template <int P, bool KAPREG>
+// D3 (PM_JN_DIV3_PROVEN): the three quotients in 3 instructions each (div_by_recip3) -- the low
+// parts of the reciprocals are then not even read.
+template <int P, bool KAPREG, bool D3 = false>
 __device__ __forceinline__ void jf_vertadvdiff(JfCol<P> &c, const double *lds, const double *ws,
                                                const double *kap, int lane, double dt) {
   using L = JfLds<P>;
@@ -243,14 +245,18 @@ __device__ __forceinline__ void jf_vertadvdiff(JfCol<P> &c, const double *lds, c
   const double nb0 = from_next_lane_z(c.b[0]);
 #pragma unroll
   for (int h = 0; h < P / 2; ++h) {
-    const double2 dz = jf_pair(lds + L::T_DZ, lane, h), y = jf_pair(lds + L::T_RDZ, lane, h),
-                  yl = jf_pair(lds + L::T_RDZL, lane, h);
+    const double2 dz = jf_pair(lds + L::T_DZ, lane, h), y = jf_pair(lds + L::T_RDZ, lane, h);
+    double2 yl = make_double2(0., 0.);
+    if constexpr (!D3) yl = jf_pair(lds + L::T_RDZL, lane, h);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int p = 2 * h + q;
       const double up = (p < P - 1) ? c.b[p + 1 < P ? p + 1 : p] : nb0;
       // 1/dz = 0 at and above the top level
-      bz[p] = div_by_recip2(up - c.b[p], q ? dz.y : dz.x, q ? y.y : y.x, q ? yl.y : yl.x);
+      if constexpr (D3)
+        bz[p] = div_by_recip3(up - c.b[p], q ? dz.y : dz.x, q ? y.y : y.x);
+      else
+        bz[p] = div_by_recip2(up - c.b[p], q ? dz.y : dz.x, q ? y.y : y.x, q ? yl.y : yl.x);
     }
     if (P > 2) __builtin_amdgcn_sched_barrier(0);  // one slot pair's tables live at a time
   }
@@ -262,8 +268,9 @@ __device__ __forceinline__ void jf_vertadvdiff(JfCol<P> &c, const double *lds, c
   const double2 ra = *reinterpret_cast<const double2 *>(ws + S_RAREA);  // {1/area, its low part}
 #pragma unroll
   for (int h = 0; h < P / 2; ++h) {
-    const double2 dzc = jf_pair(lds + L::T_DZC, lane, h), y = jf_pair(lds + L::T_RDZC, lane, h),
-                  yl = jf_pair(lds + L::T_RDZCL, lane, h);
+    const double2 dzc = jf_pair(lds + L::T_DZC, lane, h), y = jf_pair(lds + L::T_RDZC, lane, h);
+    double2 yl = make_double2(0., 0.);
+    if constexpr (!D3) yl = jf_pair(lds + L::T_RDZCL, lane, h);
     double2 kp;
     if constexpr (KAPREG)
       kp = make_double2(c.kap[2 * h], c.kap[2 * h + 1]);
@@ -274,11 +281,12 @@ __device__ __forceinline__ void jf_vertadvdiff(JfCol<P> &c, const double *lds, c
       const int p = 2 * h + q;
       const double dn = (p > 0) ? bz[p > 0 ? p - 1 : 0] : pbz;
       const double bzz =
-          div_by_recip2(bz[p] - dn, q ? dzc.y : dzc.x, q ? y.y : y.x, q ? yl.y : yl.x);  // :238
+          D3 ? div_by_recip3(bz[p] - dn, q ? dzc.y : dzc.x, q ? y.y : y.x)
+             : div_by_recip2(bz[p] - dn, q ? dzc.y : dzc.x, q ? y.y : y.x, q ? yl.y : yl.x);  // :238
       // upwind flux (-weff) bz* (column.py:242-246): exactly one of wn, wp is -weff, the other
       // product an exact zero
       const double flx = __builtin_fma(c.wn[p], bz[p], c.wp[p] * dn);
-      const double adv = div_by_recip2(flx, area, ra.x, ra.y);
+      const double adv = D3 ? div_by_recip3(flx, area, ra.x) : div_by_recip2(flx, area, ra.x, ra.y);
       c.b[p] = c.b[p] + dt * (adv + (q ? kp.y : kp.x) * bzz);  // column.py:245-249
     }
     if (P > 2) __builtin_amdgcn_sched_barrier(0);
@@ -486,7 +494,7 @@ __device__ __forceinline__ void jf_block_tables(const pm_jn2018 &a, double dt, d
 // that code (inlined as a second leg it cost 6.5 % of config 5).  Returns the steps done.
 // CT: the columns step in the contracted form (tolerance mode); otherwise every operation is
 // the reference's, in its order.
-template <int P, bool CT, bool VEC, bool SYNC, bool IEEE>
+template <int P, bool CT, bool VEC, bool SYNC, bool IEEE, bool D3 = false>
 __device__ __forceinline__ int jf_member_run(const pm_jn2018 &a, double dt, int nsteps, int s0,
                                               int m_raw, double *lds, int wstride, int wave,
                                               int lane) {
@@ -747,9 +755,9 @@ __device__ __forceinline__ int jf_member_run(const pm_jn2018 &a, double dt, int 
         jf_vertadvdiff_ieee<P, false>(cn, lds, ws + S_NN, wl + L::W_KN, lane_o, dt, nz);
       } else {
         __builtin_amdgcn_sched_barrier(0);
-        jf_vertadvdiff<P, true>(cb, lds, ws + S_B, nullptr, lane_o, dt);
+        jf_vertadvdiff<P, true, D3>(cb, lds, ws + S_B, nullptr, lane_o, dt);
         __builtin_amdgcn_sched_barrier(0);
-        jf_vertadvdiff<P, false>(cn, lds, ws + S_NN, wl + L::W_KN, lane_o, dt);
+        jf_vertadvdiff<P, false, D3>(cn, lds, ws + S_NN, wl + L::W_KN, lane_o, dt);
         __builtin_amdgcn_sched_barrier(0);
       }
       return true;
@@ -863,9 +871,10 @@ __device__ __forceinline__ int jf_member_run(const pm_jn2018 &a, double dt, int 
             const double num = -ps * 1e6 * d;
             // num / h / L / dy, each quotient correctly rounded (k0..k4 = {1/h lo, 1/h | h,
             // 1/L lo | 1/L, L | 1/dy lo, 1/dy | dy, s/2})
-            const double q1 = div_by_recip2(num, k1.x, k0.y, k0.x);
-            const double q2 = div_by_recip2(q1, k2.y, k2.x, k1.y);
-            const double t = div_by_recip2(q2, k4.x, k3.y, k3.x);
+            // (D3: h, L and dy have passed the host's proof as well)
+            const double q1 = D3 ? div_by_recip3(num, k1.x, k0.y) : div_by_recip2(num, k1.x, k0.y, k0.x);
+            const double q2 = D3 ? div_by_recip3(q1, k2.y, k2.x) : div_by_recip2(q1, k2.y, k2.x, k1.y);
+            const double t = D3 ? div_by_recip3(q2, k4.x, k3.y) : div_by_recip2(q2, k4.x, k3.y, k3.x);
             adv = (ml_int && ps != 0. && ps == ps) ? t : 0.;
           }
           bs = bs + dt * (flux + adv);  // every tendency uses the old bs
@@ -952,14 +961,14 @@ __device__ __forceinline__ int jf_member_run(const pm_jn2018 &a, double dt, int 
   return s;
 }
 
-template <int P, bool CT, bool VEC>
+template <int P, bool CT, bool VEC, bool D3 = false>
 __global__ __launch_bounds__(64 * JF_WAVES) JF_OCC_ATTR
 void k_jn2018_fast(pm_jn2018 a, double dt, int nsteps) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   jf_block_tables<P>(a, dt, lds, wave, lane);
-  jf_member_run<P, CT, VEC, true, false>(a, dt, nsteps, 0, blockIdx.x * JF_WAVES + wave, lds,
+  jf_member_run<P, CT, VEC, true, false, D3>(a, dt, nsteps, 0, blockIdx.x * JF_WAVES + wave, lds,
                                          JfLds<P>::PER_WAVE, wave, lane);
 }
 
@@ -1857,8 +1866,16 @@ static int launch_fast(const pm_jn2018 &a, double dt, int nsteps, hipStream_t st
 #define JF_LAUNCH(CT_, VEC_)                                                                  \
   hipLaunchKernelGGL((k_jn2018_fast<P, CT_, VEC_>), dim3(grid), dim3(64 * JF_WAVES), lds, st, a, \
                      dt, nsteps)
+  // PM_JN_DIV3_PROVEN: the caller's proof for every static denominator (pm_div3_proven)
+  const bool d3 = (a.hints & PM_JN_DIV3_PROVEN) != 0 && !ct;
   if (split)
     ;
+  else if (d3 && vec)
+    hipLaunchKernelGGL((k_jn2018_fast<P, false, true, true>), dim3(grid), dim3(64 * JF_WAVES), lds, st,
+                       a, dt, nsteps);
+  else if (d3)
+    hipLaunchKernelGGL((k_jn2018_fast<P, false, false, true>), dim3(grid), dim3(64 * JF_WAVES), lds, st,
+                       a, dt, nsteps);
   else if (ct && vec)
     JF_LAUNCH(true, true);
   else if (ct)

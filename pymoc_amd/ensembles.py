@@ -503,6 +503,20 @@ class JN2018Ensemble(object):
     with launch_span(self.timer, "k_jn2018_steps", self.stream):
       check(lib.pm_jn2018_steps(self._C.byref(d), self.dt, int(nsteps), _sh(self.stream)))
 
+  def _div3(self):
+    """PM_JN_DIV3_PROVEN: the columns' static denominators (ColumnBatch.div3_proven) and the
+    mixed layer's h, L and y[1] - y[0] admit the 3-instruction exact quotient."""
+    if not hasattr(self, "_div3_ok"):
+      from .columns import div3_proven, device_reciprocals_exact, _HINT_DIV3_OFF
+      t = self.ml
+      den = np.array([t.h, t.L, t.y_host[1] - t.y_host[0]], dtype=np.float64)
+      a = np.abs(den)
+      self._div3_ok = bool(self.cols.uniform_area and self.cols.div3_proven and
+                           not (self.cols.__dict__.get("_hints_off", 0) & _HINT_DIV3_OFF) and
+                           ((a >= 2.0**-200) & (a <= 2.0**200)).all() and
+                           div3_proven(den) and device_reciprocals_exact(den))
+    return self._div3_ok
+
   def _jn_descriptor(self):
     from ._lib import pm_jn2018, pm_so_ml
     d = pm_jn2018()
@@ -514,6 +528,8 @@ class JN2018Ensemble(object):
       d.hints |= _lib.PM_JN_SHARED_COEF
     if self.split_lanes:
       d.hints |= _lib.PM_JN_SPLIT_LANES
+    if self._div3():
+      d.hints |= _lib.PM_JN_DIV3_PROVEN
     d.cols = self.cols.descriptor()
     d.wA, d.Psi_SO = self.wA.ptr, self.so.Psi.ptr
     d.Psi_res_b, d.Psi_res_n = self.tw.psibz1.ptr, self.tw.psibz2.ptr
