@@ -369,14 +369,16 @@ def bench_config2(args, env):
     weffa = aff.combine_forcing(wAb)
     msa = time_calls(lambda: aff.steps(weffa, dt, 1, lanes_per_col=args.lanes, precombined=True),
                      20, stream, Event, warm=3)
+    sname = ("k_column_stream<2,5,true,true,true,true>" if aff.div3_proven
+             else "k_column_stream<2,5,true,true,true>")  # (PM_COLS_DIV3_PROVEN: 3-instruction quotients)
     del aff, weffa
     gbps = 24.0 * nz * Cb / (msa * 1e-3) / 1e9
-    cs = (prof.get("c2s/k_column_stream<2,5,true,true,true>")
+    cs = (prof.get("c2s/" + sname) or prof.get("c2s/k_column_stream<2,5,true,true,true>")
           or prof.get("c2s/k_column_stream<2,5,true,true>") or {})
     out["hbm_regime"] = {
         "bound": "hbm", "achieved": sig(gbps), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": sig(gbps / HBM_PEAK_GBPS, 4), "traffic": cs.get("hbm_bytes_per_launch"),
-        "columns": Cb, "bytes_per_column_step": 24 * nz, "kernel": "k_column_stream<2,5,true,true,true>",
+        "columns": Cb, "bytes_per_column_step": 24 * nz, "kernel": sname,
         "kernel_us": sig(msa * 1e3), "value": sig(Cb / (msa * 1e-3)),
         "kappa_streamed_32nz": {"kernel_us": sig(msw * 1e3), "value": sig(Cb / (msw * 1e-3)),
                                 "frac": sig(32.0 * nz * Cb / (msw * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},

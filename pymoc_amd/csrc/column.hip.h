@@ -1049,7 +1049,8 @@ __device__ __forceinline__ void col_stage_load(ColStage<P> &s, const pm_columns 
 // two levels per lane move as ONE 16-byte access at a loop-invariant lane offset from a scalar
 // base.  (load_levels takes that decision per call; inside the ring the compiler turned it
 // into both address forms, selects, and two 8-byte loads.)
-template <int P, int D, bool AFF = false, bool LEAN = false, bool VEC = false>
+// D3 (lean form; PM_COLS_DIV3_PROVEN): the step's three quotients by the proven 3-instruction form
+template <int P, int D, bool AFF = false, bool LEAN = false, bool VEC = false, bool D3 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LEAN && P <= 2 && D <= 5) ? 4 : 1)))
 void k_column_stream(pm_columns c,
                                                        const double *__restrict__ wA_g,
@@ -1144,6 +1145,9 @@ void k_column_stream(pm_columns c,
         col_pin<P>(r.b);
         if (__builtin_expect(slow, 0))
           col_vertadvdiff<64, P, 0>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot, bzbot, lane, nz);
+        else if constexpr (LEAN && D3)
+          col_vertadvdiff<64, P, 6, true, false, true, false>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot,
+                                                              bzbot, lane, nz);
         else if constexpr (LEAN)  // (Area one number: its reciprocal came with the wave's scalars)
           col_vertadvdiff<64, P, 5, true, false, true>(g, r, wA, dt, do_conv, bs, bbot, use_bzbot,
                                                        bzbot, lane, nz);
@@ -1271,8 +1275,12 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
         if constexpr (P == 2)
           vec = (c.nz & 1) == 0 && ((((unsigned long long)c.b) | ((unsigned long long)wA)) & 15ull) == 0ull &&
                 !getenv("PYMOC_STREAM_NO_VEC");
+        const bool d3 = (c.reserved & PM_COLS_DIV3_PROVEN) != 0;
         if constexpr (P == 2) {
-          if (vec)
+          if (vec && d3)
+            hipLaunchKernelGGL((k_column_stream<P, 5, true, true, true, true>), dim3((wl + 3) / 4),
+                               dim3(256), 0, st, c, wA, dt, nsteps, cl, dt_ok, weff_in);
+          else if (vec)
             hipLaunchKernelGGL((k_column_stream<P, 5, true, true, true>), dim3((wl + 3) / 4), dim3(256),
                                0, st, c, wA, dt, nsteps, cl, dt_ok, weff_in);
         }
