@@ -1050,7 +1050,13 @@ __device__ __forceinline__ void col_stage_load(ColStage<P> &s, const pm_columns 
 // base.  (load_levels takes that decision per call; inside the ring the compiler turned it
 // into both address forms, selects, and two 8-byte loads.)
 // D3 (lean form; PM_COLS_DIV3_PROVEN): the step's three quotients by the proven 3-instruction form
-template <int P, int D, bool AFF = false, bool LEAN = false, bool VEC = false, bool D3 = false>
+// CPWU > 0 (the launcher: every wave has exactly CPWU columns): the wave's columns as
+// STRAIGHT-LINE code.  Inside a loop the compiler's wait-count bookkeeping forgets the order of
+// the loads issued before the loop header, and the first use of a ring stage waits for every
+// load but the two issued since (s_waitcnt vmcnt(2)): the ring drained once per D columns.
+// Unrolled, every wait names exactly the loads that lie between.
+template <int P, int D, bool AFF = false, bool LEAN = false, bool VEC = false, bool D3 = false,
+          int CPWU = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LEAN && P <= 2 && D <= 5) ? 4 : 1)))
 void k_column_stream(pm_columns c,
                                                        const double *__restrict__ wA_g,
@@ -1099,11 +1105,8 @@ void k_column_stream(pm_columns c,
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (col0 + d < cend) issue(ring[d], col0 + d);
-  for (int colb = col0; colb < cend; colb += D) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int col = colb + d;
-      if (col >= cend) break;  // wave-uniform
+  unsigned nf_bits = 0u;  // (CPWU: the columns' non-finite flags, written once at the end)
+  auto one_column = [&](int col, int d, bool prefetch, int kk) {
       ColRegs<P> r;
       double wA[P];
 #pragma unroll
@@ -1126,7 +1129,15 @@ void k_column_stream(pm_columns c,
         }
         r.rarea[p] = r.rarea_l[p] = 0.;
       }
-      if (col + D < cend) issue(ring[d], col + D);  // keep D columns' loads in flight
+      // keep D columns' loads in flight.  UNCONDITIONALLY (the wave's last columns re-request its
+      // last one, a cache hit): under `if (col + D < cend)` the loaded values had to be MERGED
+      // into the ring's registers, and the compiler waited for every prefetch right after
+      // issuing it (s_waitcnt vmcnt(0) behind the loads: the ring never overlapped anything)
+      if (CPWU > 0) {
+        if (prefetch) issue(ring[d], col + D);  // (compile-time after unrolling: no tail re-reads)
+      } else {
+        issue(ring[d], col + D < cend ? col + D : cend - 1);
+      }
       const int k = col - col0;
       const int flags = flags_of(k);
       const bool do_conv = (flags & PM_COL_DO_CONV) != 0;
@@ -1182,9 +1193,24 @@ void k_column_stream(pm_columns c,
           }
         }
       }
-      if (c.nonfinite) {
+      if (CPWU > 0) {
+        nf_bits |= (__ballot(bad) != 0ull ? 1u : 0u) << kk;
+      } else if (c.nonfinite) {
         const unsigned long long m = __ballot(bad);
         if (lane == 0) c.nonfinite[col] = (m != 0ull) ? 1 : 0;
+      }
+  };
+  if constexpr (CPWU > 0) {
+#pragma unroll
+    for (int k = 0; k < CPWU; ++k) one_column(col0 + k, k % D, k + D < CPWU, k);
+    if (c.nonfinite && lane < CPWU) c.nonfinite[col0 + lane] = (int)((nf_bits >> lane) & 1u);
+  } else {
+    for (int colb = col0; colb < cend; colb += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int col = colb + d;
+        if (col >= cend) break;  // wave-uniform
+        one_column(col, d, true, 0);
       }
     }
   }
@@ -1270,14 +1296,48 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
           cl = c.ncols / 16384;
           cl = cl < 2 ? 2 : (cl > 16 ? 16 : cl);
         }
-        const unsigned wl = (unsigned)((c.ncols + cl - 1) / cl);
+        unsigned wl = (unsigned)((c.ncols + cl - 1) / cl);
         bool vec = false;
         if constexpr (P == 2)
           vec = (c.nz & 1) == 0 && ((((unsigned long long)c.b) | ((unsigned long long)wA)) & 15ull) == 0ull &&
                 !getenv("PYMOC_STREAM_NO_VEC");
         const bool d3 = (c.reserved & PM_COLS_DIV3_PROVEN) != 0;
+        // every wave exactly 8 columns: the straight-line instantiation (CPWU).  Measured at 262144
+        // columns (profiles/r05/stream_variants.log): ring depth 3 / 4 / 5 / 6 at 16 columns per wave
+        // 132 / 133 / 133 / 134 us -- with a ring that works its depth no longer matters -- and depth
+        // 5 at 8 / 16 / 32 columns per wave 127 / 133 / 268 us
+        const bool u16 = vec && c.ncols % 8 == 0 && c.ncols >= 8 * 4096 &&
+                         !getenv("PYMOC_STREAM_LOOP") && !getenv("PYMOC_STREAM_CPW");
+        if (u16) {
+          cl = 8;
+          wl = (unsigned)(c.ncols / 8);
+        }
+#ifdef PM_STREAM_VARIANTS  // experiments (profiles/r05/stream_variants.sh): ring depth x columns per wave
         if constexpr (P == 2) {
-          if (vec && d3)
+          const char *ev = getenv("PYMOC_STREAM_VARIANT");
+          if (ev && vec && d3) {
+            const int dv = atoi(ev), cv = strchr(ev, ',') ? atoi(strchr(ev, ',') + 1) : 16;
+            const unsigned wv = (unsigned)((c.ncols + cv - 1) / cv);
+#define PM_SV(DD, CC)                                                                              \
+  if (dv == DD && cv == CC && c.ncols % CC == 0) {                                                 \
+    hipLaunchKernelGGL((k_column_stream<P, DD, true, true, true, true, CC>), dim3((wv + 3) / 4),   \
+                       dim3(256), 0, st, c, wA, dt, nsteps, cv, dt_ok, weff_in);                   \
+    PM_HIP(hipGetLastError());                                                                     \
+    return PM_OK;                                                                                  \
+  }
+            PM_SV(4, 16) PM_SV(6, 16) PM_SV(5, 32) PM_SV(5, 8) PM_SV(3, 16)
+#undef PM_SV
+          }
+        }
+#endif
+        if constexpr (P == 2) {
+          if (vec && u16 && d3)
+            hipLaunchKernelGGL((k_column_stream<P, 5, true, true, true, true, 8>), dim3((wl + 3) / 4),
+                               dim3(256), 0, st, c, wA, dt, nsteps, cl, dt_ok, weff_in);
+          else if (vec && u16)
+            hipLaunchKernelGGL((k_column_stream<P, 5, true, true, true, false, 8>), dim3((wl + 3) / 4),
+                               dim3(256), 0, st, c, wA, dt, nsteps, cl, dt_ok, weff_in);
+          else if (vec && d3)
             hipLaunchKernelGGL((k_column_stream<P, 5, true, true, true, true>), dim3((wl + 3) / 4),
                                dim3(256), 0, st, c, wA, dt, nsteps, cl, dt_ok, weff_in);
           else if (vec)
