@@ -516,6 +516,8 @@ __device__ __forceinline__ void psib_sorted_pass(const double *cell, int nc, int
     for (int j = 0; j < JT; ++j) {
       const int kl = __builtin_amdgcn_readfirstlane(kz[j]);
       const int kfirst = kl > k0 ? kl : k0;
+      // (unrolled by four: the reads of four steps go out together, the additions follow)
+#pragma unroll 4
       for (int t = 1; t <= ((full - 1 - kfirst) >> 3); ++t) {
         const int kk = kz[j] + 8 * t;
         v[j] += cv.u((cut[j] && kk < full) ? kk : SENT);
@@ -947,6 +949,7 @@ __device__ __forceinline__ void tw_member(const pm_thermwind &a, int ops, int m_
         S[p] = (k < sfull[p]) ? s_cell[(size_t)k * 6 + 4] : 0.;
       }
       const int tmax = ((TW_NBLK == 2 ? (n2 > nc_ - n2 ? n2 : nc_ - n2) : nc_) >> 3) - 1;
+#pragma unroll 4
       for (int t = 1; t <= tmax; ++t) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
