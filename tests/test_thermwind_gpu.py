@@ -96,6 +96,114 @@ def test_thermwind_ragged_sizes_vs_oracle_bitwise(gpu, nz, nb):
     assert np.array_equal(o2[m], r2, equal_nan=True), (nz, nb, m)
 
 
+def _chain_kinds(b1, b2, Psi, bgrid):
+  """Which branch of the round-5 class sums a member takes (the kernel's staging logic restated:
+  thermwind.hip.h, tw_member)."""
+  u = -(Psi[1:] - Psi[:-1])
+  north = u < 0
+  bot, top = np.where(north, b2[:-1], b1[:-1]), np.where(north, b2[1:], b1[1:])
+  d = top - bot
+  ok = (d >= 0) & np.isfinite(u)
+  ok[:-1] &= top[:-1] <= bot[1:]
+  bad = np.nonzero(~ok)[0]
+  K0 = int(bad.max()) + 1 if bad.size else 0
+  kinds = set()
+  if K0 > 2 or not (np.isfinite(b1).all() and np.isfinite(b2).all()):
+    return {"tiles"}
+  kinds.add("chain" if K0 == 0 else "K0=%d" % K0)
+  flat = np.nonzero((d == 0) & (np.arange(d.size) >= K0))[0]
+  if flat.size:
+    kinds.add("flat-in-chain")
+    if np.isin(top[flat], bgrid).any():
+      kinds.add("class-on-flat-cell")
+  x = np.concatenate([b1, b2])
+  j = np.clip(np.searchsorted(bgrid, x, side="right") - 1, 0, bgrid.size - 1)
+  need = np.zeros(bgrid.size, bool)
+  need[j] = True
+  need[np.minimum(j + 1, bgrid.size - 1)] = True
+  nn = int(need.sum())
+  kinds.add("listed<=128" if nn <= 128 else ("listed<=192" if nn <= 192 else "listed>192"))
+  return kinds
+
+
+@pytest.mark.parametrize("nz,nb", [(100, 500), (81, 500), (200, 500), (100, 130), (200, 300), (64, 500),
+                                   (17, 40)])
+def test_class_sums_in_chain_order_and_listed_classes_bitwise(gpu, nz, nb):
+  """Round 5's class sums (thermwind.hip.h, psib_sorted_pass): members whose upstream cells lie in
+  chain order are summed class by class -- all classes when `psib` is asked for, only the classes
+  Psibz's interpolations read when it is not (`store_psib=False`).  Engineered members for every
+  branch: a smooth stratification; a convecting northern column (cells of zero thickness inside
+  the chain); zero-thickness and inverted bottom cells (the no-flux bottom boundary: cells below
+  K0); a class exactly ON a zero-thickness cell's buoyancy (NaN, H6); a cell out of order in the
+  interior (the tiles); a user-assigned Psi with several sign changes; levels spread so that
+  Psibz asks for more than 128 / 192 classes.  psib / bgrid / Psibz bitwise against the oracle,
+  and the listed-class run's Psibz bitwise against the all-classes run's."""
+  from pymoc_amd import _lib
+  from pymoc_amd.device import DeviceArray
+  rng = np.random.default_rng(nz * 13 + nb)
+  z = np.linspace(-4000., 0., nz)
+  prof = np.exp(z / 300.)
+  n = 14
+  b1 = 0.03 * prof[None, :] * (1 + 0.1 * rng.random((n, 1))) + 1e-5 * np.sort(rng.random((n, nz)), axis=1)
+  b2 = 0.004 * prof[None, :] * (1 + 0.1 * rng.random((n, 1))) + 1e-6 * np.sort(rng.random((n, nz)), axis=1)
+  top = max(2, nz // 5)
+  b2[1, -top:] = b2[1, -top]                 # convecting northern column: uniform on top
+  b1[2, 0] = b1[2, 1]                          # zero-thickness bottom cells
+  b2[2, 0] = b2[2, 1]
+  b2[3, 0] = b2[3, 1] + 1e-9                   # inverted bottom cell
+  b1[3, 0] = b1[3, 1] + 1e-9
+  b2[4, :3] = min(b1[4].min(), b2[4, 3]) - 1e-6  # the row's minimum sits on two zero-thickness cells
+  b1[5, nz // 2] = b1[5, nz // 2 - 2]          # a level out of order in the interior (both columns:
+  b2[5, nz // 2] = b2[5, nz // 2 - 2]          # whichever is upstream there)
+  b1[6] = np.linspace(0.0, 0.03, nz)           # levels spread evenly over the class grid
+  b2[6] = np.linspace(0.001, 0.029, nz)
+  b1[7] = np.linspace(0.0, 0.03, nz)**1.5 / 0.03**0.5
+  b2[7] = b1[7] * 0.5
+  b2[8] = b1[8]                                # identical columns
+  b2[9, 1] = b2[9, 0]                          # only the northern bottom cell of zero thickness
+  b1[10, 1] = b1[10, 2] + 1e-9                 # cell 1 inverted, cell 0 regular (K0 = 2)
+  b2[10, 1] = b2[10, 2] + 1e-9
+  ncl = max(2, (2 * nz) // 5)                    # 129 ... 192 classes asked for: three per lane
+  b1[11] = np.concatenate([np.linspace(0, 1e-5, nz - ncl), np.linspace(2e-4, 0.03, ncl)])
+  b2[11] = np.concatenate([np.linspace(0, 0.5e-5, nz - ncl), np.linspace(1e-4, 0.0299, ncl)])
+  f = rng.uniform(0.8e-4, 1.4e-4, n)
+  ops = _lib.PM_TW_SOLVE | _lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ
+  d1, d2 = DeviceArray.from_host(b1), DeviceArray.from_host(b2)
+  full = gpu.ThermwindBatch(z, n, f=f, nb=nb)
+  full.update(d1, d2, ops=ops)                 # psib stored: every class summed
+  lazy = gpu.ThermwindBatch(z, n, f=f, nb=nb)
+  lazy.update(d1, d2, ops=ops, store_psib=False)
+  Psi, bgrid, psib = full.Psi.download(), full.bgrid.download(), full.psib.download()
+  o1, o2 = full.psibz1.download(), full.psibz2.download()
+  assert np.array_equal(lazy.psibz1.download(), o1, equal_nan=True)
+  assert np.array_equal(lazy.psibz2.download(), o2, equal_nan=True)
+  kinds = set()
+  for m in range(n):
+    rP = O.thermwind_solve(z, b1[m], b2[m], f[m])
+    rg, rp, r1, r2 = O.thermwind_psibz(b1[m], b2[m], rP, nb)
+    assert np.array_equal(Psi[m], rP) and np.array_equal(bgrid[m], rg), (nz, nb, m)
+    assert np.array_equal(psib[m], rp, equal_nan=True), (nz, nb, m)
+    assert np.array_equal(o1[m], r1, equal_nan=True) and np.array_equal(o2[m], r2, equal_nan=True), (nz, nb, m)
+    kinds |= _chain_kinds(b1[m], b2[m], rP, rg)
+  if (nz, nb) == (100, 500):  # the engineered members do reach the branches they are meant for
+    assert {"chain", "flat-in-chain", "K0=1", "K0=2", "tiles", "class-on-flat-cell", "listed<=128",
+            "listed<=192", "listed>192"} <= kinds, kinds
+  # a user-assigned overturning with several sign changes (the upstream column switches often)
+  Psi_u = np.sin(np.linspace(0, 7 * np.pi, nz))[None, :] * rng.uniform(0.5, 2., (n, 1))
+  Psi_u[:, 0] = Psi_u[:, -1] = 0.
+  ops2 = _lib.PM_TW_PSIB | _lib.PM_TW_PSIBZ
+  for batch, kw in ((full, {}), (lazy, dict(store_psib=False))):
+    batch.Psi.upload(Psi_u)
+    batch.update(d1, d2, ops=ops2, **kw)
+  o1, o2, psib = full.psibz1.download(), full.psibz2.download(), full.psib.download()
+  assert np.array_equal(lazy.psibz1.download(), o1, equal_nan=True)
+  assert np.array_equal(lazy.psibz2.download(), o2, equal_nan=True)
+  for m in range(n):
+    rg, rp, r1, r2 = O.thermwind_psibz(b1[m], b2[m], Psi_u[m], nb)
+    assert np.array_equal(psib[m], rp, equal_nan=True), (nz, nb, m)
+    assert np.array_equal(o1[m], r1, equal_nan=True) and np.array_equal(o2[m], r2, equal_nan=True), (nz, nb, m)
+
+
 def test_psi_thermwind_wrapper_api(gpu):
   g = load_golden("thermwind")
   p = "c03_"
