@@ -46,15 +46,18 @@ def test_twobasin_update_pairs_side_by_side_equal_four_launches(gpu):
   of the seven sampled fields at the driver's cadence."""
   c = configs.config_twobasin(N=96)
   s = gpu.Stream()
-  a = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48)
+  a = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48)  # whole intervals replayed
+  assert a._use_graph                                                      # from a hipGraph
+  a2 = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48, use_graph=False)
   b = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48, overlap_updates=False)
   d = gpu.TwoBasinEnsemble(c, keep_history=True, diag_iters=48, overlap_updates=False)
   d._pairs = False  # four separate launches (what round 4 ran)
-  for e in (a, b, d):
+  for e in (a, a2, b, d):
     e.run(130)
     e.gather_diagnostics()
+  assert a._graph is not None and a2._graph is None
   sa = a.state()
-  for e in (b, d):
+  for e in (a2, b, d):
     st = e.state()
     for k in FIELDS:
       assert np.array_equal(sa[k], st[k]), k
