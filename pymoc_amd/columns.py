@@ -259,8 +259,10 @@ class ColumnBatch(object):
   def descriptor(self):
     d = pm_columns()
     d.ncols, d.nz, d.nsel = self.ncols, self.nz, self.nsel
-    d.reserved = _lib.PM_COLS_ALL_UNIFORM_AREA if self.uniform_area else 0
-    if self.uniform_area and self.div3_proven and not (self.__dict__.get("_hints_off", 0) & _HINT_DIV3_OFF):
+    off = self.__dict__.get("_hints_off", 0)
+    ua = self.uniform_area and not (off & _lib.PM_COL_UNIFORM_AREA)  # (use_hints(uniform_area=False))
+    d.reserved = _lib.PM_COLS_ALL_UNIFORM_AREA if ua else 0
+    if ua and self.div3_proven and not (off & _HINT_DIV3_OFF):
       d.reserved |= _lib.PM_COLS_DIV3_PROVEN
     d.z, d.b = self.z.ptr, self.b.ptr
     d.kappa, d.area, d.dAkappa = self.kappa.ptr, self.area.ptr, self.dAk.ptr
@@ -288,9 +290,11 @@ class ColumnBatch(object):
                                     int(ops), int(bool(horadv)), buf, 96))
     name = buf.value.decode()
     # the batch-wide PM_COLS_ALL_UNIFORM_AREA hint selects the scalar-Area instantiation
-    if self.uniform_area and name.startswith("k_column_steps<64,") and name.endswith(",2,true>"):
+    off = self.__dict__.get("_hints_off", 0)
+    if (self.uniform_area and not (off & _lib.PM_COL_UNIFORM_AREA) and
+        name.startswith("k_column_steps<64,") and name.endswith(",2,true>")):
       # ... and PM_COLS_DIV3_PROVEN the 3-instruction quotients (division form 6)
-      div3 = self.div3_proven and not (self.__dict__.get("_hints_off", 0) & _HINT_DIV3_OFF)
+      div3 = self.div3_proven and not (off & _HINT_DIV3_OFF)
       name = (name[:-len(",2,true>")] + ",6,true,true>") if div3 else (name[:-1] + ",true>")
     return name
 

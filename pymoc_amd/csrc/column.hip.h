@@ -1055,8 +1055,11 @@ __device__ __forceinline__ void col_stage_load(ColStage<P> &s, const pm_columns 
 // the loads issued before the loop header, and the first use of a ring stage waits for every
 // load but the two issued since (s_waitcnt vmcnt(2)): the ring drained once per D columns.
 // Unrolled, every wait names exactly the loads that lie between.
+// WEFFT / UABT (the straight-line non-lean forms): `weff_in` and the batch-wide uniform-Area hint as
+// compile-time facts, so that a stage's loads are UNCONDITIONAL (a load under a run-time condition
+// is merged into the ring's registers by moves, which wait for it: see the refill above).
 template <int P, int D, bool AFF = false, bool LEAN = false, bool VEC = false, bool D3 = false,
-          int CPWU = 0>
+          int CPWU = 0, int WEFFT = -1, int UABT = -1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LEAN && P <= 2 && D <= 5) ? 4 : 1)))
 void k_column_stream(pm_columns c,
                                                        const double *__restrict__ wA_g,
@@ -1090,6 +1093,14 @@ void k_column_stream(pm_columns c,
       const size_t base = (size_t)col * nz;
       load_levels<P>(st.b, c.b + base, lane, nz);
       load_levels<P>(st.wA, wA_g + base, lane, nz);
+    } else if constexpr (CPWU > 0 && WEFFT >= 0 && UABT >= 0) {
+      const int sel = __builtin_amdgcn_readlane(sc.sel, k);
+      const size_t base = (size_t)col * nz, sbase = ((size_t)sel * c.ncols + col) * nz;
+      load_levels<P>(st.b, c.b + base, lane, nz);
+      load_levels<P>(st.wA, wA_g + base, lane, nz);
+      if constexpr (!AFF) load_levels<P>(st.kap, c.kappa + sbase, lane, nz);
+      if constexpr (UABT == 0) load_levels<P>(st.area, c.area + base, lane, nz);
+      if constexpr (WEFFT == 0) load_levels<P>(st.dAk, c.dAkappa + sbase, lane, nz);
     } else {
       col_stage_load<P, AFF>(st, c, wA_g, col, lane, weff_in, flags_of(k),
                              __builtin_amdgcn_readlane(sc.sel, k), lane_value(sc.area0, k));
@@ -1123,6 +1134,15 @@ void k_column_stream(pm_columns c,
           r.rarea_u = lane_value(sc.ra, col - col0);
           r.rarea_lu = lane_value(sc.ral, col - col0);
           r.dAk[p] = 0.0;  // weff - 0 = weff, exactly
+        } else if constexpr (CPWU > 0 && WEFFT >= 0 && UABT >= 0) {
+          if constexpr (UABT == 1)
+            r.area[p] = lane_value(sc.area0, col - col0);
+          else
+            r.area[p] = ring[d].area[p];
+          if constexpr (WEFFT == 1)
+            r.dAk[p] = 0.0;  // weff - 0 = weff, exactly
+          else
+            r.dAk[p] = ring[d].dAk[p];
         } else {
           r.area[p] = ring[d].area[p];
           r.dAk[p] = ring[d].dAk[p];
@@ -1347,6 +1367,22 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
         if (!vec)
           hipLaunchKernelGGL((k_column_stream<P, 5, true, true>), dim3((wl + 3) / 4), dim3(256), 0,
                              st, c, wA, dt, nsteps, cl, dt_ok, weff_in);
+      }
+      else if (P == 2 && !aff && c.ncols % 8 == 0 && c.ncols >= 8 * 4096 && !getenv("PYMOC_STREAM_LOOP") &&
+               !getenv("PYMOC_STREAM_CPW") &&
+               ((weff_in && (c.reserved & PM_COLS_ALL_UNIFORM_AREA)) ||
+                (!weff_in && !(c.reserved & PM_COLS_ALL_UNIFORM_AREA)))) {
+        // the straight-line forms of the two other regimes the bench reports: forcing precombined
+        // and every Area one number (32 nz B per column-step), and the C-ABI default (48 nz B)
+        const unsigned w8 = (unsigned)(c.ncols / 8);
+        if constexpr (P == 2) {
+          if (weff_in)
+            hipLaunchKernelGGL((k_column_stream<P, 3, false, false, false, false, 8, 1, 1>),
+                               dim3((w8 + 3) / 4), dim3(256), 0, st, c, wA, dt, nsteps, 8, dt_ok, weff_in);
+          else
+            hipLaunchKernelGGL((k_column_stream<P, 2, false, false, false, false, 8, 0, 0>),
+                               dim3((w8 + 3) / 4), dim3(256), 0, st, c, wA, dt, nsteps, 8, dt_ok, weff_in);
+        }
       }
       else if (weff_in && aff)
         hipLaunchKernelGGL((k_column_stream<P, 4, true>), dim3((waves + 3) / 4), dim3(256), 0, st, c,
