@@ -246,7 +246,10 @@ typedef struct pm_thermwind {
   const double *f;      /* [n]     Coriolis parameter                            */
   double *Psi;          /* [n][nz] overturning, Sv (out with PM_TW_SOLVE, else in)*/
   double *bgrid;        /* [n][nb] out, may be NULL                              */
-  double *psib;         /* [n][nb] out, may be NULL                              */
+  double *psib;         /* [n][nb] out, may be NULL.  With bgrid AND psib NULL and PM_TW_PSIBZ
+                           a member whose upstream cells lie in chain order sums only the
+                           classes Psibz's interpolations read (70-135 of 500 on BASELINE's
+                           ensembles): psibz1 / psibz2 / wA1 / wA2 are the same bits either way */
   double *psibz1;       /* [n][nz] out, may be NULL                              */
   double *psibz2;       /* [n][nz] out, may be NULL                              */
   const double *Psi_SO; /* [n][nz] in, may be NULL                               */
