@@ -371,8 +371,8 @@ def bench_config2(args, env):
                      20, stream, Event, warm=3)
     # (PM_COLS_DIV3_PROVEN: 3-instruction quotients; 8 columns per wave as straight-line code when
     # the batch divides: column.hip.h, launch_column_steps)
-    sname = "k_column_stream<2,5,true,true,true,%s%s>" % (
-        "true" if aff.div3_proven else "false", ",8" if Cb % 8 == 0 and Cb >= 8 * 4096 else "")
+    sname = "k_column_stream<2,5,true,true,true,%s,%d,-1,-1>" % (
+        "true" if aff.div3_proven else "false", 8 if Cb % 8 == 0 and Cb >= 8 * 4096 else 0)
     del aff, weffa
     gbps = 24.0 * nz * Cb / (msa * 1e-3) / 1e9
     cs = (prof.get("c2s/" + sname) or prof.get("c2s/k_column_stream<2,5,true,true,true>")
