@@ -467,20 +467,24 @@ class JN2018Ensemble(object):
 
   def _update(self):
     b_basin, b_north = self.cols.b.ptr, self.cols.b.ptr + self._off
+    # psib / bgrid go to HBM only in the updates a diagnostics recorder samples right after (every
+    # Diag_iters steps, run_JansenNadeau_2018.py:218-226); all the other updates sum only the
+    # classes Psibz reads (thermwind.hip.h)
+    rec = self.recorder
+    store = rec is not None and self.ii % rec.Diag_iters == 0
     if self._one_update_launch:
       # PsiSO.solve + AMOC.solve / Psibz of a member by one wave, ONE launch (pm_so_tw_update)
       ds = self.so.descriptor(b_basin, self.ml.bs)
       dw = self.tw.descriptor(b_basin, b_north, Psi_SO=self.so.Psi, wA1=self.wA.ptr,
-                              wA2=self.wA.ptr + self._off, store_psib=self.recorder is not None)
+                              wA2=self.wA.ptr + self._off, store_psib=store)
       with launch_span(self.timer, "k_so_tw_update", self.stream):
         _lib.check(_lib.lib.pm_so_tw_update(self._C.byref(ds), self._C.byref(dw), _TW_ALL,
                                             _sh(self.stream)))
       return
     with launch_span(self.timer, "k_psi_so", self.stream):
       self.so.update(b_basin, self.ml.bs)
-    # psib / bgrid go to HBM only when a diagnostics recorder will read them
     with launch_span(self.timer, "k_thermwind", self.stream):
-      self.tw.update(b_basin, b_north, ops=_TW_ALL, store_psib=self.recorder is not None,
+      self.tw.update(b_basin, b_north, ops=_TW_ALL, store_psib=store,
                      Psi_SO=self.so.Psi, wA1=self.wA.ptr,
                      wA2=self.wA.ptr + self._off)
 
