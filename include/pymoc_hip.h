@@ -146,6 +146,17 @@ int pm_graph_destroy(pm_graph_t graph);
                                 wA_north = -Psi_iso * 1e6 (example_twocol_plusSO.py:105-106) --
                                 what pm_thermwind_update's wA1 / wA2 outputs hold, without the
                                 thermal wind having to wait for Psi_SO.  Launches of >= 3 steps. */
+#define PM_OP_WA_TWOBASIN 64 /* modifier for the two-basin driver's three-column ensembles (rows [0, n)
+                                Atlantic, [n, 2n) north, [2n, 3n) Pacific, n = ncols / 3): `wA` holds the
+                                AMOC's isopycnal overturnings [2n][nz] (rows [0, n) on the Atlantic
+                                column, [n, 2n) on the northern one), `vdx_in` (horadv's slot: no horadv
+                                with this modifier) the zonal overturning's [2n][nz] (Atlantic, Pacific)
+                                and `b_in` the two sectors' Psi_SO [2n][nz] (Atlantic, Pacific), all
+                                in Sv; the kernel forms the driver's forcing itself,
+                                  wA_Atl = (iso_A + zon_A - SO_A) * 1e6,  wA_north = -iso_N * 1e6,
+                                  wA_Pac = (-zon_P - SO_P) * 1e6   (twobasin_NadeauJansen.py:103-105)
+                                -- pm_twobasin_forcing's operations, without that launch.  Launches
+                                of >= 3 steps.                                                     */
 #define PM_OP_CONTRACTED 16  /* modifier, OPT-IN tolerance mode: launches of >= 3 plain timesteps
                                 (one wave per column, nz <= 256) use the contracted update
                                 b_i += cu_i (b_{i+1}-b_i) + cl_i (b_i-b_{i-1}) with per-launch

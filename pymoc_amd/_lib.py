@@ -24,6 +24,7 @@ PM_EQ_HFREE, PM_EQ_HAS_BBOT, PM_EQ_KAPPA_ARRAY, PM_EQ_PSI_ARRAY = 1, 2, 4, 8
 PM_OP_CONVECT, PM_OP_VERTADVDIFF, PM_OP_HORADV, PM_OP_TIMESTEP, PM_OP_WEFF = 1, 2, 4, 7, 8
 PM_OP_CONTRACTED = 16
 PM_OP_WA_PSI = 32
+PM_OP_WA_TWOBASIN = 64
 PM_COLS_ALL_UNIFORM_AREA = 1
 PM_COLS_DIV3_PROVEN = 2
 

@@ -309,7 +309,8 @@ class ColumnBatch(object):
     return out
 
   def steps(self, wA, dt, nsteps=1, ops=_lib.PM_OP_TIMESTEP, vdx_in=None, b_in=None,
-            lanes_per_col=0, precombined=False, arith="exact", psi_forcing=None):
+            lanes_per_col=0, precombined=False, arith="exact", psi_forcing=None,
+            twobasin_forcing=None):
     """nsteps x (convect -> vertadvdiff -> horadv) with wA held fixed, one launch.
     precombined: `wA` is the output of `combine_forcing` (PM_OP_WEFF).
     psi_forcing=(Psi_iso [ncols, nz], Psi_SO [ncols/2, nz] or None) instead of `wA` (two-column
@@ -325,6 +326,17 @@ class ColumnBatch(object):
       raise ValueError("arith must be 'exact' or 'contracted'")
     if vdx_in is not None and b_in is None:
       raise TypeError('b_in is needed if vdx_in is provided')  # column.py:348
+    if twobasin_forcing is not None:
+      # (iso [2n, nz], zon [2n, nz], Psi_SO [2n, nz]) of a three-column two-basin ensemble instead
+      # of `wA`: the kernel forms the driver's forcing itself (PM_OP_WA_TWOBASIN, >= 3 steps)
+      if vdx_in is not None or precombined or wA is not None or psi_forcing is not None:
+        raise ValueError("twobasin_forcing replaces wA and excludes horadv / precombined forcing")
+      iso, zon, pso = twobasin_forcing
+      d = self.descriptor()
+      check(lib.pm_column_steps(C.byref(d), iso.ptr, zon.ptr, pso.ptr, float(dt), int(nsteps),
+                                int(ops | _lib.PM_OP_WA_TWOBASIN), int(lanes_per_col),
+                                _sh(self.stream)))
+      return
     if psi_forcing is not None:
       if vdx_in is not None or precombined or wA is not None:
         raise ValueError("psi_forcing replaces wA and excludes horadv / precombined forcing")

@@ -850,8 +850,34 @@ __global__ __launch_bounds__(256) void k_column_steps(
       }
     }
   }
-  if (vdx_g) load_levels<P>(vdx, vdx_g + base, lg, nz);
-  if (bin_g && !(ops & PM_OP_WA_PSI)) load_levels<P>(bin, bin_g + base, lg, nz);  // (WA_PSI: Psi_SO, read above)
+  if constexpr (PLAIN) {
+    if (ops & PM_OP_WA_TWOBASIN) {
+      // the two-basin driver's forcing (twobasin_NadeauJansen.py:103-105; pm_twobasin_forcing's
+      // operations): wA_g / vdx_g / bin_g = the AMOC's, the zonal overturning's isopycnal
+      // overturnings and the two sectors' Psi_SO, [2 ncols / 3][nz] each; wA holds wA_g's row
+      const int third = c.ncols / 3;
+      if (col < third) {  // Atlantic: (iso_A + zon_A - SO_A) * 1e6
+        double zon[P], pso[P];
+        load_levels<P>(zon, vdx_g + base, lg, nz);
+        load_levels<P>(pso, bin_g + base, lg, nz);
+#pragma unroll
+        for (int p = 0; p < P; ++p) wA[p] = (wA[p] + zon[p] - pso[p]) * 1e6;
+      } else if (col < 2 * third) {  // north: -iso_N * 1e6
+#pragma unroll
+        for (int p = 0; p < P; ++p) wA[p] = (-wA[p]) * 1e6;
+      } else {  // Pacific: (-zon_P - SO_P) * 1e6 (rows [n, 2n) of the two arrays)
+        const size_t bp = (size_t)(col - third) * nz;
+        double zon[P], pso[P];
+        load_levels<P>(zon, vdx_g + bp, lg, nz);
+        load_levels<P>(pso, bin_g + bp, lg, nz);
+#pragma unroll
+        for (int p = 0; p < P; ++p) wA[p] = (-zon[p] - pso[p]) * 1e6;
+      }
+    }
+  }
+  const bool wa_formed = (ops & (PM_OP_WA_PSI | PM_OP_WA_TWOBASIN)) != 0;  // (the slots held overturnings)
+  if (vdx_g && !wa_formed) load_levels<P>(vdx, vdx_g + base, lg, nz);
+  if (bin_g && !wa_formed) load_levels<P>(bin, bin_g + base, lg, nz);
   const bool do_conv = (flags & PM_COL_DO_CONV) != 0;
   const bool use_bzbot = (flags & PM_COL_BZBOT) != 0 && c.bzbot != nullptr;
   const double bs = c.bs[col];
@@ -1276,8 +1302,12 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
   const unsigned grid = (unsigned)((c.ncols + cols_per_block - 1) / cols_per_block);
   const bool weff_in = (ops & PM_OP_WEFF) != 0;  // wA holds wA - d(A kappa)/dz
   const bool contracted = (ops & PM_OP_CONTRACTED) != 0;  // tolerance mode (one wave per column)
-  const int wa_psi = ops & PM_OP_WA_PSI;  // the kernel forms wA from Psi_iso / Psi_SO (>= 3 steps)
-  ops &= ~(PM_OP_WEFF | PM_OP_CONTRACTED | PM_OP_WA_PSI);
+  // the kernel forms wA from Psi_iso / Psi_SO, or from the two-basin driver's overturnings (>= 3 steps)
+  const int wa_psi = ops & (PM_OP_WA_PSI | PM_OP_WA_TWOBASIN);
+  const double *const forcing2 = (ops & PM_OP_WA_TWOBASIN) ? vdx : nullptr;  // (horadv's slot)
+  if (forcing2) vdx = nullptr;  // no horadv with that modifier: the launch conditions below
+  ops &= ~(PM_OP_WEFF | PM_OP_CONTRACTED | PM_OP_WA_PSI | PM_OP_WA_TWOBASIN);
+  const double *const vk = forcing2 ? forcing2 : vdx;  // what the PLAIN kernels get in that slot
   if constexpr (G == 64 && P <= 4) {
     const int cpw = stream_cols_per_wave(c.ncols);
     if (nsteps < 3 && ops == PM_OP_TIMESTEP && !vdx && cpw >= 2) {
@@ -1402,7 +1432,7 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
   }
   if constexpr (G == 64 && P <= 4) {
     if (contracted && nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx) {
-      hipLaunchKernelGGL((k_column_steps<G, P, 4, true>), dim3(grid), dim3(256), 0, st, c, wA, vdx,
+      hipLaunchKernelGGL((k_column_steps<G, P, 4, true>), dim3(grid), dim3(256), 0, st, c, wA, vk,
                          bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
       PM_HIP(hipGetLastError());
       return PM_OK;
@@ -1418,17 +1448,17 @@ int launch_column_steps(const pm_columns &c, const double *wA, const double *vdx
       }();
       if ((c.reserved & PM_COLS_DIV3_PROVEN) != 0)  // (the caller's pm_div3_proven verdict)
         hipLaunchKernelGGL((k_column_steps<G, P, 6, true, true>), dim3(grid), dim3(256), lds_pad, st, c, wA,
-                           vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
+                           vk, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
       else
         hipLaunchKernelGGL((k_column_steps<G, P, 2, true, true>), dim3(grid), dim3(256), lds_pad, st, c, wA,
-                           vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
+                           vk, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
       launched = true;
     }
   }
   if (launched) {
   } else if (nsteps >= 3 && ops == PM_OP_TIMESTEP && !vdx)
     hipLaunchKernelGGL((k_column_steps<G, P, 2, true>), dim3(grid), dim3(256), 0, st, c, wA,
-                       vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
+                       vk, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0) | wa_psi);
   else if (nsteps >= 3)
     hipLaunchKernelGGL((k_column_steps<G, P, 1, false>), dim3(grid), dim3(256), 0, st, c, wA,
                        vdx, bin, dt, nsteps, ops | (weff_in ? PM_OP_WEFF : 0));

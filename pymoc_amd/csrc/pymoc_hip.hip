@@ -531,7 +531,7 @@ int pm_column_kernel_name(int32_t ncols, int32_t nz, int32_t lanes_per_col, int3
   const int rc = column_shape(ncols, nz, lanes_per_col, &G, &P);
   if (rc != PM_OK) return rc;
   const bool plain =
-      (ops & ~(PM_OP_WEFF | PM_OP_CONTRACTED | PM_OP_WA_PSI)) == PM_OP_TIMESTEP && !has_horadv;
+      (ops & ~(PM_OP_WEFF | PM_OP_CONTRACTED | PM_OP_WA_PSI | PM_OP_WA_TWOBASIN)) == PM_OP_TIMESTEP && !has_horadv;
   if (G == 64 && P <= 4 && nsteps < 3 && plain && stream_cols_per_wave(ncols) >= 2)
     snprintf(name, name_len, "k_column_stream<%d>", P);  // (+ ring depth / affine-kappa variants)
   else if (G == 64 && P <= 4 && nsteps >= 3 && plain && (ops & PM_OP_CONTRACTED))
@@ -554,9 +554,14 @@ int pm_column_steps(const pm_columns *cols, const double *wA, const double *vdx_
   PM_REQUIRE(c.z && c.b && c.kappa && c.area && c.dAkappa && c.bs && c.bbot && c.N2min,
              "pm_columns has a NULL required pointer");
   PM_REQUIRE(nsteps >= 0, "nsteps < 0");
-  PM_REQUIRE((ops & ~(PM_OP_TIMESTEP | PM_OP_WEFF | PM_OP_CONTRACTED | PM_OP_WA_PSI)) == 0,
+  PM_REQUIRE((ops & ~(PM_OP_TIMESTEP | PM_OP_WEFF | PM_OP_CONTRACTED | PM_OP_WA_PSI | PM_OP_WA_TWOBASIN)) == 0,
              "unknown op bits 0x%x", ops);
-  if (ops & PM_OP_WA_PSI) {
+  if (ops & PM_OP_WA_TWOBASIN) {
+    PM_REQUIRE(vdx_in && b_in && !(ops & (PM_OP_WEFF | PM_OP_WA_PSI)) &&
+                   (ops & PM_OP_TIMESTEP) == PM_OP_TIMESTEP && nsteps >= 3 && c.ncols % 3 == 0,
+               "PM_OP_WA_TWOBASIN: plain timesteps (>= 3 per launch) of a three-column ensemble, the "
+               "three overturning arrays given, no PM_OP_WEFF / PM_OP_WA_PSI");
+  } else if (ops & PM_OP_WA_PSI) {
     PM_REQUIRE(!vdx_in && !(ops & PM_OP_WEFF) && (ops & PM_OP_TIMESTEP) == PM_OP_TIMESTEP &&
                    nsteps >= 3 && (c.ncols & 1) == 0,
                "PM_OP_WA_PSI: plain timesteps (>= 3 per launch) of a two-column ensemble, no "

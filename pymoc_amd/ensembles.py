@@ -644,9 +644,10 @@ class TwoBasinEnsemble(object):
   An update (:111-122) is four independent solves of the columns' current profiles:
   {SO_Atl.solve, AMOC.solve / Psibz} and {SO_Pac.solve, ZOC.solve / Psibz}.  Each pair is ONE
   launch (pm_so_tw_update: Psi_SO.solve and the thermal wind of a member by one wavefront) and
-  the two pairs run SIDE BY SIDE on two streams (`overlap_updates`), joined by an event before
-  the forcing kernel (:103-105) -- the same device functions as four separate launches,
-  bit-identical results.
+  the two pairs run one after the other, or SIDE BY SIDE on two streams (`overlap_updates=True`),
+  joined by an event; the forcing of the columns (:103-105) is formed by the column kernel itself
+  from the overturnings (PM_OP_WA_TWOBASIN) -- the same device functions and operations as four
+  separate launches and a forcing kernel, bit-identical results.
   `comm`, `n_total`, `diag_iters`, `keep_history`, `gather`, `gather_overlap`: as for
   TwoColEnsemble; the exchanged fields are what the script samples every `plot_iters` steps
   (:124-133): the three columns' b and the four overturnings.  `arith="contracted"`: the columns
@@ -655,16 +656,18 @@ class TwoBasinEnsemble(object):
   FIELDS = ("b_Atl", "b_north", "b_Pac", "Psi_AMOC", "Psi_ZOC", "Psi_SO_Atl", "Psi_SO_Pac")
 
   def __init__(self, cfg, stream=None, lanes_per_col=0, comm=None, n_total=None,
-               diag_iters=None, keep_history=False, arith="exact", overlap_updates=True,
+               diag_iters=None, keep_history=False, arith="exact", overlap_updates=False,
                gather="all", gather_overlap=True, use_graph=True):
     if arith not in ("exact", "contracted"):
       raise ValueError("arith must be 'exact' or 'contracted'")
-    # `use_graph`: a whole interval (MOC_up_iters column steps, the two update pairs on their two
-    # streams, the forcing kernel: 4 launches of 4-20 us each and three event operations) is
-    # captured once into a hipGraph and replayed -- at 2048 members the interval is bound by the
-    # host's launch rate otherwise (70.6 -> 65.5 us per interval).  Off while a LaunchTimer is
-    # attached.  (Both pairs as the halves of ONE launch instead of two streams: 33 us against
-    # 19 us for one pair, the same 65.5 us per interval -- not kept.)
+    # Measured at 2048 members (profiles/r05/probe_c6_modes.py, us per interval of 24 steps):
+    #   the two update pairs one after the other on ONE stream, the forcing formed by the column
+    #   kernel (PM_OP_WA_TWOBASIN): 58.2 -- the default;  ... with pm_twobasin_forcing: 63.8;
+    #   the pairs side by side on two streams (`overlap_updates=True`; fork / join events):
+    #   66-78, 64-70 replayed from a hipGraph (`use_graph`: a whole interval captured once; only
+    #   with overlap_updates, off while a LaunchTimer is attached).  With the round-5 thermal wind
+    #   a pair is 17 us: the events cost more than the overlap gives.  (Both pairs as the halves
+    #   of ONE launch: 33 us against 2 x 17 -- not kept.)
     self._use_graph, self._graph = bool(use_graph), None
     z, y = cfg['z'], cfg['y']
     nz, ny = z.size, y.size
@@ -689,6 +692,13 @@ class TwoBasinEnsemble(object):
     so = dict(tau=cfg['tau'], KGM=cfg['K'], f=cfg['f_SO'], stream=stream, z_dev=zd)
     self.so_atl = PsiSOBatch(z, y, n, L=cfg['L_Atl'], **so)
     self.so_pac = PsiSOBatch(z, y, n, L=cfg['L_Pac'], **so)
+    # the two sectors' Psi_SO in ONE array (rows [0, n) Atlantic, [n, 2n) Pacific): with the two
+    # thermal winds' psibz arrays that is what the column kernel forms its forcing from
+    # (PM_OP_WA_TWOBASIN) -- no forcing launch between an update and the steps that follow it
+    self._so_psi = DeviceArray.zeros((2 * n, nz), stream=stream)
+    self.so_atl.Psi, self.so_pac.Psi = self._so_psi.view(0, n), self._so_psi.view(n, n)
+    self._forcing_in_k1 = True
+    self._wA_fresh = False  # does self.wA hold the forcing of the last update?
     self.bs_SO = DeviceArray.from_host(_rows(cfg['bs_SO'], n, ny) if np.ndim(cfg['bs_SO']) == 1
                                        else cfg['bs_SO'], stream=stream)
     self.wA = DeviceArray.zeros((3 * n, nz), stream=stream)
@@ -751,11 +761,31 @@ class TwoBasinEnsemble(object):
     else:
       self._solve_pair(self.so_atl, self.amoc, bA, bA, bN, self.stream, "atl")
       self._solve_pair(self.so_pac, self.zoc, bP, bA, bP, self.stream, "pac")
+    self._wA_fresh = False
+    if not self._forcing_in_k1:
+      self._form_forcing()
+
+  def _form_forcing(self):
+    """wA of the three columns as an array (:103-105; launches of 1-2 steps, and
+    `_forcing_in_k1 = False`): pm_twobasin_forcing."""
+    from ._lib import check, lib
     w = self.wA.ptr
     check(lib.pm_twobasin_forcing(self.n, self.nz, self.amoc.psibz1.ptr, self.zoc.psibz1.ptr,
                                   self.so_atl.Psi.ptr, self.amoc.psibz2.ptr,
                                   self.zoc.psibz2.ptr, self.so_pac.Psi.ptr, w, w + self._off,
                                   w + 2 * self._off, _sh(self.stream)))
+    self._wA_fresh = True
+
+  def _steps(self, n):
+    """n column steps under the forcing of the last update: formed by the column kernel itself
+    (>= 3 steps per launch) or taken from the array."""
+    if self._forcing_in_k1 and n >= 3:
+      self.cols.steps(None, self.dt, n, lanes_per_col=self.lanes, arith=self.arith,
+                      twobasin_forcing=(self.amoc.psibz, self.zoc.psibz, self._so_psi))
+      return
+    if not self._wA_fresh:
+      self._form_forcing()
+    self.cols.steps(self.wA, self.dt, n, lanes_per_col=self.lanes, arith=self.arith)
 
   def run(self, nsteps):
     remaining = int(nsteps)
@@ -768,7 +798,7 @@ class TwoBasinEnsemble(object):
         from .device import Graph
         if self._graph is None:
           with Graph.capture(self.stream) as cap:
-            self.cols.steps(self.wA, self.dt, n, lanes_per_col=self.lanes, arith=self.arith)
+            self._steps(n)
             self._update()
           self._graph = cap.graph
         self._graph.launch(self.stream)
@@ -779,7 +809,7 @@ class TwoBasinEnsemble(object):
         continue
       with launch_span(self.timer, "k_column_steps" if n >= 3 else "k_column_steps_short",
                        self.stream):
-        self.cols.steps(self.wA, self.dt, n, lanes_per_col=self.lanes, arith=self.arith)
+        self._steps(n)
       self.ii += n
       remaining -= n
       if (self.ii - 1) % self.M == 0:

@@ -46,16 +46,22 @@ def test_twobasin_update_pairs_side_by_side_equal_four_launches(gpu):
   of the seven sampled fields at the driver's cadence."""
   c = configs.config_twobasin(N=96)
   s = gpu.Stream()
-  a = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48)  # whole intervals replayed
-  assert a._use_graph                                                      # from a hipGraph
-  a2 = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48, use_graph=False)
-  b = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48, overlap_updates=False)
+  # default: the pairs one after the other, the forcing formed by the column kernel
+  a = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48)
+  assert a._forcing_in_k1 and not a._overlap
+  # the pairs on two streams, whole intervals replayed from a hipGraph
+  a2 = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48, overlap_updates=True)
+  # ... eagerly, and the forcing by pm_twobasin_forcing (round 5's first form)
+  b = gpu.TwoBasinEnsemble(c, stream=s, keep_history=True, diag_iters=48, overlap_updates=True,
+                           use_graph=False)
+  b._forcing_in_k1 = False
   d = gpu.TwoBasinEnsemble(c, keep_history=True, diag_iters=48, overlap_updates=False)
   d._pairs = False  # four separate launches (what round 4 ran)
+  d._forcing_in_k1 = False
   for e in (a, a2, b, d):
     e.run(130)
     e.gather_diagnostics()
-  assert a._graph is not None and a2._graph is None
+  assert a2._graph is not None and a._graph is None and b._graph is None
   sa = a.state()
   for e in (a2, b, d):
     st = e.state()
