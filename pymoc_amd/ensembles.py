@@ -146,7 +146,7 @@ class TwoColEnsemble(object):
   mapped to isopycnal space every MOC_up_iters steps."""
 
   def __init__(self, cfg, stream=None, lanes_per_col=0, comm=None, n_total=None,
-               diag_iters=None, keep_history=False, arith="exact", overlap_updates=True,
+               diag_iters=None, keep_history=False, arith="exact", overlap_updates=False,
                fused_run=None, gather="all", gather_overlap=True):
     """`fused_run`: carry the members through whole stretches of the loop -- many [refresh the
     overturning, MOC_up_iters steps] intervals -- in ONE launch of the persistent per-member
@@ -154,8 +154,11 @@ class TwoColEnsemble(object):
     functions as the launch sequence, bit-identical results; needs: no SO channel, exact
     arithmetic, Area constant in z, the phases' LDS within 160 KB.  None = off (measured slower
     than the launch sequence on config 3: DESIGN.md section 6).
-    `overlap_updates`: with an SO channel, Psi_SO.solve and the thermal wind of an update run
-    side by side on two streams (bit-identical results; see `_update`).
+    `overlap_updates=True`: with an SO channel, Psi_SO.solve and the thermal wind of an update run
+    side by side on two streams (bit-identical results; see `_update`).  Round 3's default; since
+    the round-5 thermal wind (37 us beside a Psi_SO.solve of 113) the fork / join events cost what
+    the overlap gives: config 4 203-204 us per interval side by side, 194-204 one after the other
+    (profiles/r05/c4_modes.log).
     `comm` (a pymoc_amd.sharding communicator) makes this rank's members one shard of an
     `n_total`-member ensemble: stepping is unchanged (members never interact) and
     {b_basin, b_north, Psi, Psi_SO} are all-gathered on device buffers every `diag_iters`

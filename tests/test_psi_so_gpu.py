@@ -455,7 +455,7 @@ def test_twocol_so_updates_side_by_side_equal_serial_updates(gpu, arith):
   to the serial update with the thermal-wind launch's wA1 / wA2 epilogue, over whole and split
   intervals (launches of 1-2 steps take the forcing from pm_twocol_forcing)."""
   cfg = configs.config4(N=96)
-  a = gpu.TwoColEnsemble(cfg, arith=arith)
+  a = gpu.TwoColEnsemble(cfg, arith=arith, overlap_updates=True)
   b = gpu.TwoColEnsemble(cfg, arith=arith, overlap_updates=False)
   assert a._overlap and not b._overlap
   for n in (1, 2, 23, 24, 25, 2, 1, 70):
